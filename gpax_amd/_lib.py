@@ -1,0 +1,298 @@
+"""
+ctypes binding of libgpx (include/gpx.h) and the `Engine` object the model classes drive.
+
+There is NO CPU fallback in this package: if the shared library is missing or no gfx950 device
+is present, constructing an Engine raises.  (tests/ inject a checker-backed engine to exercise the
+host-side samplers on a CPU-only machine; the product never does.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+KERNEL_KINDS = {"RBF": 0, "Matern": 1}
+MAX_DIM = 16
+
+PROF_GEMM_TRAILING, PROF_GEMM_OTHER, PROF_POTF2, PROF_GRAM = 0, 1, 2, 3
+STAGE_GRAM, STAGE_POTRF, STAGE_FITSTEP, STAGE_POSTERIOR, STAGE_PREDICT = 0, 1, 2, 3, 4
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgpx.so")
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class GpxError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """dlopen libgpx.so (built in-tree by `__graft_entry__.build()` / gpax_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise GpxError(
+            f"libgpx.so not found at {_LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C gpax_amd/csrc`). gpax_amd has no CPU fallback."
+        )
+    lib = C.CDLL(_LIB_PATH)
+    vp = C.c_void_p
+    sig = {
+        "gpx_init": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "gpx_destroy": (None, [vp]),
+        "gpx_last_error": (C.c_char_p, [vp]),
+        "gpx_device_info": (C.c_int, [vp, C.c_char_p, C.c_int, _ip, C.POINTER(C.c_int64), _ip]),
+        "gpx_synchronize": (C.c_int, [vp]),
+        "gpx_gram": (C.c_int, [vp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_double,
+                               C.c_double, C.c_int, _dp]),
+        "gpx_set_train": (C.c_int, [vp, _dp, C.c_int, C.c_int]),
+        "gpx_factor": (C.c_int, [vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _ip]),
+        "gpx_lml_grad": (C.c_int, [vp, _dp, _dp, _dp, _dp]),
+        "gpx_posterior": (C.c_int, [vp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]),
+        "gpx_mvn_draw": (C.c_int, [vp, _dp, C.c_int, _dp, _ip]),
+        "gpx_predict_sweep": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _dp,
+                                        C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip]),
+        "gpx_profile_enable": (C.c_int, [vp, C.c_int]),
+        "gpx_profile_reset": (C.c_int, [vp]),
+        "gpx_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64), _dp, _dp]),
+        "gpx_time_stage": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
+        "gpx_mfma_f64_peak": (C.c_int, [vp, _dp]),
+        "gpx_gemm_nt": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_double, _dp]),
+        "gpx_potrf": (C.c_int, [vp, C.c_int, _dp, _dp, _ip]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "gpx_init gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train "
+    "gpx_factor gpx_lml_grad gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_profile_enable "
+    "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_mfma_f64_peak gpx_gemm_nt gpx_potrf"
+).split()
+
+
+def _f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def kernel_kind(name) -> int:
+    try:
+        return KERNEL_KINDS[name]
+    except (KeyError, TypeError):
+        raise NotImplementedError(
+            f"kernel {name!r} has no MI355X path; the HIP Gram kernels cover {sorted(KERNEL_KINDS)}") from None
+
+
+def broadcast_lengthscale(k_length, d: int) -> np.ndarray:
+    """k_length may be scalar, (d,), (1,), (1,1), (1,d) — gpax/tests/test_kernels.py:19,38,
+    gpax/tests/test_vigp.py:73-75."""
+    ell = np.asarray(k_length, dtype=np.float64).reshape(-1)
+    if ell.size == 1:
+        ell = np.full(d, ell[0])
+    if ell.size != d:
+        raise ValueError(f"k_length has {ell.size} entries for input_dim {d}")
+    return np.ascontiguousarray(ell)
+
+
+class Engine:
+    """One libgpx context = one GPU.  Thin, stateful mirror of the C-ABI."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        rc = self._lib.gpx_init(int(device), C.byref(self._ctx))
+        if rc != 0:
+            msg = self._lib.gpx_last_error(self._ctx).decode() if self._ctx else "gpx_init failed"
+            if self._ctx:
+                self._lib.gpx_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+            raise GpxError(f"gpx_init(device={device}) failed: {msg}. gpax_amd needs an MI355X (gfx950); "
+                           "there is no CPU fallback.")
+        self.device = int(device)
+        self.N = 0
+        self.d = 0
+        self.M = 0
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise GpxError(f"{what} failed ({rc}): {self._lib.gpx_last_error(self._ctx).decode()}")
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.gpx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cu, hbm, clk = C.c_int(), C.c_int64(), C.c_int()
+        self._check(self._lib.gpx_device_info(self._ctx, name, 256, C.byref(cu), C.byref(hbm), C.byref(clk)),
+                    "gpx_device_info")
+        return {"name": name.value.decode(), "num_cu": cu.value, "hbm_bytes": hbm.value, "clock_khz": clk.value}
+
+    def synchronize(self):
+        self._check(self._lib.gpx_synchronize(self._ctx), "gpx_synchronize")
+
+    # -- Gram ---------------------------------------------------------------------------------
+    def gram(self, kind: int, X, Z, ell, scale: float, diag_add: float, add_diag: bool) -> np.ndarray:
+        X = _f64(X)
+        Z = _f64(Z)
+        n, d = X.shape
+        m = Z.shape[0]
+        ell = broadcast_lengthscale(ell, d)
+        out = np.empty((n, m), dtype=np.float64)
+        self._check(self._lib.gpx_gram(self._ctx, kind, _ptr(X), n, _ptr(Z), m, d, _ptr(ell), float(scale),
+                                       float(diag_add), int(bool(add_diag)), _ptr(out)), "gpx_gram")
+        return out
+
+    # -- exact GP -----------------------------------------------------------------------------
+    def set_train(self, X):
+        X = _f64(X)
+        self.N, self.d = X.shape
+        self._check(self._lib.gpx_set_train(self._ctx, _ptr(X), self.N, self.d), "gpx_set_train")
+
+    def factor(self, kind: int, ell, scale: float, noise: float, jitter: float, yres) -> Tuple[float, int]:
+        ell = broadcast_lengthscale(ell, self.d)
+        yres = _f64(yres, (self.N,))
+        lml, info = C.c_double(), C.c_int()
+        self._check(self._lib.gpx_factor(self._ctx, kind, _ptr(ell), float(scale), float(noise), float(jitter),
+                                         _ptr(yres), C.byref(lml), C.byref(info)), "gpx_factor")
+        return lml.value, info.value
+
+    def lml_grad(self):
+        g_ell = np.empty(self.d)
+        g_scale, g_noise = C.c_double(), C.c_double()
+        alpha = np.empty(self.N)
+        self._check(self._lib.gpx_lml_grad(self._ctx, _ptr(g_ell), C.byref(g_scale), C.byref(g_noise),
+                                           _ptr(alpha)), "gpx_lml_grad")
+        return g_ell, g_scale.value, g_noise.value, alpha
+
+    def posterior(self, Xnew, noise_p: float, jitter: float, want_cov: bool = True, want_var: bool = False):
+        Xnew = _f64(Xnew)
+        M = Xnew.shape[0]
+        self.M = M
+        mean = np.empty(M)
+        cov = np.empty((M, M)) if want_cov else None
+        var = np.empty(M) if want_var else None
+        self._check(self._lib.gpx_posterior(self._ctx, _ptr(Xnew), M, float(noise_p), float(jitter), _ptr(mean),
+                                            _ptr(cov), _ptr(var)), "gpx_posterior")
+        return mean, cov, var
+
+    def mvn_draw(self, eps) -> Tuple[np.ndarray, int]:
+        eps = _f64(eps)
+        n = eps.shape[0]
+        out = np.empty((n, self.M))
+        info = C.c_int()
+        self._check(self._lib.gpx_mvn_draw(self._ctx, _ptr(eps), n, _ptr(out), C.byref(info)), "gpx_mvn_draw")
+        return out, info.value
+
+    def predict_sweep(self, kind: int, ells, scales, noises, yres, Xnew, noiseless: bool, jitter: float,
+                      eps: Optional[np.ndarray]):
+        ells = _f64(ells)
+        S = ells.shape[0]
+        ells = _f64(ells, (S, self.d))
+        scales = _f64(scales, (S,))
+        noises = _f64(noises, (S,))
+        yres = _f64(yres)
+        stride = 0 if yres.ndim == 1 else self.N
+        yres = yres.reshape(-1)
+        Xnew = _f64(Xnew)
+        M = Xnew.shape[0]
+        self.M = M
+        n = 0 if eps is None else int(np.asarray(eps).shape[1])
+        eps_c = None if n == 0 else _f64(eps, (S, n, M))
+        means = np.empty((S, M))
+        samples = np.empty((S, n, M))
+        infos = np.zeros(S, dtype=np.int32)
+        self._check(self._lib.gpx_predict_sweep(
+            self._ctx, kind, S, _ptr(ells), _ptr(scales), _ptr(noises), _ptr(yres), stride, _ptr(Xnew), M,
+            int(bool(noiseless)), float(jitter), _ptr(eps_c), n, _ptr(means),
+            _ptr(samples) if n else None, infos.ctypes.data_as(_ip)), "gpx_predict_sweep")
+        return means, samples, infos
+
+    # -- measurement ----------------------------------------------------------------------------
+    def profile_enable(self, on: bool):
+        self._check(self._lib.gpx_profile_enable(self._ctx, int(on)), "gpx_profile_enable")
+
+    def profile_reset(self):
+        self._check(self._lib.gpx_profile_reset(self._ctx), "gpx_profile_reset")
+
+    def profile_read(self, cls: int):
+        n, ms, work = C.c_int64(), C.c_double(), C.c_double()
+        self._check(self._lib.gpx_profile_read(self._ctx, cls, C.byref(n), C.byref(ms), C.byref(work)),
+                    "gpx_profile_read")
+        return n.value, ms.value, work.value
+
+    def time_stage(self, stage: int, reps: int) -> float:
+        ms = C.c_double()
+        self._check(self._lib.gpx_time_stage(self._ctx, stage, reps, C.byref(ms)), "gpx_time_stage")
+        return ms.value
+
+    def mfma_f64_peak(self) -> float:
+        tf = C.c_double()
+        self._check(self._lib.gpx_mfma_f64_peak(self._ctx, C.byref(tf)), "gpx_mfma_f64_peak")
+        return tf.value
+
+    # -- unit-test entry points -------------------------------------------------------------------
+    def gemm_nt(self, A, B, alpha=1.0, beta=0.0, Cin=None) -> np.ndarray:
+        A = _f64(A)
+        B = _f64(B)
+        M, K = A.shape
+        N = B.shape[0]
+        Cm = np.zeros((M, N)) if Cin is None else _f64(Cin).copy()
+        self._check(self._lib.gpx_gemm_nt(self._ctx, M, N, K, float(alpha), _ptr(A), _ptr(B), float(beta),
+                                          _ptr(Cm)), "gpx_gemm_nt")
+        return Cm
+
+    def potrf(self, A) -> Tuple[np.ndarray, int]:
+        A = _f64(A)
+        n = A.shape[0]
+        L = np.empty((n, n))
+        info = C.c_int()
+        self._check(self._lib.gpx_potrf(self._ctx, n, _ptr(A), _ptr(L), C.byref(info)), "gpx_potrf")
+        return L, info.value
+
+
+_default_engine: Optional[Engine] = None
+
+
+def get_engine(device: Optional[int] = None) -> Engine:
+    """Process-wide engine (one GPU).  `device` defaults to $LOCAL_RANK or 0."""
+    global _default_engine
+    if device is None:
+        device = int(os.environ.get("GPX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if _default_engine is None or _default_engine.device != device:
+        _default_engine = Engine(device)
+    return _default_engine
+
+
+def set_engine(engine) -> None:
+    """Install an engine object (tests use this to inject a checker-backed engine on CPU)."""
+    global _default_engine
+    _default_engine = engine

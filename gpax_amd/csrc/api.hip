@@ -1,0 +1,706 @@
+// api.hip — the C-ABI of libgpx (declared in include/gpx.h): host orchestration of the
+// device-resident exact-GP pipeline.  Each entry point cites the gpax interface it replaces in
+// gpx.h; this file only sequences kernels on the context's stream and moves data H<->D.
+#include "common.h"
+
+using namespace gpx;
+
+namespace {
+
+constexpr int SC_QUAD = 0, SC_SUMLOG = 1, SC_GRAD = 2; // doubles in ctx->scal
+constexpr int SC_INT_OFF = 512;                         // ints start at byte 2048
+constexpr int SI_TRAIN = 0, SI_COV = 1;
+constexpr double LOG_2PI = 1.83787706640934548356;
+
+inline int* sc_int(gpx_ctx* ctx) { return ctx->scal.i() + SC_INT_OFF; }
+
+int ensure(gpx_ctx* ctx, DevBuf& b, size_t bytes) {
+  hipError_t e = b.ensure(bytes);
+  if (e != hipSuccess) return fail(ctx, "hipMalloc", e, __FILE__, __LINE__);
+  return 0;
+}
+
+int set_theta(gpx_ctx* ctx, int kind, int d, const double* ell, double scale) {
+  if (kind != GPX_KERNEL_RBF && kind != GPX_KERNEL_MATERN52) return bad_arg(ctx, "kernel kind");
+  if (d < 1 || d > GPX_MAX_DIM) return bad_arg(ctx, "input dimension must be 1..16");
+  ctx->theta.kind = kind;
+  ctx->theta.d = d;
+  for (int c = 0; c < GPX_MAX_DIM; ++c) ctx->theta.inv_ell[c] = (c < d) ? 1.0 / ell[c] : 0.0;
+  ctx->theta.scale = scale;
+  return 0;
+}
+
+double kdiag_value(const KernelParams& kp) {
+  if (kp.kind == GPX_KERNEL_RBF) return kp.scale;
+  const double r = std::sqrt(MATERN_EPS);
+  const double s5r = SQRT5 * r;
+  return kp.scale * (1.0 + s5r) * std::exp(-s5r);
+}
+
+// Gram (lower tiles) + augmentation + blocked Cholesky + lml reductions; all async.
+int dev_factor(gpx_ctx* ctx) {
+  const int N = ctx->N, Np = ctx->Np;
+  double* K = ctx->K.d();
+  GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->X.d(), N, N, ctx->X.d(), N, Np,
+                             ctx->noise + ctx->jitter, 1, 1, K, ctx->ldk));
+  GPX_TRY(launch_augment(ctx, K, ctx->ldk, N, Np, ctx->yres.d()));
+  GPX_HIP(ctx, hipMemsetAsync(sc_int(ctx) + SI_TRAIN, 0, sizeof(int), ctx->stream));
+  GPX_TRY(potrf_lower(ctx, K, ctx->ldk, Np, ctx->Linv.d(), sc_int(ctx) + SI_TRAIN));
+  GPX_TRY(launch_lml_terms(ctx, K, ctx->ldk, N, ctx->scal.d() + SC_QUAD));
+  ctx->factored = true;
+  ctx->have_post = false;
+  return 0;
+}
+
+// L^-T (upper) into W, K^-1 = L^-T L^-1 (lower) over K, alpha = L^-T w, gradient contraction.
+int dev_grad(gpx_ctx* ctx) {
+  const int N = ctx->N;
+  const int nt = (N + TILE - 1) / TILE; // tiles that carry real rows (excludes a pure aug tile)
+  const int n128 = nt * TILE;
+  GPX_TRY(ensure(ctx, ctx->W, (size_t)ctx->Np * ctx->ldk * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->alpha, (size_t)ctx->Np * sizeof(double)));
+  double* W = ctx->W.d();
+  double* K = ctx->K.d();
+  GPX_TRY(launch_set_identity(ctx, W, ctx->ldk, n128));
+  GPX_TRY(trsm_right_lt(ctx, W, ctx->ldk, nt, K, ctx->ldk, ctx->Linv.d(), nt, 1));
+  // alpha_i = sum_{k>=i} W[i][k] w[k], w = row N of the augmented factor (read before K is
+  // overwritten by K^-1)
+  GPX_TRY(launch_rowdot(ctx, W, ctx->ldk, N, N, K + (int64_t)N * ctx->ldk, 0.0, ctx->alpha.d(),
+                        nullptr, 1));
+  {
+    GemmArgs g{};
+    g.A = W;
+    g.lda = ctx->ldk;
+    g.B = W;
+    g.ldb = ctx->ldk;
+    g.C = K;
+    g.ldc = ctx->ldk;
+    g.K = n128;
+    g.alpha = 1.0;
+    g.beta = 0.0;
+    g.lower = 1;
+    g.ktri = 1;
+    const double n = (double)n128;
+    GPX_TRY(launch_gemm_nt(ctx, g, nt, nt, 0, GPX_PROF_GEMM_OTHER, n * n * n / 3.0));
+  }
+  const int nt64 = (N + 63) / 64;
+  GPX_TRY(ensure(ctx, ctx->part, (size_t)nt64 * (nt64 + 1) / 2 * (GPX_MAX_DIM + 2) * sizeof(double)));
+  int nblocks = 0;
+  GPX_TRY(launch_grad_contract(ctx, ctx->theta, ctx->X.d(), N, K, ctx->ldk, ctx->alpha.d(),
+                               ctx->part.d(), &nblocks));
+  GPX_TRY(launch_grad_reduce(ctx, ctx->part.d(), nblocks, ctx->d + 2, ctx->scal.d() + SC_GRAD));
+  ctx->factored = false; // K now holds K^-1
+  return 0;
+}
+
+int set_xnew(gpx_ctx* ctx, const double* Xnew, int M) {
+  if (M < 1) return bad_arg(ctx, "M must be >= 1");
+  ctx->M = M;
+  ctx->Mp = round_up(M, TILE);
+  ctx->ldv = pick_ld(ctx->Np);
+  ctx->ldc = pick_ld(ctx->Mp);
+  GPX_TRY(ensure(ctx, ctx->Xnew, (size_t)M * ctx->d * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->Vt, (size_t)ctx->Mp * ctx->ldv * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->mean, (size_t)ctx->Mp * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->var, (size_t)ctx->Mp * sizeof(double)));
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->Xnew.d(), Xnew, (size_t)M * ctx->d * sizeof(double),
+                              hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+// k_pX -> Vt = k_pX L^-T, mean = Vt w, var, and (optionally) cov = k_pp - Vt Vt^T.
+int dev_posterior(gpx_ctx* ctx, bool want_cov) {
+  const int N = ctx->N, M = ctx->M, Mp = ctx->Mp;
+  const int nt = (N + TILE - 1) / TILE;
+  const int mt = Mp / TILE;
+  const double* K = ctx->K.d();
+  double* Vt = ctx->Vt.d();
+  KernelParams kp = ctx->theta;
+  // k_pX = kernel(X_new, X_train, params, jitter=0.0): no diagonal term (gp.py:268)
+  GPX_TRY(launch_gram_padded(ctx, kp, ctx->Xnew.d(), M, Mp, ctx->X.d(), N, nt * TILE, 0.0, 0, 0, Vt,
+                             ctx->ldv));
+  GPX_TRY(trsm_right_lt(ctx, Vt, ctx->ldv, mt, K, ctx->ldk, ctx->Linv.d(), nt, 0));
+  const double kd = kdiag_value(kp) + ctx->noise_p + ctx->jitter;
+  GPX_TRY(launch_rowdot(ctx, Vt, ctx->ldv, M, N, K + (int64_t)N * ctx->ldk, kd, ctx->mean.d(),
+                        ctx->var.d(), 0));
+  ctx->cov_factored = false;
+  if (want_cov) {
+    GPX_TRY(ensure(ctx, ctx->Cov, (size_t)Mp * ctx->ldc * sizeof(double)));
+    const int ktot = nt * TILE;
+    const int lower_tiles = mt * (mt + 1) / 2;
+    int splits = (512 + lower_tiles - 1) / lower_tiles;
+    const int max_splits = ktot / 256 > 0 ? ktot / 256 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int kchunk = round_up((ktot + splits - 1) / splits, TILE);
+    splits = (ktot + kchunk - 1) / kchunk;
+    const int64_t ldp = ctx->ldc;
+    const int64_t stride = (int64_t)Mp * ldp;
+    GPX_TRY(ensure(ctx, ctx->SplitK, (size_t)splits * stride * sizeof(double)));
+    GemmArgs g{};
+    g.A = Vt;
+    g.lda = ctx->ldv;
+    g.B = Vt;
+    g.ldb = ctx->ldv;
+    g.C = ctx->SplitK.d();
+    g.ldc = ldp;
+    g.K = ktot;
+    g.alpha = 1.0;
+    g.beta = 0.0;
+    g.lower = 1;
+    g.kchunk = kchunk;
+    g.c_split_stride = stride;
+    const double m = (double)Mp;
+    GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, splits, GPX_PROF_GEMM_OTHER, m * (m + 1.0) * ktot));
+    GPX_TRY(launch_cov_finalize(ctx, kp, ctx->Xnew.d(), M, Mp, ctx->SplitK.d(), splits, stride, ldp,
+                                ctx->noise_p + ctx->jitter, ctx->Cov.d(), ctx->ldc));
+  }
+  ctx->have_post = want_cov;
+  return 0;
+}
+
+// chol(cov) (once per posterior) and draws = mean + eps Lc^T; eps already on device, padded.
+int dev_draw(gpx_ctx* ctx, int n_pad, int n) {
+  const int Mp = ctx->Mp, mt = Mp / TILE;
+  if (!ctx->cov_factored) {
+    GPX_TRY(ensure(ctx, ctx->CovLinv, (size_t)mt * TILE * TILE * sizeof(double)));
+    GPX_HIP(ctx, hipMemsetAsync(sc_int(ctx) + SI_COV, 0, sizeof(int), ctx->stream));
+    GPX_TRY(potrf_lower(ctx, ctx->Cov.d(), ctx->ldc, Mp, ctx->CovLinv.d(), sc_int(ctx) + SI_COV));
+    ctx->cov_factored = true;
+  }
+  GemmArgs g{};
+  g.A = ctx->eps.d();
+  g.lda = ctx->ldc;
+  g.B = ctx->Cov.d();
+  g.ldb = ctx->ldc;
+  g.C = ctx->draws.d();
+  g.ldc = ctx->ldc;
+  g.K = Mp;
+  g.alpha = 1.0;
+  g.beta = 0.0;
+  g.kupper = 1;
+  GPX_TRY(launch_gemm_nt(ctx, g, n_pad / TILE, mt, 0, GPX_PROF_GEMM_OTHER,
+                         2.0 * n_pad * (double)Mp * Mp / 2.0));
+  GPX_TRY(launch_add_mean(ctx, ctx->draws.d(), ctx->ldc, n, ctx->M, ctx->mean.d()));
+  return 0;
+}
+
+int upload_eps(gpx_ctx* ctx, const double* eps, int n, int* n_pad_out) {
+  const int n_pad = round_up(n, TILE);
+  *n_pad_out = n_pad;
+  GPX_TRY(ensure(ctx, ctx->eps, (size_t)n_pad * ctx->ldc * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->draws, (size_t)n_pad * ctx->ldc * sizeof(double)));
+  GPX_HIP(ctx, hipMemsetAsync(ctx->eps.d(), 0, (size_t)n_pad * ctx->ldc * sizeof(double), ctx->stream));
+  if (eps) {
+    GPX_HIP(ctx, hipMemcpy2DAsync(ctx->eps.d(), ctx->ldc * sizeof(double), eps,
+                                  (size_t)ctx->M * sizeof(double), (size_t)ctx->M * sizeof(double), n,
+                                  hipMemcpyHostToDevice, ctx->stream));
+  }
+  return 0;
+}
+
+void drain_profile(gpx_ctx* ctx) {
+  for (int c = 0; c < GPX_PROF_NCLASS; ++c) {
+    for (auto& pr : ctx->prof[c].pending) {
+      float ms = 0.f;
+      if (hipEventSynchronize(pr.second) == hipSuccess &&
+          hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess)
+        ctx->prof[c].ms += ms;
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+    ctx->prof[c].pending.clear();
+  }
+}
+
+} // namespace
+
+extern "C" {
+
+int gpx_init(int device, gpx_ctx** out) {
+  if (!out) return -1;
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  gpx_ctx* ctx = new gpx_ctx();
+  *out = ctx; // returned even on failure so the caller can read gpx_last_error
+  if (e != hipSuccess || count <= 0) {
+    ctx->err = std::string("no HIP device available: ") + hipGetErrorString(e);
+    return -2;
+  }
+  if (device < 0 || device >= count) {
+    ctx->err = "device ordinal out of range";
+    return -1;
+  }
+  GPX_HIP(ctx, hipSetDevice(device));
+  ctx->device = device;
+  GPX_HIP(ctx, hipGetDeviceProperties(&ctx->prop, device));
+  if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+    ctx->err = std::string("libgpx is built for gfx950 only; device is ") + ctx->prop.gcnArchName;
+    return -3;
+  }
+  GPX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  GPX_HIP(ctx, hipEventCreate(&ctx->ev0));
+  GPX_HIP(ctx, hipEventCreate(&ctx->ev1));
+  GPX_TRY(ensure(ctx, ctx->scal, 8192));
+  GPX_HIP(ctx, hipMemsetAsync(ctx->scal.p, 0, 8192, ctx->stream));
+  return 0;
+}
+
+void gpx_destroy(gpx_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->device >= 0) {
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    drain_profile(ctx);
+    DevBuf* bufs[] = {&ctx->X,    &ctx->K,   &ctx->W,       &ctx->Linv,   &ctx->yres, &ctx->scal,
+                      &ctx->part, &ctx->alpha, &ctx->Xnew,  &ctx->Vt,     &ctx->Cov,  &ctx->CovLinv,
+                      &ctx->SplitK, &ctx->mean, &ctx->var,  &ctx->eps,    &ctx->draws, &ctx->tA,
+                      &ctx->tB,   &ctx->tC};
+    for (DevBuf* b : bufs) b->release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  }
+  delete ctx;
+}
+
+const char* gpx_last_error(const gpx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int gpx_device_info(gpx_ctx* ctx, char* name, int name_len, int* num_cu, int64_t* hbm_bytes,
+                    int* clock_khz) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (name && name_len > 0) {
+    snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  }
+  if (num_cu) *num_cu = ctx->prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+  if (clock_khz) *clock_khz = ctx->prop.clockRate;
+  return 0;
+}
+
+int gpx_synchronize(gpx_ctx* ctx) {
+  if (!ctx || ctx->device < 0) return -1;
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int gpx_gram(gpx_ctx* ctx, int kind, const double* X, int n, const double* Z, int m, int d,
+             const double* ell, double scale, double diag_add, int add_diag, double* out) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (n < 0 || m < 0) return bad_arg(ctx, "negative size");
+  if (n == 0 || m == 0) return 0;
+  if (!X || !Z || !ell || !out) return bad_arg(ctx, "null pointer");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  KernelParams kp{};
+  {
+    KernelParams saved = ctx->theta;
+    GPX_TRY(set_theta(ctx, kind, d, ell, scale));
+    kp = ctx->theta;
+    ctx->theta = saved;
+  }
+  const int64_t ld = pick_ld(m);
+  GPX_TRY(ensure(ctx, ctx->tA, (size_t)n * d * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->tB, (size_t)m * d * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->tC, (size_t)n * ld * sizeof(double)));
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->tA.d(), X, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice,
+                              ctx->stream));
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->tB.d(), Z, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice,
+                              ctx->stream));
+  GPX_TRY(launch_gram(ctx, kp, ctx->tA.d(), n, ctx->tB.d(), m, diag_add, add_diag, 0, ctx->tC.d(), ld));
+  GPX_HIP(ctx, hipMemcpy2DAsync(out, (size_t)m * sizeof(double), ctx->tC.d(), ld * sizeof(double),
+                                (size_t)m * sizeof(double), n, hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int gpx_set_train(gpx_ctx* ctx, const double* X, int N, int d) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (!X) return bad_arg(ctx, "null X");
+  if (N < 1) return bad_arg(ctx, "N must be >= 1");
+  if (d < 1 || d > GPX_MAX_DIM) return bad_arg(ctx, "input dimension must be 1..16");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->N = N;
+  ctx->d = d;
+  ctx->Np = round_up(N + 1, TILE);
+  ctx->ldk = pick_ld(ctx->Np);
+  GPX_TRY(ensure(ctx, ctx->X, (size_t)N * d * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->K, (size_t)ctx->Np * ctx->ldk * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->Linv, (size_t)(ctx->Np / TILE) * TILE * TILE * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->yres, (size_t)N * sizeof(double)));
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->X.d(), X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice,
+                              ctx->stream));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->factored = false;
+  ctx->have_post = false;
+  return 0;
+}
+
+int gpx_factor(gpx_ctx* ctx, int kind, const double* ell, double scale, double noise,
+               double jitter, const double* yres, double* lml, int* info) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (ctx->N < 1) return bad_arg(ctx, "gpx_set_train must be called first");
+  if (!ell || !yres) return bad_arg(ctx, "null pointer");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  GPX_TRY(set_theta(ctx, kind, ctx->d, ell, scale));
+  ctx->noise = noise;
+  ctx->jitter = jitter;
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->yres.d(), yres, (size_t)ctx->N * sizeof(double),
+                              hipMemcpyHostToDevice, ctx->stream));
+  GPX_TRY(dev_factor(ctx));
+  double h[2];
+  int hinfo = 0;
+  GPX_HIP(ctx, hipMemcpyAsync(h, ctx->scal.d() + SC_QUAD, 2 * sizeof(double), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  GPX_HIP(ctx, hipMemcpyAsync(&hinfo, sc_int(ctx) + SI_TRAIN, sizeof(int), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // a failure at the augmentation pivot itself (order N + 1) is not a failure of K
+  if (hinfo > ctx->N) hinfo = 0;
+  if (info) *info = hinfo;
+  if (lml) {
+    *lml = (hinfo != 0) ? NAN : (-0.5 * h[0] - h[1] - 0.5 * ctx->N * LOG_2PI);
+  }
+  return 0;
+}
+
+int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* grad_noise,
+                 double* alpha) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (!ctx->factored) return bad_arg(ctx, "gpx_lml_grad must follow gpx_factor");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  GPX_TRY(dev_grad(ctx));
+  double h[GPX_MAX_DIM + 2];
+  GPX_HIP(ctx, hipMemcpyAsync(h, ctx->scal.d() + SC_GRAD, (ctx->d + 2) * sizeof(double),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  if (alpha) {
+    GPX_HIP(ctx, hipMemcpyAsync(alpha, ctx->alpha.d(), (size_t)ctx->N * sizeof(double),
+                                hipMemcpyDeviceToHost, ctx->stream));
+  }
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (grad_ell)
+    for (int c = 0; c < ctx->d; ++c) grad_ell[c] = h[c];
+  if (grad_scale) *grad_scale = h[ctx->d];
+  if (grad_noise) *grad_noise = h[ctx->d + 1];
+  return 0;
+}
+
+int gpx_posterior(gpx_ctx* ctx, const double* Xnew, int M, double noise_p, double jitter,
+                  double* mean, double* cov, double* var) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (!ctx->factored) return bad_arg(ctx, "gpx_posterior must follow gpx_factor");
+  if (!Xnew) return bad_arg(ctx, "null Xnew");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  GPX_TRY(set_xnew(ctx, Xnew, M));
+  ctx->noise_p = noise_p;
+  const double saved_jitter = ctx->jitter;
+  ctx->jitter = jitter;
+  int rc = dev_posterior(ctx, cov != nullptr);
+  ctx->jitter = saved_jitter;
+  GPX_TRY(rc);
+  if (mean)
+    GPX_HIP(ctx, hipMemcpyAsync(mean, ctx->mean.d(), (size_t)M * sizeof(double), hipMemcpyDeviceToHost,
+                                ctx->stream));
+  if (var)
+    GPX_HIP(ctx, hipMemcpyAsync(var, ctx->var.d(), (size_t)M * sizeof(double), hipMemcpyDeviceToHost,
+                                ctx->stream));
+  if (cov)
+    GPX_HIP(ctx, hipMemcpy2DAsync(cov, (size_t)M * sizeof(double), ctx->Cov.d(),
+                                  ctx->ldc * sizeof(double), (size_t)M * sizeof(double), M,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int gpx_mvn_draw(gpx_ctx* ctx, const double* eps, int n, double* out, int* info) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (!ctx->have_post) return bad_arg(ctx, "gpx_mvn_draw must follow gpx_posterior with cov");
+  if (n < 1 || !eps || !out) return bad_arg(ctx, "bad draw arguments");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  int n_pad = 0;
+  GPX_TRY(upload_eps(ctx, eps, n, &n_pad));
+  GPX_TRY(dev_draw(ctx, n_pad, n));
+  int hinfo = 0;
+  GPX_HIP(ctx, hipMemcpy2DAsync(out, (size_t)ctx->M * sizeof(double), ctx->draws.d(),
+                                ctx->ldc * sizeof(double), (size_t)ctx->M * sizeof(double), n,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(ctx, hipMemcpyAsync(&hinfo, sc_int(ctx) + SI_COV, sizeof(int), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hinfo > ctx->M) hinfo = 0;
+  if (info) *info = hinfo;
+  if (hinfo != 0)
+    for (int64_t t = 0; t < (int64_t)n * ctx->M; ++t) out[t] = NAN;
+  return 0;
+}
+
+int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales,
+                      const double* noises, const double* yres, int64_t yres_stride,
+                      const double* Xnew, int M, int noiseless, double jitter,
+                      const double* eps, int n, double* means, double* samples, int* infos) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (ctx->N < 1) return bad_arg(ctx, "gpx_set_train must be called first");
+  if (S < 0 || n < 0) return bad_arg(ctx, "negative count");
+  if (S == 0) return 0;
+  if (!ells || !scales || !noises || !yres || !Xnew || !means) return bad_arg(ctx, "null pointer");
+  if (n > 0 && (!eps || !samples)) return bad_arg(ctx, "eps/samples required when n > 0");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  const int N = ctx->N, d = ctx->d;
+  GPX_TRY(set_xnew(ctx, Xnew, M));
+  ctx->jitter = jitter;
+  const int n_pad = round_up(n > 0 ? n : 1, TILE);
+  // device staging for all inputs/outputs of the sweep: nothing crosses PCIe inside the loop
+  DevBuf dEps, dYres, dMeans, dSamples, dInfos;
+  int rc = 0;
+  auto cleanup = [&]() {
+    dEps.release();
+    dYres.release();
+    dMeans.release();
+    dSamples.release();
+    dInfos.release();
+  };
+#define SWEEP_TRY(expr)  \
+  do {                   \
+    rc = (expr);         \
+    if (rc < 0) {        \
+      cleanup();         \
+      return rc;         \
+    }                    \
+  } while (0)
+#define SWEEP_HIP(expr)                                            \
+  do {                                                             \
+    hipError_t _e = (expr);                                        \
+    if (_e != hipSuccess) {                                        \
+      cleanup();                                                   \
+      return fail(ctx, #expr, _e, __FILE__, __LINE__);             \
+    }                                                              \
+  } while (0)
+  const bool strided = yres_stride != 0;
+  SWEEP_TRY(ensure(ctx, dMeans, (size_t)S * M * sizeof(double)));
+  SWEEP_TRY(ensure(ctx, dInfos, (size_t)2 * S * sizeof(int)));
+  SWEEP_HIP(hipMemsetAsync(dInfos.p, 0, (size_t)2 * S * sizeof(int), ctx->stream));
+  if (strided) {
+    SWEEP_TRY(ensure(ctx, dYres, (size_t)S * N * sizeof(double)));
+    SWEEP_HIP(hipMemcpy2DAsync(dYres.d(), (size_t)N * sizeof(double), yres,
+                               (size_t)yres_stride * sizeof(double), (size_t)N * sizeof(double), S,
+                               hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    SWEEP_HIP(hipMemcpyAsync(ctx->yres.d(), yres, (size_t)N * sizeof(double), hipMemcpyHostToDevice,
+                             ctx->stream));
+  }
+  if (n > 0) {
+    SWEEP_TRY(ensure(ctx, dEps, (size_t)S * n * M * sizeof(double)));
+    SWEEP_TRY(ensure(ctx, dSamples, (size_t)S * n * M * sizeof(double)));
+    SWEEP_HIP(hipMemcpyAsync(dEps.d(), eps, (size_t)S * n * M * sizeof(double), hipMemcpyHostToDevice,
+                             ctx->stream));
+    SWEEP_TRY(ensure(ctx, ctx->eps, (size_t)n_pad * ctx->ldc * sizeof(double)));
+    SWEEP_TRY(ensure(ctx, ctx->draws, (size_t)n_pad * ctx->ldc * sizeof(double)));
+    SWEEP_HIP(hipMemsetAsync(ctx->eps.d(), 0, (size_t)n_pad * ctx->ldc * sizeof(double), ctx->stream));
+  }
+  for (int s = 0; s < S; ++s) {
+    SWEEP_TRY(set_theta(ctx, kind, d, ells + (int64_t)s * d, scales[s]));
+    ctx->noise = noises[s];
+    ctx->noise_p = noiseless ? 0.0 : noises[s];
+    if (strided)
+      SWEEP_HIP(hipMemcpyAsync(ctx->yres.d(), dYres.d() + (int64_t)s * N, (size_t)N * sizeof(double),
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    SWEEP_TRY(dev_factor(ctx));
+    SWEEP_TRY(dev_posterior(ctx, n > 0));
+    SWEEP_HIP(hipMemcpyAsync(dMeans.d() + (int64_t)s * M, ctx->mean.d(), (size_t)M * sizeof(double),
+                             hipMemcpyDeviceToDevice, ctx->stream));
+    SWEEP_HIP(hipMemcpyAsync(dInfos.i() + 2 * s, sc_int(ctx) + SI_TRAIN, sizeof(int),
+                             hipMemcpyDeviceToDevice, ctx->stream));
+    if (n > 0) {
+      SWEEP_HIP(hipMemcpy2DAsync(ctx->eps.d(), ctx->ldc * sizeof(double),
+                                 dEps.d() + (int64_t)s * n * M, (size_t)M * sizeof(double),
+                                 (size_t)M * sizeof(double), n, hipMemcpyDeviceToDevice, ctx->stream));
+      SWEEP_TRY(dev_draw(ctx, n_pad, n));
+      SWEEP_HIP(hipMemcpy2DAsync(dSamples.d() + (int64_t)s * n * M, (size_t)M * sizeof(double),
+                                 ctx->draws.d(), ctx->ldc * sizeof(double), (size_t)M * sizeof(double),
+                                 n, hipMemcpyDeviceToDevice, ctx->stream));
+      SWEEP_HIP(hipMemcpyAsync(dInfos.i() + 2 * s + 1, sc_int(ctx) + SI_COV, sizeof(int),
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
+  std::vector<int> hinfos(2 * (size_t)S);
+  SWEEP_HIP(hipMemcpyAsync(means, dMeans.d(), (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost,
+                           ctx->stream));
+  if (n > 0)
+    SWEEP_HIP(hipMemcpyAsync(samples, dSamples.d(), (size_t)S * n * M * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  SWEEP_HIP(hipMemcpyAsync(hinfos.data(), dInfos.p, (size_t)2 * S * sizeof(int), hipMemcpyDeviceToHost,
+                           ctx->stream));
+  SWEEP_HIP(hipStreamSynchronize(ctx->stream));
+  cleanup();
+#undef SWEEP_TRY
+#undef SWEEP_HIP
+  for (int s = 0; s < S; ++s) {
+    int it = hinfos[2 * s], ic = hinfos[2 * s + 1];
+    if (it > N) it = 0;
+    if (ic > M) ic = 0;
+    const int code = it != 0 ? it : (ic != 0 ? -ic : 0);
+    if (infos) infos[s] = code;
+    if (it != 0)
+      for (int a = 0; a < M; ++a) means[(int64_t)s * M + a] = NAN;
+    if (code != 0 && n > 0)
+      for (int64_t t = 0; t < (int64_t)n * M; ++t) samples[(int64_t)s * n * M + t] = NAN;
+  }
+  return 0;
+}
+
+int gpx_profile_enable(gpx_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  ctx->prof_on = on != 0;
+  return 0;
+}
+
+int gpx_profile_reset(gpx_ctx* ctx) {
+  if (!ctx || ctx->device < 0) return -1;
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  drain_profile(ctx);
+  for (int c = 0; c < GPX_PROF_NCLASS; ++c) {
+    ctx->prof[c].launches = 0;
+    ctx->prof[c].work = 0.0;
+    ctx->prof[c].ms = 0.0;
+  }
+  return 0;
+}
+
+int gpx_profile_read(gpx_ctx* ctx, int cls, int64_t* launches, double* total_ms,
+                     double* total_work) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (cls < 0 || cls >= GPX_PROF_NCLASS) return bad_arg(ctx, "profile class");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  drain_profile(ctx);
+  if (launches) *launches = ctx->prof[cls].launches;
+  if (total_ms) *total_ms = ctx->prof[cls].ms;
+  if (total_work) *total_work = ctx->prof[cls].work;
+  return 0;
+}
+
+int gpx_time_stage(gpx_ctx* ctx, int stage, int reps, double* elapsed_ms) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (ctx->N < 1) return bad_arg(ctx, "gpx_set_train / gpx_factor must be called first");
+  if (reps < 1) return bad_arg(ctx, "reps must be >= 1");
+  if (stage >= GPX_STAGE_POSTERIOR && ctx->M < 1) return bad_arg(ctx, "gpx_posterior must be called first");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  int n_pad = 0;
+  if (stage == GPX_STAGE_PREDICT) {
+    // one draw per pass from a fixed device-resident eps (zeros are fine for timing: the GEMM
+    // does the same work) — keep whatever eps the last gpx_mvn_draw uploaded if present
+    n_pad = TILE;
+    GPX_TRY(ensure(ctx, ctx->eps, (size_t)n_pad * ctx->ldc * sizeof(double)));
+    GPX_TRY(ensure(ctx, ctx->draws, (size_t)n_pad * ctx->ldc * sizeof(double)));
+  }
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  GPX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  for (int r = 0; r < reps; ++r) {
+    switch (stage) {
+      case GPX_STAGE_GRAM:
+        GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->X.d(), ctx->N, ctx->N, ctx->X.d(), ctx->N,
+                                   ctx->Np, ctx->noise + ctx->jitter, 1, 1, ctx->K.d(), ctx->ldk));
+        ctx->factored = false;
+        break;
+      case GPX_STAGE_POTRF:
+        GPX_TRY(dev_factor(ctx));
+        break;
+      case GPX_STAGE_FITSTEP:
+        GPX_TRY(dev_factor(ctx));
+        GPX_TRY(dev_grad(ctx));
+        break;
+      case GPX_STAGE_POSTERIOR:
+        GPX_TRY(dev_factor(ctx));
+        GPX_TRY(dev_posterior(ctx, true));
+        break;
+      case GPX_STAGE_PREDICT:
+        GPX_TRY(dev_factor(ctx));
+        GPX_TRY(dev_posterior(ctx, true));
+        GPX_TRY(dev_draw(ctx, n_pad, 1));
+        break;
+      default:
+        return bad_arg(ctx, "unknown stage");
+    }
+  }
+  GPX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  GPX_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  GPX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (elapsed_ms) *elapsed_ms = ms;
+  return 0;
+}
+
+int gpx_mfma_f64_peak(gpx_ctx* ctx, double* tflops) {
+  if (!ctx || ctx->device < 0 || !tflops) return -1;
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  return mfma_peak(ctx, tflops);
+}
+
+int gpx_gemm_nt(gpx_ctx* ctx, int M, int N, int K, double alpha, const double* A,
+                const double* B, double beta, double* C) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (M < 1 || N < 1 || K < 1 || !A || !B || !C) return bad_arg(ctx, "gemm arguments");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  const int Mp = round_up(M, TILE), Np = round_up(N, TILE), Kp = round_up(K, 16);
+  const int64_t lda = pick_ld(Kp), ldc = pick_ld(Np);
+  GPX_TRY(ensure(ctx, ctx->tA, (size_t)Mp * lda * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->tB, (size_t)Np * lda * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->tC, (size_t)Mp * ldc * sizeof(double)));
+  GPX_HIP(ctx, hipMemsetAsync(ctx->tA.p, 0, (size_t)Mp * lda * sizeof(double), ctx->stream));
+  GPX_HIP(ctx, hipMemsetAsync(ctx->tB.p, 0, (size_t)Np * lda * sizeof(double), ctx->stream));
+  GPX_HIP(ctx, hipMemsetAsync(ctx->tC.p, 0, (size_t)Mp * ldc * sizeof(double), ctx->stream));
+  GPX_HIP(ctx, hipMemcpy2DAsync(ctx->tA.d(), lda * sizeof(double), A, (size_t)K * sizeof(double),
+                                (size_t)K * sizeof(double), M, hipMemcpyHostToDevice, ctx->stream));
+  GPX_HIP(ctx, hipMemcpy2DAsync(ctx->tB.d(), lda * sizeof(double), B, (size_t)K * sizeof(double),
+                                (size_t)K * sizeof(double), N, hipMemcpyHostToDevice, ctx->stream));
+  if (beta != 0.0)
+    GPX_HIP(ctx, hipMemcpy2DAsync(ctx->tC.d(), ldc * sizeof(double), C, (size_t)N * sizeof(double),
+                                  (size_t)N * sizeof(double), M, hipMemcpyHostToDevice, ctx->stream));
+  GemmArgs g{};
+  g.A = ctx->tA.d();
+  g.lda = lda;
+  g.B = ctx->tB.d();
+  g.ldb = lda;
+  g.C = ctx->tC.d();
+  g.ldc = ldc;
+  g.K = Kp;
+  g.alpha = alpha;
+  g.beta = beta;
+  GPX_TRY(launch_gemm_nt(ctx, g, Mp / TILE, Np / TILE, 0, GPX_PROF_GEMM_OTHER,
+                         2.0 * M * (double)N * K));
+  GPX_HIP(ctx, hipMemcpy2DAsync(C, (size_t)N * sizeof(double), ctx->tC.d(), ldc * sizeof(double),
+                                (size_t)N * sizeof(double), M, hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int gpx_potrf(gpx_ctx* ctx, int n, const double* A, double* L, int* info) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (n < 1 || !A || !L) return bad_arg(ctx, "potrf arguments");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  const int np = round_up(n, TILE);
+  const int64_t ld = pick_ld(np);
+  GPX_TRY(ensure(ctx, ctx->tA, (size_t)np * ld * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->tB, (size_t)(np / TILE) * TILE * TILE * sizeof(double)));
+  GPX_HIP(ctx, hipMemsetAsync(ctx->tA.p, 0, (size_t)np * ld * sizeof(double), ctx->stream));
+  GPX_HIP(ctx, hipMemcpy2DAsync(ctx->tA.d(), ld * sizeof(double), A, (size_t)n * sizeof(double),
+                                (size_t)n * sizeof(double), n, hipMemcpyHostToDevice, ctx->stream));
+  GPX_TRY(launch_pad_identity(ctx, ctx->tA.d(), ld, n, np));
+  GPX_HIP(ctx, hipMemsetAsync(sc_int(ctx) + SI_TRAIN, 0, sizeof(int), ctx->stream));
+  GPX_TRY(potrf_lower(ctx, ctx->tA.d(), ld, np, ctx->tB.d(), sc_int(ctx) + SI_TRAIN));
+  int hinfo = 0;
+  GPX_HIP(ctx, hipMemcpy2DAsync(L, (size_t)n * sizeof(double), ctx->tA.d(), ld * sizeof(double),
+                                (size_t)n * sizeof(double), n, hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(ctx, hipMemcpyAsync(&hinfo, sc_int(ctx) + SI_TRAIN, sizeof(int), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) L[(int64_t)i * n + j] = 0.0;
+  if (hinfo > n) hinfo = 0;
+  if (info) *info = hinfo;
+  return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,222 @@
+// common.h — context, device buffers, launch/profiling helpers shared by the libgpx sources.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gpx.h"
+
+namespace gpx {
+
+constexpr int TILE = 128;      // MFMA GEMM block tile and diagonal-block size
+constexpr int OUTER_TILES = 4; // outer blocking of the right-looking sweeps (4*128 = 512)
+constexpr double AUG_BIG = 1e300;
+constexpr double SQRT5 = 2.23606797749978969641;
+constexpr double MATERN_EPS = 1e-12; // gpax/kernels/kernels.py:20-21
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// Leading dimension for an internal matrix with `cols` logical columns: multiple of 16
+// doubles (128-B rows) and never a multiple of 512 doubles, so that a 128-row tile load does
+// not put every row on the same HBM channel set.
+inline int64_t pick_ld(int64_t cols) {
+  int64_t ld = round_up64(cols, 16);
+  if (ld % 512 == 0) ld += 16;
+  return ld;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      p = nullptr;
+      cap = 0;
+      if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  double* d() const { return static_cast<double*>(p); }
+  int* i() const { return static_cast<int*>(p); }
+};
+
+struct KernelParams {
+  int kind;
+  int d;
+  double inv_ell[GPX_MAX_DIM];
+  double scale;
+};
+
+struct ProfAcc {
+  int64_t launches = 0;
+  double work = 0.0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double ms = 0.0;
+};
+
+} // namespace gpx
+
+struct gpx_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  hipDeviceProp_t prop;
+
+  // ---- training state -------------------------------------------------------------------
+  int N = 0, d = 0;
+  int Np = 0;        // padded order of the augmented matrix: round_up(N + 1, 128)
+  int64_t ldk = 0;   // leading dimension of K/W buffers
+  gpx::DevBuf X;     // N x d
+  gpx::DevBuf K;     // Np x ldk : Gram -> L (lower) -> K^-1 (lower)
+  gpx::DevBuf W;     // Np x ldk : L^-T (upper), allocated on first gradient
+  gpx::DevBuf Linv;  // (Np/128) x 128 x 128 inverses of the diagonal blocks of L
+  gpx::DevBuf yres;  // N
+  gpx::DevBuf scal;  // small device scalars (lml pieces, gradient, info)
+  gpx::DevBuf part;  // reduction partials
+  gpx::DevBuf alpha; // N
+  gpx::KernelParams theta{};
+  double noise = 0, jitter = 0;
+  bool factored = false;
+
+  // ---- posterior state ------------------------------------------------------------------
+  int M = 0, Mp = 0;
+  int64_t ldv = 0, ldc = 0;
+  gpx::DevBuf Xnew;   // M x d
+  gpx::DevBuf Vt;     // Mp x ldv : k_pX -> k_pX L^-T
+  gpx::DevBuf Cov;    // Mp x ldc : posterior covariance -> its Cholesky factor (lower)
+  gpx::DevBuf CovLinv;// (Mp/128) x 128 x 128
+  gpx::DevBuf SplitK; // split-K partial slabs
+  gpx::DevBuf mean;   // Mp
+  gpx::DevBuf var;    // Mp
+  gpx::DevBuf eps;    // n_pad x ldc
+  gpx::DevBuf draws;  // n_pad x ldc
+  double noise_p = 0;
+  bool have_post = false;
+  bool cov_factored = false;
+
+  // ---- generic scratch for unit-test entry points ---------------------------------------
+  gpx::DevBuf tA, tB, tC;
+
+  // ---- profiling ------------------------------------------------------------------------
+  bool prof_on = false;
+  gpx::ProfAcc prof[GPX_PROF_NCLASS];
+};
+
+namespace gpx {
+
+inline int fail(gpx_ctx* ctx, const char* what, hipError_t e, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+  if (ctx) ctx->err = buf;
+  return -2;
+}
+inline int bad_arg(gpx_ctx* ctx, const char* msg) {
+  if (ctx) ctx->err = std::string("bad argument: ") + msg;
+  return -1;
+}
+
+#define GPX_HIP(ctx, expr)                                                   \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) return gpx::fail((ctx), #expr, _e, __FILE__, __LINE__); \
+  } while (0)
+
+#define GPX_TRY(expr)      \
+  do {                     \
+    int _rc = (expr);      \
+    if (_rc < 0) return _rc; \
+  } while (0)
+
+// Bracket a kernel launch with events when profiling is on.
+struct ProfScope {
+  gpx_ctx* ctx;
+  int cls;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(gpx_ctx* c, int cls_, double work) : ctx(c), cls(cls_) {
+    if (!ctx->prof_on) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      a = b = nullptr;
+      return;
+    }
+    ctx->prof[cls].launches += 1;
+    ctx->prof[cls].work += work;
+    (void)hipEventRecord(a, ctx->stream);
+  }
+  ~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof[cls].pending.emplace_back(a, b);
+  }
+};
+
+// ---- kernels implemented across the .hip files ------------------------------------------
+
+// gram.hip
+int launch_gram(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, const double* dZ,
+                int m, double diag_add, int add_diag, int lower_only, double* dOut, int64_t ld);
+int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, int n_pad,
+                       const double* dZ, int m, int m_pad, double diag_add, int add_diag,
+                       int lower_only, double* dOut, int64_t ld);
+int launch_augment(gpx_ctx* ctx, double* dK, int64_t ld, int N, int Np, const double* dy);
+int launch_pad_identity(gpx_ctx* ctx, double* dA, int64_t ld, int n, int np);
+
+// gemm_f64.hip
+struct GemmArgs {
+  const double* A;
+  int64_t lda;
+  const double* B;
+  int64_t ldb;
+  double* C;
+  int64_t ldc;
+  int K;       // reduction length, multiple of 16
+  double alpha, beta;
+  int lower;   // skip tiles with (tj_off + bx) > (ti_off + by)
+  int ti_off, tj_off;
+  int ktri;    // k range starts at (ti_off + by) * 128 (upper-triangular operands)
+  int kupper;  // k range ends at (tj_off + bx + 1) * 128 (B lower triangular, e.g. chol factor)
+  int kchunk;  // split-K chunk (multiple of 16), 0 = no split
+  int64_t c_split_stride;
+};
+int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
+                   int prof_cls, double work);
+int mfma_peak(gpx_ctx* ctx, double* tflops);
+
+// potf2.hip
+int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo,
+                     int info_base);
+
+// linalg.hip
+int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, double* dLinv, int* dInfo);
+int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_p, const double* dL,
+                  int64_t ldl, const double* dLinv, int nblk, int upper_rows);
+int launch_set_identity(gpx_ctx* ctx, double* dA, int64_t ld, int np);
+int launch_lml_terms(gpx_ctx* ctx, const double* dL, int64_t ld, int N, double* dOut2);
+int launch_rowdot(gpx_ctx* ctx, const double* dV, int64_t ldv, int rows, int cols,
+                  const double* dw, double kdiag, double* dmean, double* dvar,
+                  int col_start_by_row);
+int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXnew, int M, int Mp,
+                        const double* dPart, int splits, int64_t split_stride, int64_t ldp,
+                        double diag_add, double* dCov, int64_t ldc);
+int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int N,
+                         const double* dKinv, int64_t ld, const double* dalpha, double* dpart,
+                         int* nblocks_out);
+int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals, double* dout);
+int launch_add_mean(gpx_ctx* ctx, double* ddraws, int64_t ld, int n, int M, const double* dmean);
+
+} // namespace gpx

@@ -1,0 +1,207 @@
+// gemm_f64.hip — fp64 MFMA "NT" GEMM tile kernel for gfx950:
+//     C[i][j] = beta * C[i][j] + alpha * sum_k A[i][k] * B[j][k]        (row-major everywhere)
+//
+// This one kernel carries every dense contraction on the exact-GP path (the work JAX hands to
+// LAPACK/cuSOLVER underneath gpax/models/gp.py:160-164,271-273,292): the Cholesky trailing
+// update (SYRK form, lower tiles only), the panel TRSM (multiplication by the inverted 128x128
+// diagonal block), the right-looking TRSM sweeps of the posterior, the split-K SYRK of the
+// posterior covariance, L^-T L^-1 for the gradient, and the MVN draw.
+//
+// Design (CDNA4): 128x128 block tile, BK = 16, 256 threads = 4 waves in a 2x2 grid, each wave
+// owns a 64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 accumulator VGPRs).
+// A and B tiles are both "row x k" with k contiguous (that is what NT means in row-major), so
+// both fragments are read from LDS with the same pattern: lane l reads row (l & 15), k (l >> 4).
+// LDS rows are padded to 18 doubles: 18 r mod 32 is a permutation of the even residues, so the
+// 32 lanes of each ds_read_b64 half hit 32 distinct banks.  Global -> register -> LDS staging,
+// double-buffered in LDS with the next tile's global loads in flight during the MFMAs: one
+// barrier per k-step.  73.7 KB LDS + <256 VGPRs => 2 workgroups (8 waves) per CU.
+//
+// f64 MFMA fragment layout (differs from the f32 forms!):
+//   A: lane l holds A[i = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][j = l & 15];
+//   D: lane l, register r holds D[row = (l >> 4) + 4 r][col = l & 15].
+#include "common.h"
+
+namespace gpx {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDT = BK + 2; // padded LDS row (doubles)
+constexpr int TILE_DOUBLES = BM * LDT;
+constexpr size_t GEMM_LDS_BYTES = size_t(4) * TILE_DOUBLES * sizeof(double); // 2 bufs x (A,B)
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int ti = g.ti_off + by, tj = g.tj_off + bx;
+  if (g.lower && tj > ti) return;
+
+  int kb = 0, ke = g.K;
+  if (g.ktri) kb = ti * BM;
+  if (g.kupper) ke = min(ke, (tj + 1) * BN);
+  double* C = g.C;  // may alias A (in-place panel TRSM): no restrict here
+  if (g.kchunk > 0) {
+    kb = max(kb, bz * g.kchunk);
+    ke = min(ke, (bz + 1) * g.kchunk);
+    C += (int64_t)bz * g.c_split_stride;
+  }
+  const int nk = (ke > kb) ? (ke - kb) / BK : 0;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  // staging map: thread -> (row lr + 32 i, cols lc, lc + 1)
+  const int lr = tid >> 3, lc = (tid & 7) * 2;
+  const double* Ap = g.A + ((int64_t)by * BM + lr) * g.lda + kb + lc;
+  const double* Bp = g.B + ((int64_t)bx * BN + lr) * g.ldb + kb + lc;
+  const int64_t a_step = 32 * g.lda, b_step = 32 * g.ldb;
+
+  double* sA0 = smem;
+  double* sB0 = smem + TILE_DOUBLES;
+  double* sA1 = smem + 2 * TILE_DOUBLES;
+  double* sB1 = smem + 3 * TILE_DOUBLES;
+
+  d4_t acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+  const int a_frag_off = (wr * 64 + fr) * LDT + fk;
+  const int b_frag_off = (wc * 64 + fr) * LDT + fk;
+  const int st_off = lr * LDT + lc;
+
+  if (nk > 0) {
+    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define GPX_LOAD_TILE(koff)                                                \
+  ra0 = *reinterpret_cast<const double2*>(Ap + (koff));                    \
+  ra1 = *reinterpret_cast<const double2*>(Ap + a_step + (koff));           \
+  ra2 = *reinterpret_cast<const double2*>(Ap + 2 * a_step + (koff));       \
+  ra3 = *reinterpret_cast<const double2*>(Ap + 3 * a_step + (koff));       \
+  rb0 = *reinterpret_cast<const double2*>(Bp + (koff));                    \
+  rb1 = *reinterpret_cast<const double2*>(Bp + b_step + (koff));           \
+  rb2 = *reinterpret_cast<const double2*>(Bp + 2 * b_step + (koff));       \
+  rb3 = *reinterpret_cast<const double2*>(Bp + 3 * b_step + (koff));
+#define GPX_STORE_TILE(dA, dB)                                             \
+  *reinterpret_cast<double2*>((dA) + st_off) = ra0;                        \
+  *reinterpret_cast<double2*>((dA) + st_off + 32 * LDT) = ra1;             \
+  *reinterpret_cast<double2*>((dA) + st_off + 64 * LDT) = ra2;             \
+  *reinterpret_cast<double2*>((dA) + st_off + 96 * LDT) = ra3;             \
+  *reinterpret_cast<double2*>((dB) + st_off) = rb0;                        \
+  *reinterpret_cast<double2*>((dB) + st_off + 32 * LDT) = rb1;             \
+  *reinterpret_cast<double2*>((dB) + st_off + 64 * LDT) = rb2;             \
+  *reinterpret_cast<double2*>((dB) + st_off + 96 * LDT) = rb3;
+    GPX_LOAD_TILE(0)
+    GPX_STORE_TILE(sA0, sB0)
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const double* cA = (kt & 1) ? sA1 : sA0;
+      const double* cB = (kt & 1) ? sB1 : sB0;
+      double* nA = (kt & 1) ? sA0 : sA1;
+      double* nB = (kt & 1) ? sB0 : sB1;
+      // prefetch the next k-tile (the last iteration re-reads its own tile: in bounds, unused)
+      const int koff = ((kt + 1 < nk) ? (kt + 1) : kt) * BK;
+      GPX_LOAD_TILE(koff)
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[m] = cA[a_frag_off + m * 16 * LDT + kk * 4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bf[n] = cB[b_frag_off + n * 16 * LDT + kk * 4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0); // keep the LDS refill (and its vmcnt wait) behind the MFMAs
+      GPX_STORE_TILE(nA, nB)
+      __syncthreads();
+    }
+#undef GPX_LOAD_TILE
+#undef GPX_STORE_TILE
+  }
+
+  // epilogue: D[row = (lane >> 4) + 4 r][col = lane & 15] per 16x16 accumulator.  A wave
+  // store covers 4 rows x 16 contiguous doubles (full 128-B lines).  The beta path batches the
+  // 16 C loads of one accumulator row-block ahead of their use (one latency, not sixteen).
+  const double alpha = g.alpha, beta = g.beta;
+  double* Cw = C + ((int64_t)by * BM + wr * 64 + fk) * g.ldc + (int64_t)bx * BN + wc * 64 + fr;
+  if (beta != 0.0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      double cv[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) cv[r][n] = Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = fma(beta, cv[r][n], alpha * acc[m][n][r]);
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = alpha * acc[m][n][r];
+  }
+}
+
+int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
+                   int prof_cls, double work) {
+  if (tiles_m <= 0 || tiles_n <= 0) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)GEMM_LDS_BYTES));
+    attr_set = true;
+  }
+  dim3 grid(tiles_n, tiles_m, splits > 0 ? splits : 1);
+  ProfScope ps(ctx, prof_cls, work);
+  gemm_nt_kernel<<<grid, 256, GEMM_LDS_BYTES, ctx->stream>>>(g);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// ---- raw MFMA issue-rate microbenchmark ----------------------------------------------------
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
+  d4_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = d4_t{0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s; // keep the chain live
+}
+
+int mfma_peak(gpx_ctx* ctx, double* tflops) {
+  GPX_TRY(ctx->scal.ensure(4096) == hipSuccess ? 0 : -2);
+  const int iters = 4096;
+  const int blocks = ctx->prop.multiProcessorCount * 2; // 8 waves per CU = 2 per SIMD
+  mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(ctx->scal.d(), 16); // warm-up
+  GPX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(ctx->scal.d(), iters);
+  GPX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  GPX_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  GPX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  return 0;
+}
+
+} // namespace gpx

@@ -1,0 +1,379 @@
+// linalg.hip — blocked drivers (Cholesky, right-looking triangular sweeps) and the small
+// bandwidth-bound kernels of the exact-GP path.  All matrices are row-major, padded to
+// multiples of 128; the dense contractions are launches of gemm_nt_kernel (gemm_f64.hip).
+//
+// Reference seam: the Cholesky / solve_triangular / matmul calls JAX performs underneath
+// gpax/models/gp.py:160-164 (MultivariateNormal log_prob), gp.py:271-273 (posterior) and
+// gp.py:292 (MVN draw).
+#include "common.h"
+
+namespace gpx {
+
+static inline GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t ldb,
+                                 double* C, int64_t ldc, int K, double alpha, double beta) {
+  GemmArgs g{};
+  g.A = A;
+  g.lda = lda;
+  g.B = B;
+  g.ldb = ldb;
+  g.C = C;
+  g.ldc = ldc;
+  g.K = K;
+  g.alpha = alpha;
+  g.beta = beta;
+  return g;
+}
+
+// ---- blocked right-looking Cholesky (lower, in place), two-level blocking ------------------
+// Outer blocks of OUTER_TILES*128 columns keep the big trailing SYRK at K = 512 (C-tile HBM
+// traffic / flop is 1/4 of a K = 128 update); inside an outer block the panel is advanced 128
+// columns at a time: potf2+inverse (1 workgroup) -> panel TRSM as GEMM with the inverse ->
+// update of the remaining columns of the outer block only.
+int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, double* dLinv, int* dInfo) {
+  const int nblk = np / TILE;
+  for (int ob = 0; ob < nblk; ob += OUTER_TILES) {
+    const int oe = (ob + OUTER_TILES < nblk) ? ob + OUTER_TILES : nblk;
+    for (int kb = ob; kb < oe; ++kb) {
+      double* Akk = dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE;
+      double* Li = dLinv + (int64_t)kb * TILE * TILE;
+      GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE));
+      const int below = nblk - kb - 1;
+      if (below <= 0) continue;
+      double* Apan = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)kb * TILE;
+      { // panel TRSM, in place: A[kb+1.., kb] <- A[kb+1.., kb] * Linv^T
+        GemmArgs g = gemm_args(Apan, lda, Li, TILE, Apan, lda, TILE, 1.0, 0.0);
+        GPX_TRY(launch_gemm_nt(ctx, g, below, 1, 0, GPX_PROF_GEMM_OTHER,
+                               2.0 * below * TILE * (double)TILE * TILE));
+      }
+      const int inner_cols = oe - kb - 1;
+      if (inner_cols > 0) { // update the rest of the outer block's columns (lower tiles)
+        double* Cin = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)(kb + 1) * TILE;
+        GemmArgs g = gemm_args(Apan, lda, Apan, lda, Cin, lda, TILE, -1.0, 1.0);
+        g.lower = 1;
+        g.ti_off = kb + 1;
+        g.tj_off = kb + 1;
+        GPX_TRY(launch_gemm_nt(ctx, g, below, inner_cols, 0, GPX_PROF_GEMM_OTHER,
+                               2.0 * below * inner_cols * (double)TILE * TILE * TILE));
+      }
+    }
+    const int rest = nblk - oe;
+    if (rest > 0) { // trailing update with K = (oe - ob) * 128, lower tiles only
+      const int K = (oe - ob) * TILE;
+      const double* Pan = dA + (int64_t)oe * TILE * lda + (int64_t)ob * TILE;
+      double* Ctr = dA + (int64_t)oe * TILE * lda + (int64_t)oe * TILE;
+      GemmArgs g = gemm_args(Pan, lda, Pan, lda, Ctr, lda, K, -1.0, 1.0);
+      g.lower = 1;
+      g.ti_off = oe;
+      g.tj_off = oe;
+      const double n = (double)rest * TILE;
+      GPX_TRY(launch_gemm_nt(ctx, g, rest, rest, 0, GPX_PROF_GEMM_TRAILING, n * (n + 1.0) * K));
+    }
+  }
+  return 0;
+}
+
+// ---- right-looking solve of  X * L^T = B  in place (B: rows_t*128 x nblk*128) --------------
+// Column block i:  X_i = B_i * Linv_i^T, then B_{>i} -= X_i * L[>i, i]^T.  Two-level blocking
+// as in potrf_lower.  upper_rows != 0: B is upper triangular (the L^-T build of the gradient),
+// so column block i only involves row tiles 0..i.
+int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const double* dL,
+                  int64_t ldl, const double* dLinv, int nblk, int upper_rows) {
+  for (int ob = 0; ob < nblk; ob += OUTER_TILES) {
+    const int oe = (ob + OUTER_TILES < nblk) ? ob + OUTER_TILES : nblk;
+    for (int i = ob; i < oe; ++i) {
+      const int rt = upper_rows ? (i + 1) : rows_t;
+      double* Bi = dB + (int64_t)i * TILE;
+      {
+        GemmArgs g = gemm_args(Bi, ldb, dLinv + (int64_t)i * TILE * TILE, TILE, Bi, ldb, TILE, 1.0,
+                               0.0);
+        GPX_TRY(launch_gemm_nt(ctx, g, rt, 1, 0, GPX_PROF_GEMM_OTHER,
+                               2.0 * rt * TILE * (double)TILE * TILE));
+      }
+      const int inner_cols = oe - i - 1;
+      if (inner_cols > 0) {
+        const double* Lsub = dL + (int64_t)(i + 1) * TILE * ldl + (int64_t)i * TILE;
+        GemmArgs g = gemm_args(Bi, ldb, Lsub, ldl, dB + (int64_t)(i + 1) * TILE, ldb, TILE, -1.0,
+                               1.0);
+        GPX_TRY(launch_gemm_nt(ctx, g, rt, inner_cols, 0, GPX_PROF_GEMM_OTHER,
+                               2.0 * rt * inner_cols * (double)TILE * TILE * TILE));
+      }
+    }
+    const int rest = nblk - oe;
+    if (rest > 0) {
+      const int rt = upper_rows ? oe : rows_t;
+      const int K = (oe - ob) * TILE;
+      const double* Lsub = dL + (int64_t)oe * TILE * ldl + (int64_t)ob * TILE;
+      GemmArgs g = gemm_args(dB + (int64_t)ob * TILE, ldb, Lsub, ldl, dB + (int64_t)oe * TILE, ldb,
+                             K, -1.0, 1.0);
+      GPX_TRY(launch_gemm_nt(ctx, g, rt, rest, 0, GPX_PROF_GEMM_OTHER,
+                             2.0 * rt * rest * (double)TILE * TILE * K));
+    }
+  }
+  return 0;
+}
+
+// ---- small kernels ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ A, int64_t ld,
+                                                           int np) {
+  const int i = blockIdx.y;
+  double* row = A + (int64_t)i * ld;
+  for (int j = (blockIdx.x * 256 + threadIdx.x) * 2; j < np; j += gridDim.x * 512) {
+    *reinterpret_cast<double2*>(row + j) = make_double2(j == i ? 1.0 : 0.0, j + 1 == i ? 1.0 : 0.0);
+  }
+}
+
+int launch_set_identity(gpx_ctx* ctx, double* dA, int64_t ld, int np) {
+  dim3 grid(min(32, (np / 2 + 255) / 256), np);
+  set_identity_kernel<<<grid, 256, 0, ctx->stream>>>(dA, ld, np);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Block-wide deterministic sum (fixed tree): result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double* red /* >= 16 doubles */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) s += red[w];
+  }
+  return s;
+}
+
+// out[0] = sum_{k<N} L[N][k]^2 (= |L^-1 y|^2: row N of the augmented factor),
+// out[1] = sum_{i<N} log L[i][i].
+__global__ __launch_bounds__(1024) void lml_terms_kernel(const double* __restrict__ L, int64_t ld,
+                                                         int N, double* __restrict__ out) {
+  __shared__ double red[16];
+  double q = 0.0, s = 0.0;
+  const double* w = L + (int64_t)N * ld;
+  for (int k = threadIdx.x; k < N; k += 1024) {
+    const double wk = w[k];
+    q = fma(wk, wk, q);
+    s += log(L[(int64_t)k * ld + k]);
+  }
+  const double qs = block_sum(q, red);
+  const double ss = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    out[0] = qs;
+    out[1] = ss;
+  }
+}
+
+int launch_lml_terms(gpx_ctx* ctx, const double* dL, int64_t ld, int N, double* dOut2) {
+  lml_terms_kernel<<<1, 1024, 0, ctx->stream>>>(dL, ld, N, dOut2);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// One wave per row:  mean[r] = sum_k V[r][k] w[k];  var[r] = kdiag - sum_k V[r][k]^2.
+// col_start_by_row: V is upper triangular, start at k = r (alpha = L^-T w).
+__global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ V, int64_t ldv,
+                                                     int rows, int cols,
+                                                     const double* __restrict__ w, double kdiag,
+                                                     double* __restrict__ mean,
+                                                     double* __restrict__ var,
+                                                     int col_start_by_row) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  const double* v = V + (int64_t)r * ldv;
+  double m = 0.0, q = 0.0;
+  int k0 = col_start_by_row ? (r & ~63) : 0;
+  for (int k = k0 + lane; k < cols; k += 64) {
+    const double x = (col_start_by_row && k < r) ? 0.0 : v[k];
+    m = fma(x, w[k], m);
+    q = fma(x, x, q);
+  }
+  m = wave_sum(m);
+  q = wave_sum(q);
+  if (lane == 0) {
+    if (mean) mean[r] = m;
+    if (var) var[r] = kdiag - q;
+  }
+}
+
+int launch_rowdot(gpx_ctx* ctx, const double* dV, int64_t ldv, int rows, int cols,
+                  const double* dw, double kdiag, double* dmean, double* dvar,
+                  int col_start_by_row) {
+  if (rows <= 0) return 0;
+  rowdot_kernel<<<(rows + 3) / 4, 256, 0, ctx->stream>>>(dV, ldv, rows, cols, dw, kdiag, dmean,
+                                                         dvar, col_start_by_row);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+__device__ __forceinline__ double kval_rt(int kind, double r2, double scale) {
+  if (kind == GPX_KERNEL_RBF) return scale * exp(-0.5 * r2);
+  const double r = sqrt(r2 + MATERN_EPS);
+  const double s5r = SQRT5 * r;
+  return scale * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);
+}
+
+// cov[a][b] = k_pp(a, b) - sum_z P_z[max(a,b)][min(a,b)]   (a, b < M); identity padding.
+// k_pp = kernel(X_new, X_new, theta, noise_p, jitter)  (gpax/models/gp.py:267) evaluated on
+// the fly; the split-K slabs only hold lower tiles.
+__global__ __launch_bounds__(256) void cov_finalize_kernel(KernelParams kp,
+                                                           const double* __restrict__ Xn, int M,
+                                                           int Mp, const double* __restrict__ P,
+                                                           int splits, int64_t split_stride,
+                                                           int64_t ldp, double diag_add,
+                                                           double* __restrict__ Cov, int64_t ldc) {
+  const int b = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int a0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+  if (b >= Mp) return;
+  const int d = kp.d;
+  for (int t = 0; t < 4; ++t) {
+    const int a = a0 + t;
+    if (a >= Mp) return;
+    double v;
+    if (a < M && b < M) {
+      double r2 = 0.0;
+      for (int c = 0; c < d; ++c) {
+        const double u = (Xn[(int64_t)a * d + c] - Xn[(int64_t)b * d + c]) * kp.inv_ell[c];
+        r2 = fma(u, u, r2);
+      }
+      v = kval_rt(kp.kind, r2, kp.scale);
+      if (a == b) v += diag_add;
+      const int hi = a > b ? a : b, lo = a > b ? b : a;
+      double acc = 0.0;
+      for (int z = 0; z < splits; ++z) acc += P[(int64_t)z * split_stride + (int64_t)hi * ldp + lo];
+      v -= acc;
+    } else {
+      v = (a == b) ? 1.0 : 0.0;
+    }
+    Cov[(int64_t)a * ldc + b] = v;
+  }
+}
+
+int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXnew, int M, int Mp,
+                        const double* dPart, int splits, int64_t split_stride, int64_t ldp,
+                        double diag_add, double* dCov, int64_t ldc) {
+  dim3 grid((Mp + 63) / 64, (Mp + 15) / 16);
+  cov_finalize_kernel<<<grid, 256, 0, ctx->stream>>>(kp, dXnew, M, Mp, dPart, splits, split_stride,
+                                                     ldp, diag_add, dCov, ldc);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// ---- gradient contraction --------------------------------------------------------------------
+// d lml / d theta = 1/2 sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta, accumulated over the
+// lower triangle (off-diagonal weight 1, diagonal weight 1/2) with dK evaluated on the fly:
+//   d/d scale : k_ij / scale          d/d noise : delta_ij
+//   d/d ell_m : dk/dr2 * (-2 u_m^2 / ell_m),  u_m = (x_im - x_jm) / ell_m
+//   RBF: dk/dr2 = -k/2;  Matern52: dk/dr2 = -(5/6) s e^{-sqrt5 r} (1 + sqrt5 r2 / r).
+// Output per block: [g_ell(0..d), g_scale, g_noise]; reduced in fixed order afterwards.
+constexpr int GC_TILE = 64;
+constexpr int GC_MAXV = GPX_MAX_DIM + 2;
+
+__global__ __launch_bounds__(256) void grad_contract_kernel(KernelParams kp,
+                                                            const double* __restrict__ X, int N,
+                                                            const double* __restrict__ Kinv,
+                                                            int64_t ld,
+                                                            const double* __restrict__ alpha,
+                                                            double* __restrict__ part) {
+  // linear block id -> lower-triangle tile (ti >= tj)
+  const int bid = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * bid + 1.0) - 1.0) * 0.5);
+  while ((int64_t)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+  while ((int64_t)ti * (ti + 1) / 2 > bid) --ti;
+  const int tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
+  const int d = kp.d;
+  __shared__ double red[16];
+  double acc[GC_MAXV];
+  for (int c = 0; c < d + 2; ++c) acc[c] = 0.0;
+  const int j = tj * GC_TILE + (threadIdx.x & 63);
+  const int ibase = ti * GC_TILE + (threadIdx.x >> 6);
+  if (j < N) {
+    const double aj = alpha[j];
+    for (int t = 0; t < GC_TILE / 4; ++t) {
+      const int i = ibase + 4 * t;
+      if (i >= N || j > i) continue;
+      const double G = alpha[i] * aj - Kinv[(int64_t)i * ld + j];
+      const double wgt = (i == j) ? 0.5 : 1.0;
+      double r2 = 0.0;
+      double u2[GPX_MAX_DIM];
+      for (int c = 0; c < d; ++c) {
+        const double u = (X[(int64_t)i * d + c] - X[(int64_t)j * d + c]) * kp.inv_ell[c];
+        u2[c] = u * u;
+        r2 += u2[c];
+      }
+      double kv, dk;
+      if (kp.kind == GPX_KERNEL_RBF) {
+        kv = kp.scale * exp(-0.5 * r2);
+        dk = -0.5 * kv;
+      } else {
+        const double r = sqrt(r2 + MATERN_EPS);
+        const double e = exp(-SQRT5 * r);
+        kv = kp.scale * (1.0 + SQRT5 * r + (5.0 / 3.0) * r2) * e;
+        dk = -(5.0 / 6.0) * kp.scale * e * (1.0 + SQRT5 * r2 / r);
+      }
+      const double wg = wgt * G;
+      for (int c = 0; c < d; ++c) acc[c] += wg * dk * (-2.0 * u2[c] * kp.inv_ell[c]);
+      acc[d] += wg * kv / kp.scale;
+      if (i == j) acc[d + 1] += wg;
+    }
+  }
+  for (int c = 0; c < d + 2; ++c) {
+    const double s = block_sum(acc[c], red);
+    if (threadIdx.x == 0) part[(int64_t)bid * GC_MAXV + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ part,
+                                                          int nblocks, int nvals,
+                                                          double* __restrict__ out) {
+  __shared__ double red[16];
+  for (int c = 0; c < nvals; ++c) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(int64_t)b * GC_MAXV + c];
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) out[c] = t;
+  }
+}
+
+int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int N,
+                         const double* dKinv, int64_t ld, const double* dalpha, double* dpart,
+                         int* nblocks_out) {
+  const int nt = (N + GC_TILE - 1) / GC_TILE;
+  const int nblocks = nt * (nt + 1) / 2;
+  *nblocks_out = nblocks;
+  grad_contract_kernel<<<nblocks, 256, 0, ctx->stream>>>(kp, dX, N, dKinv, ld, dalpha, dpart);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals, double* dout) {
+  grad_reduce_kernel<<<1, 256, 0, ctx->stream>>>(dpart, nblocks, nvals, dout);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// draws[s][a] += mean[a]
+__global__ __launch_bounds__(256) void add_mean_kernel(double* __restrict__ D, int64_t ld, int n,
+                                                       int M, const double* __restrict__ mean) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  const int s = blockIdx.y;
+  if (a < M && s < n) D[(int64_t)s * ld + a] += mean[a];
+}
+
+int launch_add_mean(gpx_ctx* ctx, double* ddraws, int64_t ld, int n, int M, const double* dmean) {
+  if (n <= 0) return 0;
+  dim3 grid((M + 255) / 256, n);
+  add_mean_kernel<<<grid, 256, 0, ctx->stream>>>(ddraws, ld, n, M, dmean);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+} // namespace gpx

@@ -1,0 +1,150 @@
+/*
+ * gpx.h — C-ABI of libgpx: the MI355X (gfx950) exact-GP hot path behind gpax's
+ * kernel / ExactGP / viGP / viSparseGP Python surface.
+ *
+ * The reference (ziatdinovmax/gpax, pure Python on JAX/NumPyro) has no FFI; its seam for this
+ * path is the kernel-callable protocol and the model methods cited per entry point below
+ * (paths relative to the reference checkout).  Every entry point names the reference
+ * interface it replaces.  INTEGRATION.md shows the ctypes binding a gpax maintainer would add.
+ *
+ * Conventions
+ *   - All pointers are caller-owned HOST buffers, C-order (row-major) fp64, unless the
+ *     parameter name starts with `d_` (device pointer).  The library copies H<->D.
+ *   - One gpx_ctx per GPU; calls on one ctx must be serialised by the caller; distinct
+ *     ctxs are independent.  Functions block until results are in the host buffers.
+ *   - Return value: 0 = ok; < 0 = bad argument / HIP failure (text via gpx_last_error).
+ *     Numerical failure (non-positive Cholesky pivot) is NOT an error return: it is
+ *     reported LAPACK-style through an `info` out-parameter (1-based order of the first
+ *     bad pivot) and outputs are NaN-filled, mirroring JAX's silent-NaN Cholesky that
+ *     gpax's `filter_nans` relies on (gpax/models/gp.py:396-398).  Never aborts.
+ *   - fp64 end to end.  Parity tolerance vs the reference algorithm: 1e-6 relative
+ *     (BASELINE.json north_star); tests assert 1e-8 or tighter.
+ */
+#ifndef GPX_H
+#define GPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpx_ctx gpx_ctx;
+
+/* kernel family selector — gpax/kernels/kernels.py:227-241 (get_kernel registry) */
+#define GPX_KERNEL_RBF 0      /* gpax/kernels/kernels.py:44-65 */
+#define GPX_KERNEL_MATERN52 1 /* gpax/kernels/kernels.py:68-91 */
+
+#define GPX_MAX_DIM 16 /* max input dimension d handled by the fused kernels */
+
+/* profiling classes for gpx_profile_read */
+#define GPX_PROF_GEMM_TRAILING 0 /* potrf outer trailing update (syrk, K = outer block) */
+#define GPX_PROF_GEMM_OTHER 1    /* every other MFMA GEMM launch */
+#define GPX_PROF_POTF2 2         /* diagonal-block factor+inverse */
+#define GPX_PROF_GRAM 3          /* Gram builds */
+#define GPX_PROF_NCLASS 4
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+
+/* Replaces JAX device selection (`device=` kwarg -> jax.device_put, gpax/models/gp.py:201-203).
+ * Fails (<0) when no gfx950-capable HIP device `device` exists. */
+int gpx_init(int device, gpx_ctx** out);
+void gpx_destroy(gpx_ctx* ctx);
+const char* gpx_last_error(const gpx_ctx* ctx);
+int gpx_device_info(gpx_ctx* ctx, char* name, int name_len, int* num_cu, int64_t* hbm_bytes,
+                    int* clock_khz);
+int gpx_synchronize(gpx_ctx* ctx);
+
+/* ---- Gram matrix: gpax/kernels/kernels.py:28-91 ------------------------------------------
+ * out[i*m + j] = scale * k(||(X_i - Z_j)/ell||)  (+ diag_add on i == j when add_diag != 0).
+ * The reference adds (noise + jitter) * eye iff X.shape == Z.shape (kernels.py:63,89); the
+ * host wrapper decides add_diag by that same rule and passes diag_add = noise + jitter.
+ * ell has d entries (the wrapper broadcasts scalar / (1,) / (1,1) lengthscales). */
+int gpx_gram(gpx_ctx* ctx, int kind, const double* X, int n, const double* Z, int m, int d,
+             const double* ell, double scale, double diag_add, int add_diag, double* out);
+
+/* ---- training state: ExactGP._set_data / fit, gpax/models/gp.py:166-220,410-414 -----------
+ * Uploads X_train (N,d) and sizes the device workspaces (Gram/factor buffer etc.). */
+int gpx_set_train(gpx_ctx* ctx, const double* X, int N, int d);
+
+/* ---- log marginal likelihood: ExactGP.model, gpax/models/gp.py:137-164 --------------------
+ * (NumPyro MultivariateNormal(loc, covariance_matrix=k).log_prob(y): Cholesky, triangular
+ * solve, sum log diag.)  Builds K = kernel(X,X,theta,noise,jitter) on device, factors it
+ * (blocked right-looking fp64 MFMA Cholesky) and returns
+ *   lml = -1/2 yres^T K^-1 yres - sum log L_ii - N/2 log(2 pi),   yres = y - mean_fn(X).
+ * The factor stays resident for gpx_lml_grad / gpx_posterior.  *info > 0 => lml = NaN. */
+int gpx_factor(gpx_ctx* ctx, int kind, const double* ell, double scale, double noise,
+               double jitter, const double* yres, double* lml, int* info);
+
+/* Analytic gradient of the lml above w.r.t. (ell[0..d), scale, noise) — replaces JAX
+ * reverse-mode autodiff through gp.py:137-164 used by NUTS (gp.py:207-218) and SVI
+ * (vigp.py:108-120).  Also returns alpha = K^-1 yres (d lml / d yres = -alpha) for the
+ * mean-function chain rule.  Must follow gpx_factor; CONSUMES the factor (K^-1 overwrites it). */
+int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* grad_noise,
+                 double* alpha);
+
+/* ---- posterior: ExactGP.get_mvn_posterior, gpax/models/gp.py:253-277 ----------------------
+ * Must follow gpx_factor (same theta).  mean (M), cov (M*M, may be NULL), var (M, may be
+ * NULL; = diag(cov), what viGP.predict returns, gpax/models/vigp.py:184-185).
+ *   k_pp = kernel(Xnew,Xnew,theta,noise_p,jitter); k_pX = kernel(Xnew,X,theta) (no diag)
+ *   mean = k_pX K^-1 yres;  cov = k_pp - k_pX K^-1 k_pX^T    (POTRF+TRSM route; the
+ * reference's explicit inverse, gp.py:271, is not replicated).
+ * The M x M posterior covariance stays resident for gpx_mvn_draw. */
+int gpx_posterior(gpx_ctx* ctx, const double* Xnew, int M, double noise_p, double jitter,
+                  double* mean, double* cov, double* var);
+
+/* ---- MVN draw: ExactGP._predict, gpax/models/gp.py:279-293 --------------------------------
+ * out[s*M + a] = mean[a] + sum_b Lc[a][b] eps[s*M + b], Lc = chol(cov) of the last
+ * gpx_posterior.  eps are caller-supplied standard normals (JAX threefry streams are not
+ * reproducible here; parity is defined given eps).  *info > 0 => out is NaN-filled. */
+int gpx_mvn_draw(gpx_ctx* ctx, const double* eps, int n, double* out, int* info);
+
+/* ---- predictive sweep: ExactGP.predict, gpax/models/gp.py:351-399 -------------------------
+ * The jax.vmap over S posterior samples, run as a device-resident loop (one theta at a
+ * time; nothing S*N*N is ever materialised).  For sample s:
+ *   theta_s = (ells[s*d .. s*d+d), scales[s], noises[s]);
+ *   yres_s  = yres + s*yres_stride (yres_stride = 0 when no mean function);
+ *   mean_s, cov_s as gpx_posterior with noise_p = noiseless ? 0 : noises[s];
+ *   samples[s] = mean_s + chol(cov_s) eps[s]   (n draws).
+ * means (S*M), samples (S*n*M), infos (S; bit 0.. = train-factor info, negative = draw chol
+ * failed).  Rows whose info != 0 are NaN-filled.  eps may be NULL when n == 0. */
+int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales,
+                      const double* noises, const double* yres, int64_t yres_stride,
+                      const double* Xnew, int M, int noiseless, double jitter,
+                      const double* eps, int n, double* means, double* samples, int* infos);
+
+/* ---- measurement hooks (bench.py / profiles) ----------------------------------------------
+ * When enabled, HIP events bracket every launch of the profiled kernel classes on the
+ * library's own stream; gpx_profile_read returns launches, summed duration and summed
+ * ALGORITHMIC flops (MFMA classes) or bytes (Gram) since the last reset. */
+int gpx_profile_enable(gpx_ctx* ctx, int on);
+int gpx_profile_reset(gpx_ctx* ctx);
+int gpx_profile_read(gpx_ctx* ctx, int cls, int64_t* launches, double* total_ms,
+                     double* total_work);
+
+/* Device-only timed repetitions (inputs resident in HBM; used by bench.py so that `value`
+ * excludes PCIe).  Each call runs `reps` passes of the named stage at the theta/Xnew last set
+ * by gpx_factor/gpx_posterior and returns the elapsed milliseconds between HIP events. */
+#define GPX_STAGE_GRAM 0      /* Gram build of K (N x N, lower tiles) */
+#define GPX_STAGE_POTRF 1     /* Gram + blocked Cholesky (+ lml)                    */
+#define GPX_STAGE_FITSTEP 2   /* Gram + potrf + lml + potri + gradient contraction  */
+#define GPX_STAGE_POSTERIOR 3 /* Gram + potrf + k_pX + trsm + syrk + mean           */
+#define GPX_STAGE_PREDICT 4   /* POSTERIOR + chol(cov) + n draws                    */
+int gpx_time_stage(gpx_ctx* ctx, int stage, int reps, double* elapsed_ms);
+
+/* Raw MFMA fp64 ceiling microbenchmark (v_mfma_f64_16x16x4_f64 issue rate), TFLOP/s. */
+int gpx_mfma_f64_peak(gpx_ctx* ctx, double* tflops);
+
+/* Plain GEMM entry used by the unit tests of the MFMA tile kernel:
+ * C[M x N] = alpha * A[M x K] * B[N x K]^T + beta * C   (row-major, any sizes). */
+int gpx_gemm_nt(gpx_ctx* ctx, int M, int N, int K, double alpha, const double* A,
+                const double* B, double beta, double* C);
+
+/* Plain Cholesky entry used by the unit tests: in: A (n x n, symmetric, lower read);
+ * out: L (n x n lower, zeros above).  *info as above. */
+int gpx_potrf(gpx_ctx* ctx, int n, const double* A, double* L, int* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPX_H */

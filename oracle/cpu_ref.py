@@ -1,0 +1,360 @@
+"""
+oracle/cpu_ref.py — CPU restatement (NumPy/SciPy, fp64) of gpax's exact-GP hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under gpax_amd/ imports this file; only tests/,
+__graft_entry__.smoke() and bench.py's `cpu_baseline` leg may, and only as the checker /
+the reported CPU baseline — never as the thing measured or shipped.
+
+PARITY UNPINNED: the reference (ziatdinovmax/gpax v0.1.9) is pure Python on JAX + NumPyro.
+Neither jax, jaxlib nor numpyro is installed in the build container (and they never travel to
+the GPU box), so the reference cannot be imported to generate vectors, and its own tests pin no
+numeric value on this path.  This restatement therefore follows the
+reference line by line (file:line cited per function, paths relative to the reference checkout)
+and is cross-checked independently (tests/test_oracle.py): direct-formula Gram in mpmath at 50
+digits, scipy.stats.multivariate_normal for the log-density, explicit-inverse vs Cholesky route
+for the posterior, central finite differences for the gradient, dense W W^T + D formulation for
+the low-rank MVN.  The third-party arithmetic reached by the path (NumPyro MultivariateNormal /
+LowRankMultivariateNormal log_prob and sample; jnp.linalg.inv / cholesky; pins
+jax>=0.6.2, numpyro>=0.18.0 in the reference's pyproject.toml:26-28) is restated from its
+published definitions and marked [knowledge].
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, Optional, Tuple
+
+import numpy as np
+import scipy.linalg as sla
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+# ------------------------------------------------------------------------------------------
+# gpax/kernels/kernels.py
+# ------------------------------------------------------------------------------------------
+def _sqrt(x, eps=1e-12):
+    """gpax/kernels/kernels.py:20-21"""
+    return np.sqrt(x + eps)
+
+
+def add_jitter(x, jitter=1e-6):
+    """gpax/kernels/kernels.py:24-25"""
+    return x + jitter
+
+
+def square_scaled_distance(X, Z, lengthscale=1.0):
+    """gpax/kernels/kernels.py:28-41 — expansion form with the clip at 0, op for op."""
+    X = np.asarray(X, dtype=np.float64)
+    Z = np.asarray(Z, dtype=np.float64)
+    scaled_X = X / lengthscale
+    scaled_Z = Z / lengthscale
+    X2 = (scaled_X ** 2).sum(1, keepdims=True)
+    Z2 = (scaled_Z ** 2).sum(1, keepdims=True)
+    XZ = np.matmul(scaled_X, scaled_Z.T)
+    r2 = X2 - 2 * XZ + Z2.T
+    return r2.clip(0)
+
+
+def RBFKernel(X, Z, params, noise=0, jitter=1e-6, **kwargs):
+    """gpax/kernels/kernels.py:44-65"""
+    X = np.asarray(X, dtype=np.float64)
+    Z = np.asarray(Z, dtype=np.float64)
+    r2 = square_scaled_distance(X, Z, params["k_length"])
+    k = params["k_scale"] * np.exp(-0.5 * r2)
+    if X.shape == Z.shape:
+        k = k + add_jitter(noise, jitter) * np.eye(X.shape[0])
+    return k
+
+
+def MaternKernel(X, Z, params, noise=0, jitter=1e-6, **kwargs):
+    """gpax/kernels/kernels.py:68-91 (Matern-5/2)"""
+    X = np.asarray(X, dtype=np.float64)
+    Z = np.asarray(Z, dtype=np.float64)
+    r2 = square_scaled_distance(X, Z, params["k_length"])
+    r = _sqrt(r2)
+    sqrt5_r = 5 ** 0.5 * r
+    k = params["k_scale"] * (1 + sqrt5_r + (5 / 3) * r2) * np.exp(-sqrt5_r)
+    if X.shape == Z.shape:
+        k = k + add_jitter(noise, jitter) * np.eye(X.shape[0])
+    return k
+
+
+def get_kernel(kernel="RBF"):
+    """gpax/kernels/kernels.py:227-241 (in-scope names only)"""
+    kernel_book = {"RBF": RBFKernel, "Matern": MaternKernel}
+    if isinstance(kernel, str):
+        return kernel_book[kernel]
+    return kernel
+
+
+# ------------------------------------------------------------------------------------------
+# NumPyro MultivariateNormal [knowledge]: log_prob = -1/2 |L^-1 (y-loc)|^2 - sum log L_ii
+#   - n/2 log 2 pi with L = cholesky(covariance_matrix); sample = loc + L @ eps
+# ------------------------------------------------------------------------------------------
+def mvn_log_prob(y, loc, cov) -> float:
+    y = np.asarray(y, dtype=np.float64)
+    try:
+        L = np.linalg.cholesky(cov)
+    except np.linalg.LinAlgError:
+        return float("nan")
+    w = sla.solve_triangular(L, y - loc, lower=True)
+    return float(-0.5 * (w @ w) - np.log(np.diag(L)).sum() - 0.5 * y.shape[0] * LOG_2PI)
+
+
+def mvn_sample(loc, cov, eps):
+    """dist.MultivariateNormal(loc, cov).sample given the standard normals eps (n, M)."""
+    try:
+        L = np.linalg.cholesky(cov)
+    except np.linalg.LinAlgError:
+        return np.full((np.asarray(eps).shape[0], loc.shape[0]), np.nan)
+    return loc[None, :] + np.asarray(eps) @ L.T
+
+
+# ------------------------------------------------------------------------------------------
+# gpax/models/gp.py
+# ------------------------------------------------------------------------------------------
+def _set_data(X, y=None):
+    """gpax/models/gp.py:410-414"""
+    X = np.asarray(X, dtype=np.float64)
+    X = X if X.ndim > 1 else X[:, None]
+    if y is not None:
+        return X, np.asarray(y, dtype=np.float64).squeeze()
+    return X
+
+
+def exactgp_log_likelihood(X, y, params, kernel="RBF", jitter=1e-6, mean_fn=None, mean_params=None) -> float:
+    """log p(y | theta) of ExactGP.model, gpax/models/gp.py:137-164 (the `y` site only)."""
+    X, y = _set_data(X, y)
+    kfn = get_kernel(kernel)
+    f_loc = np.zeros(X.shape[0])
+    if mean_fn is not None:
+        args = [X] if mean_params is None else [X, mean_params]
+        f_loc = f_loc + np.asarray(mean_fn(*args)).squeeze()
+    k = kfn(X, X, params, params["noise"], jitter=jitter)
+    return mvn_log_prob(y, f_loc, k)
+
+
+def exactgp_log_likelihood_grad(X, y, params, kernel="RBF", jitter=1e-6, yres=None):
+    """Analytic gradient of the log-likelihood w.r.t. (k_length[d], k_scale, noise) and
+    alpha = K^-1 yres: 1/2 sum_ij (alpha alpha^T - K^-1)_ij dK_ij/dtheta.  (The reference gets
+    this from JAX autodiff through gp.py:137-164; tests check it against central differences.)"""
+    X, y = _set_data(X, y)
+    if yres is None:
+        yres = y
+    N, d = X.shape
+    ell = np.broadcast_to(np.asarray(params["k_length"], dtype=np.float64).reshape(-1), (d,)).astype(np.float64)
+    s = float(params["k_scale"])
+    kfn = get_kernel(kernel)
+    K = kfn(X, X, params, params["noise"], jitter=jitter)
+    Kinv = np.linalg.inv(K)
+    alpha = Kinv @ yres
+    G = np.outer(alpha, alpha) - Kinv
+    diff = (X[:, None, :] - X[None, :, :]) / ell  # u_m
+    r2 = (diff ** 2).sum(-1)
+    if kernel == "RBF":
+        kb = s * np.exp(-0.5 * r2)
+        dk = -0.5 * kb
+    else:
+        r = np.sqrt(r2 + 1e-12)
+        e = np.exp(-math.sqrt(5.0) * r)
+        kb = s * (1 + math.sqrt(5.0) * r + (5 / 3) * r2) * e
+        dk = -(5.0 / 6.0) * s * e * (1 + math.sqrt(5.0) * r2 / r)
+    g_ell = np.array([0.5 * np.sum(G * dk * (-2.0 * diff[:, :, m] ** 2 / ell[m])) for m in range(d)])
+    g_scale = 0.5 * np.sum(G * kb) / s
+    g_noise = 0.5 * np.trace(G)
+    return g_ell, g_scale, g_noise, alpha
+
+
+def get_mvn_posterior(X_train, y_train, X_new, params, noiseless=False, kernel="RBF", jitter=1e-6,
+                      mean_fn=None, mean_fn_has_params=False, route="inv") -> Tuple[np.ndarray, np.ndarray]:
+    """ExactGP.get_mvn_posterior, gpax/models/gp.py:253-277.
+    route='inv' is the reference's explicit inverse (gp.py:271-273); route='chol' is the
+    POTRF+TRSM route the GPU runs.  tests assert the two agree."""
+    X_train, y_train = _set_data(X_train, y_train)
+    X_new = _set_data(X_new)
+    kfn = get_kernel(kernel)
+    noise = params["noise"]
+    noise_p = noise * (1 - int(bool(noiseless)))
+    y_residual = y_train.copy()
+    if mean_fn is not None:
+        args = [X_train, params] if mean_fn_has_params else [X_train]
+        y_residual = y_residual - np.asarray(mean_fn(*args)).squeeze()
+    k_pp = kfn(X_new, X_new, params, noise_p, jitter=jitter)
+    k_pX = kfn(X_new, X_train, params, jitter=0.0)
+    k_XX = kfn(X_train, X_train, params, noise, jitter=jitter)
+    if route == "inv":
+        K_xx_inv = np.linalg.inv(k_XX)
+        cov = k_pp - np.matmul(k_pX, np.matmul(K_xx_inv, np.transpose(k_pX)))
+        mean = np.matmul(k_pX, np.matmul(K_xx_inv, y_residual))
+    else:
+        L = np.linalg.cholesky(k_XX)
+        V = sla.solve_triangular(L, k_pX.T, lower=True)
+        w = sla.solve_triangular(L, y_residual, lower=True)
+        cov = k_pp - V.T @ V
+        mean = V.T @ w
+    if mean_fn is not None:
+        args = [X_new, params] if mean_fn_has_params else [X_new]
+        mean = mean + np.asarray(mean_fn(*args)).squeeze()
+    return mean, cov
+
+
+def predict_one(X_train, y_train, X_new, params, eps, noiseless=False, kernel="RBF", jitter=1e-6, **kw):
+    """ExactGP._predict, gpax/models/gp.py:279-293, with the MVN draw made explicit in eps (n, M)."""
+    y_mean, K = get_mvn_posterior(X_train, y_train, X_new, params, noiseless, kernel, jitter, **kw)
+    return y_mean, mvn_sample(y_mean, K, eps)
+
+
+def predict(X_train, y_train, X_new, samples: Dict[str, np.ndarray], eps, noiseless=False, kernel="RBF",
+            jitter=1e-6, **kw):
+    """ExactGP.predict, gpax/models/gp.py:351-399: the vmap over S samples as a loop.
+    eps has shape (S, n, M).  Returns (y_means.mean(0), y_sampled (S, n, M), y_means (S, M))."""
+    S = len(next(iter(samples.values())))
+    means, draws = [], []
+    for s in range(S):
+        prm = {k: np.asarray(v)[s] for k, v in samples.items()}
+        m, y = predict_one(X_train, y_train, X_new, prm, eps[s], noiseless, kernel, jitter, **kw)
+        means.append(m)
+        draws.append(y)
+    means = np.stack(means)
+    return means.mean(0), np.stack(draws), means
+
+
+def vigp_predict(X_train, y_train, X_new, params, noiseless=False, kernel="RBF", jitter=1e-6, **kw):
+    """viGP.predict, gpax/models/vigp.py:153-185: (mean, cov.diagonal())."""
+    mean, cov = get_mvn_posterior(X_train, y_train, X_new, params, noiseless, kernel, jitter, **kw)
+    return mean, cov.diagonal()
+
+
+# ------------------------------------------------------------------------------------------
+# gpax/models/sparse_gp.py  +  NumPyro LowRankMultivariateNormal [knowledge]
+# ------------------------------------------------------------------------------------------
+def lowrank_mvn_log_prob(y, loc, W, D) -> float:
+    """LowRankMultivariateNormal(loc, cov_factor=W (N,M), cov_diag=D (N,)).log_prob(y):
+    Woodbury + matrix-determinant lemma with the capacitance matrix C = I + W^T D^-1 W."""
+    y = np.asarray(y, dtype=np.float64)
+    r = y - loc
+    Wt_Dinv = W.T / D
+    Cm = np.eye(W.shape[1]) + Wt_Dinv @ W
+    Lc = np.linalg.cholesky(Cm)
+    Wt_Dinv_r = Wt_Dinv @ r
+    t = sla.solve_triangular(Lc, Wt_Dinv_r, lower=True)
+    maha = (r * r / D).sum() - t @ t
+    logdet = np.log(D).sum() + 2.0 * np.log(np.diag(Lc)).sum()
+    return float(-0.5 * (y.shape[0] * LOG_2PI + logdet + maha))
+
+
+def sparse_bound(X, y, Xu, params, kernel="Matern", jitter=1e-6, f_loc=None) -> float:
+    """viSparseGP.model, gpax/models/sparse_gp.py:62-114: VFE bound =
+    LowRankMVN log_prob - trace_term / 2 (the `y` site plus the `trace_term` factor)."""
+    X, y = _set_data(X, y)
+    kfn = get_kernel(kernel)
+    noise = params["noise"]
+    N = X.shape[0]
+    D = np.broadcast_to(noise, (N,)).astype(np.float64)
+    loc = np.zeros(N) if f_loc is None else f_loc
+    Kuu = kfn(Xu, Xu, params, jitter=jitter)
+    Luu = np.linalg.cholesky(Kuu)  # cholesky(Kuu).T of the upper factor == lower factor
+    Kuf = kfn(Xu, X, params)
+    W = sla.solve_triangular(Luu, Kuf, lower=True).T
+    Kffdiag = np.diag(kfn(X, X, params, jitter=0))
+    Qffdiag = np.square(W).sum(axis=-1)
+    trace_term = (Kffdiag - Qffdiag).sum() / noise
+    trace_term = np.clip(trace_term, 0, None)
+    return lowrank_mvn_log_prob(y, loc, W, D) - trace_term / 2.0
+
+
+def sparse_posterior(X_train, y_train, Xu, X_new, params, noiseless=False, kernel="Matern", jitter=1e-6):
+    """viSparseGP.get_mvn_posterior, gpax/models/sparse_gp.py:173-223 (no mean function)."""
+    X_train, y_train = _set_data(X_train, y_train)
+    X_new = _set_data(X_new)
+    kfn = get_kernel(kernel)
+    noise = params["noise"]
+    N = X_train.shape[0]
+    D = np.broadcast_to(noise, (N,)).astype(np.float64)
+    noise_p = noise * (1 - int(bool(noiseless)))
+    y_residual = y_train.copy()
+    Kuu = kfn(Xu, Xu, params, jitter=jitter)
+    Luu = np.linalg.cholesky(Kuu)
+    Kuf = kfn(Xu, X_train, params, jitter=0)
+    W = sla.solve_triangular(Luu, Kuf, lower=True)
+    W_Dinv = W / D
+    K = W_Dinv @ W.T
+    K[np.diag_indices(K.shape[0])] += 1
+    L = np.linalg.cholesky(K)
+    y_2D = y_residual.reshape(-1, N).T
+    W_Dinv_y = W_Dinv @ y_2D
+    Kus = kfn(Xu, X_new, params, jitter=0)
+    Ws = sla.solve_triangular(Luu, Kus, lower=True)
+    pack = np.concatenate((W_Dinv_y, Ws), axis=1)
+    Linv_pack = sla.solve_triangular(L, pack, lower=True)
+    Linv_W_Dinv_y = Linv_pack[:, : W_Dinv_y.shape[1]]
+    Linv_Ws = Linv_pack[:, W_Dinv_y.shape[1]:]
+    mean = (Linv_W_Dinv_y.T @ Linv_Ws).squeeze()
+    Kss = kfn(X_new, X_new, params, noise_p, jitter=jitter)
+    Qss = Ws.T @ Ws
+    cov = Kss - Qss + Linv_Ws.T @ Linv_Ws
+    return mean, cov
+
+
+# ------------------------------------------------------------------------------------------
+# gpax/utils/utils.py (host plumbing the build's API reproduces)
+# ------------------------------------------------------------------------------------------
+def split_in_batches(X_new, batch_size=100, dim=0):
+    """gpax/utils/utils.py:33-51 (including its UnboundLocalError when len < batch_size)."""
+    if dim not in [0, 1]:
+        raise NotImplementedError("'dim' must be equal to 0 or 1")
+    num_batches = X_new.shape[dim] // batch_size
+    X_split = []
+    for i in range(num_batches):
+        X_i = X_new[i * batch_size:(i + 1) * batch_size] if dim == 0 else X_new[:, i * batch_size:(i + 1) * batch_size]
+        X_split.append(X_i)
+    X_i = X_new[(i + 1) * batch_size:] if dim == 0 else X_new[:, (i + 1) * batch_size:]
+    if X_i.shape[dim] > 0:
+        X_split.append(X_i)
+    return X_split
+
+
+def split_dict(data, chunk_size):
+    """gpax/utils/utils.py:54-81"""
+    N = len(next(iter(data.values())))
+    num_chunks = int(np.ceil(N / chunk_size))
+    result = []
+    for i in range(num_chunks):
+        s, e = i * chunk_size, min((i + 1) * chunk_size, N)
+        result.append({k: v[s:e] for k, v in data.items()})
+    return result
+
+
+def preprocess_sparse_image(sparse_image):
+    """gpax/utils/utils.py:150-168"""
+    dtype = sparse_image.dtype
+    non_zero_indices = np.nonzero(sparse_image)
+    gp_input = np.column_stack(non_zero_indices)
+    targets = sparse_image[non_zero_indices]
+    full_indices = np.array(np.meshgrid(*[np.arange(dim) for dim in sparse_image.shape])).T.reshape(
+        -1, sparse_image.ndim)
+    return gp_input.astype(dtype), targets.astype(dtype), full_indices.astype(dtype)
+
+
+# ------------------------------------------------------------------------------------------
+# synthetic workloads of BASELINE.md §3 (shared by tests and bench.py)
+# ------------------------------------------------------------------------------------------
+def synthetic_problem(N: int, d: int, M: int, seed: int = 0, noise: float = 0.1):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0.0, 10.0, size=(N, d))
+    f = np.prod(np.sin(X + 0.3 * np.arange(d)[None, :]), axis=1)
+    y = f + math.sqrt(noise) * rng.standard_normal(N)
+    Xnew = rng.uniform(0.0, 10.0, size=(M, d))
+    params = {"k_length": 1.0 + 0.25 * np.arange(d), "k_scale": 1.3, "noise": noise}
+    return X, y, Xnew, params
+
+
+def synthetic_theta_samples(S: int, d: int, seed: int = 1, noise: float = 0.1):
+    """C4 of BASELINE.md: lengthscales / scale ~ LogNormal(0, 0.1) * base, noise ~ LogNormal(log .1, .1)."""
+    rng = np.random.default_rng(seed)
+    base_l = 1.0 + 0.25 * np.arange(d)
+    return {
+        "k_length": base_l[None, :] * np.exp(0.1 * rng.standard_normal((S, d))),
+        "k_scale": 1.3 * np.exp(0.1 * rng.standard_normal(S)),
+        "noise": noise * np.exp(0.1 * rng.standard_normal(S)),
+    }
