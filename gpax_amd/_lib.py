@@ -65,6 +65,7 @@ def load_library() -> C.CDLL:
         "gpx_profile_reset": (C.c_int, [vp]),
         "gpx_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64), _dp, _dp]),
         "gpx_time_stage": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
+        "gpx_sweep_resident": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp]),
         "gpx_mfma_f64_peak": (C.c_int, [vp, _dp]),
         "gpx_gemm_nt": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_double, _dp]),
         "gpx_potrf": (C.c_int, [vp, C.c_int, _dp, _dp, _ip]),
@@ -80,7 +81,8 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = (
     "gpx_init gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train "
     "gpx_factor gpx_lml_grad gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_profile_enable "
-    "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_mfma_f64_peak gpx_gemm_nt gpx_potrf"
+    "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_sweep_resident gpx_mfma_f64_peak gpx_gemm_nt "
+    "gpx_potrf"
 ).split()
 
 
@@ -252,6 +254,18 @@ class Engine:
     def time_stage(self, stage: int, reps: int) -> float:
         ms = C.c_double()
         self._check(self._lib.gpx_time_stage(self._ctx, stage, reps, C.byref(ms)), "gpx_time_stage")
+        return ms.value
+
+    def sweep_resident(self, kind: int, ells, scales, noises, noiseless: bool, jitter: float, n_draws: int) -> float:
+        ells = _f64(ells)
+        S = ells.shape[0]
+        ells = _f64(ells, (S, self.d))
+        scales = _f64(scales, (S,))
+        noises = _f64(noises, (S,))
+        ms = C.c_double()
+        self._check(self._lib.gpx_sweep_resident(self._ctx, kind, S, _ptr(ells), _ptr(scales), _ptr(noises),
+                                                 int(bool(noiseless)), float(jitter), int(n_draws), C.byref(ms)),
+                    "gpx_sweep_resident")
         return ms.value
 
     def mfma_f64_peak(self) -> float:

@@ -632,6 +632,37 @@ int gpx_time_stage(gpx_ctx* ctx, int stage, int reps, double* elapsed_ms) {
   return 0;
 }
 
+int gpx_sweep_resident(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales,
+                       const double* noises, int noiseless, double jitter, int n_draws,
+                       double* elapsed_ms) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (ctx->N < 1 || ctx->M < 1) return bad_arg(ctx, "gpx_factor and gpx_posterior must be called first");
+  if (S < 1 || !ells || !scales || !noises || n_draws < 0) return bad_arg(ctx, "sweep arguments");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  const int n_pad = round_up(n_draws > 0 ? n_draws : 1, TILE);
+  if (n_draws > 0) {
+    GPX_TRY(ensure(ctx, ctx->eps, (size_t)n_pad * ctx->ldc * sizeof(double)));
+    GPX_TRY(ensure(ctx, ctx->draws, (size_t)n_pad * ctx->ldc * sizeof(double)));
+  }
+  ctx->jitter = jitter;
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  GPX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  for (int s = 0; s < S; ++s) {
+    GPX_TRY(set_theta(ctx, kind, ctx->d, ells + (int64_t)s * ctx->d, scales[s]));
+    ctx->noise = noises[s];
+    ctx->noise_p = noiseless ? 0.0 : noises[s];
+    GPX_TRY(dev_factor(ctx));
+    GPX_TRY(dev_posterior(ctx, n_draws > 0));
+    if (n_draws > 0) GPX_TRY(dev_draw(ctx, n_pad, n_draws));
+  }
+  GPX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  GPX_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  GPX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (elapsed_ms) *elapsed_ms = ms;
+  return 0;
+}
+
 int gpx_mfma_f64_peak(gpx_ctx* ctx, double* tflops) {
   if (!ctx || ctx->device < 0 || !tflops) return -1;
   GPX_HIP(ctx, hipSetDevice(ctx->device));

@@ -190,17 +190,23 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) 
 
 int mfma_peak(gpx_ctx* ctx, double* tflops) {
   GPX_TRY(ctx->scal.ensure(4096) == hipSuccess ? 0 : -2);
-  const int iters = 4096;
-  const int blocks = ctx->prop.multiProcessorCount * 2; // 8 waves per CU = 2 per SIMD
-  mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(ctx->scal.d(), 16); // warm-up
-  GPX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(ctx->scal.d(), iters);
-  GPX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  GPX_HIP(ctx, hipEventSynchronize(ctx->ev1));
-  float ms = 0.f;
-  GPX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-  const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
-  *tflops = flops / (ms * 1e-3) / 1e12;
+  const int iters = 16384;
+  double best = 0.0;
+  // 1, 2 and 4 waves per SIMD; report the best sustained issue rate
+  for (int bpc = 1; bpc <= 4; bpc *= 2) {
+    const int blocks = ctx->prop.multiProcessorCount * bpc;
+    mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(ctx->scal.d(), iters); // warm-up / clock ramp
+    GPX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(ctx->scal.d(), iters);
+    GPX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    GPX_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    GPX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
+    const double tf = flops / (ms * 1e-3) / 1e12;
+    if (tf > best) best = tf;
+  }
+  *tflops = best;
   return 0;
 }
 

@@ -132,6 +132,15 @@ int gpx_profile_read(gpx_ctx* ctx, int cls, int64_t* launches, double* total_ms,
 #define GPX_STAGE_PREDICT 4   /* POSTERIOR + chol(cov) + n draws                    */
 int gpx_time_stage(gpx_ctx* ctx, int stage, int reps, double* elapsed_ms);
 
+/* The predictive sweep with everything resident in HBM (bench.py's timed region): runs the
+ * per-sample pipeline of gpx_predict_sweep for S thetas against the X / yres / Xnew already on
+ * the device (set by gpx_set_train, gpx_factor and gpx_posterior), n_draws MVN draws per sample
+ * from device-resident eps, outputs left on the device.  No PCIe traffic; returns the elapsed
+ * milliseconds between HIP events on the library's stream. */
+int gpx_sweep_resident(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales,
+                       const double* noises, int noiseless, double jitter, int n_draws,
+                       double* elapsed_ms);
+
 /* Raw MFMA fp64 ceiling microbenchmark (v_mfma_f64_16x16x4_f64 issue rate), TFLOP/s. */
 int gpx_mfma_f64_peak(gpx_ctx* ctx, double* tflops);
 
