@@ -269,9 +269,12 @@ class Engine:
         return ms.value
 
     def mfma_f64_peak(self) -> float:
-        tf = C.c_double()
-        self._check(self._lib.gpx_mfma_f64_peak(self._ctx, C.byref(tf)), "gpx_mfma_f64_peak")
-        return tf.value
+        return self.mfma_f64_probe()["tflops"]
+
+    def mfma_f64_probe(self) -> dict:
+        out = (C.c_double * 3)()
+        self._check(self._lib.gpx_mfma_f64_peak(self._ctx, out), "gpx_mfma_f64_peak")
+        return {"tflops": out[0], "cycles_per_mfma": out[1], "effective_mhz": out[2]}
 
     # -- unit-test entry points -------------------------------------------------------------------
     def gemm_nt(self, A, B, alpha=1.0, beta=0.0, Cin=None) -> np.ndarray:

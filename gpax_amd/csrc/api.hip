@@ -666,7 +666,7 @@ int gpx_sweep_resident(gpx_ctx* ctx, int kind, int S, const double* ells, const 
 int gpx_mfma_f64_peak(gpx_ctx* ctx, double* tflops) {
   if (!ctx || ctx->device < 0 || !tflops) return -1;
   GPX_HIP(ctx, hipSetDevice(ctx->device));
-  return mfma_peak(ctx, tflops);
+  return mfma_peak(ctx, tflops); // tflops[0..2]: TFLOP/s, cycles per MFMA, effective MHz
 }
 
 int gpx_gemm_nt(gpx_ctx* ctx, int M, int N, int K, double alpha, const double* A,

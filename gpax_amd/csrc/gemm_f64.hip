@@ -173,40 +173,62 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
 }
 
 // ---- raw MFMA issue-rate microbenchmark ----------------------------------------------------
+// out[0] = shader cycles (s_memtime) spent by wave 0 of block 0 in the loop,
+// out[1] = constant-rate wall clock ticks (100 MHz) over the same span.
 __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
   d4_t acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = d4_t{0.0, 0.0, 0.0, 0.0};
   double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  const long long c0 = clock64();
+  const long long w0 = wall_clock64();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < 8; ++i)
+      asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
   }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // MFMA results -> VALU readers (no auto-padding for asm)
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  if (s == 12345.678) out[0] = s; // keep the chain live
+  const long long c1 = clock64();
+  const long long w1 = wall_clock64();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[0] = (double)(c1 - c0);
+    out[1] = (double)(w1 - w0);
+  }
+  if (s == 12345.678) out[2] = s; // keep the chain live
 }
 
+// tflops[0] = best sustained TFLOP/s over 1/2/4 waves per SIMD; [1] = shader cycles per MFMA
+// (per wave) in that configuration; [2] = effective shader clock in MHz during the run.
 int mfma_peak(gpx_ctx* ctx, double* tflops) {
   GPX_TRY(ctx->scal.ensure(4096) == hipSuccess ? 0 : -2);
   const int iters = 16384;
-  double best = 0.0;
-  // 1, 2 and 4 waves per SIMD; report the best sustained issue rate
+  double best = 0.0, best_cyc = 0.0, best_mhz = 0.0;
   for (int bpc = 1; bpc <= 4; bpc *= 2) {
     const int blocks = ctx->prop.multiProcessorCount * bpc;
-    mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(ctx->scal.d(), iters); // warm-up / clock ramp
+    double* probe = ctx->scal.d() + 64;
+    mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(probe, iters); // warm-up / clock ramp
     GPX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(ctx->scal.d(), iters);
+    mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(probe, iters);
     GPX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     GPX_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
     GPX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    double h[2];
+    GPX_HIP(ctx, hipMemcpy(h, probe, sizeof h, hipMemcpyDeviceToHost));
     const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
     const double tf = flops / (ms * 1e-3) / 1e12;
-    if (tf > best) best = tf;
+    if (tf > best) {
+      best = tf;
+      best_cyc = h[0] / ((double)iters * 8.0);
+      best_mhz = h[1] > 0 ? h[0] / (h[1] / 100.0) : 0.0; // wall clock ticks at 100 MHz
+    }
   }
-  *tflops = best;
+  tflops[0] = best;
+  tflops[1] = best_cyc;
+  tflops[2] = best_mhz;
   return 0;
 }
 

@@ -1,0 +1,426 @@
+"""
+ExactGP — fully Bayesian exact Gaussian process with the reference's method surface
+(gpax/models/gp.py:30-432), computed by libgpx on an MI355X.
+
+What changed underneath:
+  * the NumPyro model + NUTS (gp.py:137-220) become an explicit log-joint whose likelihood term
+    and analytic gradient come from gpx_factor / gpx_lml_grad, sampled by the host NUTS in
+    gpax_amd/infer/nuts.py;
+  * get_mvn_posterior (gp.py:253-277) uses POTRF + TRSM instead of the explicit inverse;
+  * predict (gp.py:351-399) runs the vmap over posterior samples as the device-resident sweep
+    gpx_predict_sweep (one theta in flight, nothing S*N*N is materialised);
+  * priors are gpax_amd.infer.dist objects (NumPyro is not a dependency); `kernel_prior` /
+    `noise_prior` (callables that run numpyro.sample) are not supported;
+  * rng_key is an opaque seed (utils.rng_from_key); JAX threefry streams are not reproduced.
+"""
+from __future__ import annotations
+
+import sys
+import warnings
+from typing import Callable, Dict, Optional, Tuple, Union
+
+import numpy as np
+
+from .. import _lib
+from ..infer import dist
+from ..infer.nuts import run_nuts
+from ..kernels.kernels import kernel_name
+from ..utils.utils import rng_from_key, split_in_batches
+
+kernel_fn_type = Callable[[np.ndarray, np.ndarray, Dict[str, np.ndarray], np.ndarray], np.ndarray]
+
+
+class _Site:
+    def __init__(self, name: str, shape: Tuple[int, ...], distribution: dist.Distribution):
+        self.name, self.shape, self.dist = name, tuple(shape), distribution
+        self.size = int(np.prod(shape)) if shape else 1
+
+
+class ExactGP:
+    """
+    Gaussian process class
+
+    Args:
+        input_dim: number of input (feature) dimensions
+        kernel: 'RBF' or 'Matern' (or gpax_amd.kernels.RBFKernel / MaternKernel)
+        mean_fn: optional deterministic mean function  mean_fn(X) or mean_fn(X, params)
+        kernel_prior: not supported on this path (NumPyro-program callable in the reference)
+        mean_fn_prior: dict name -> distribution (or a callable returning one) for the mean-function
+            parameters; the reference takes a callable that runs numpyro.sample
+        noise_prior: not supported (deprecated in the reference)
+        noise_prior_dist: prior on the noise variance (default LogNormal(0, 1))
+        lengthscale_prior_dist: prior on the lengthscales (default LogNormal(0, 1))
+    """
+
+    def __init__(
+        self,
+        input_dim: int,
+        kernel: Union[str, kernel_fn_type],
+        mean_fn: Optional[Callable] = None,
+        kernel_prior: Optional[Callable] = None,
+        mean_fn_prior=None,
+        noise_prior: Optional[Callable] = None,
+        noise_prior_dist: Optional[dist.Distribution] = None,
+        lengthscale_prior_dist: Optional[dist.Distribution] = None,
+    ) -> None:
+        if noise_prior is not None:
+            warnings.warn("`noise_prior` is deprecated in gpax; use `noise_prior_dist`.", FutureWarning)
+            raise NotImplementedError("`noise_prior` callables run numpyro.sample and have no MI355X path; "
+                                      "pass `noise_prior_dist` (gpax_amd.dist.*) instead")
+        if kernel_prior is not None:
+            raise NotImplementedError("`kernel_prior` callables run numpyro.sample and have no MI355X path; "
+                                      "pass `lengthscale_prior_dist` (gpax_amd.dist.*) instead")
+        self.kernel_dim = input_dim
+        self.kernel_name = kernel_name(kernel)
+        self.kernel = kernel
+        self._kind = _lib.kernel_kind(self.kernel_name)
+        self.mean_fn = mean_fn
+        self.kernel_prior = None
+        self.mean_fn_prior = mean_fn_prior
+        self.noise_prior = None
+        self.noise_prior_dist = noise_prior_dist
+        self.lengthscale_prior_dist = lengthscale_prior_dist
+        self.X_train = None
+        self.y_train = None
+        self.mcmc = None
+        self._samples = None
+        self._chain_shape = None
+        self._device = None
+
+    # ------------------------------------------------------------------------------------------
+    # model definition: sites, transforms, log-joint  (gp.py:137-164, 222-247)
+    # ------------------------------------------------------------------------------------------
+    def _mean_prior_dict(self) -> Dict[str, dist.Distribution]:
+        if self.mean_fn_prior is None:
+            return {}
+        pri = self.mean_fn_prior() if callable(self.mean_fn_prior) else self.mean_fn_prior
+        if not isinstance(pri, dict) or not all(isinstance(v, dist.Distribution) for v in pri.values()):
+            raise NotImplementedError("mean_fn_prior must be a dict name -> gpax_amd.dist distribution "
+                                      "(or a callable returning one)")
+        return pri
+
+    def _sites(self):
+        length_dist = self.lengthscale_prior_dist if self.lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
+        noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
+        sites = [_Site("k_length", (self.kernel_dim,), length_dist),  # plate "ard", gp.py:238-239
+                 _Site("k_scale", (), dist.LogNormal(0.0, 1.0)),     # gp.py:241
+                 _Site("noise", (), noise_dist)]                     # gp.py:222-227
+        for name, d in self._mean_prior_dict().items():
+            sites.append(_Site(name, (), d))
+        return sites
+
+    def _engine(self) -> _lib.Engine:
+        eng = _lib.get_engine(self._device)
+        if getattr(eng, "_train_owner", None) is not self or getattr(eng, "_train_version", None) is not self.X_train:
+            eng.set_train(self.X_train)
+            eng._train_owner = self
+            eng._train_version = self.X_train
+        return eng
+
+    def _mean(self, X, params) -> np.ndarray:
+        if self.mean_fn is None:
+            return np.zeros(X.shape[0])
+        args = [X, params] if self.mean_fn_prior is not None else [X]
+        return np.asarray(self.mean_fn(*args), dtype=np.float64).squeeze()
+
+    def _unpack(self, sites, u):
+        theta, off = {}, 0
+        for s in sites:
+            ui = u[off:off + s.size]
+            x = s.dist.transform(ui)
+            theta[s.name] = x.reshape(s.shape) if s.shape else float(x[0])
+            off += s.size
+        return theta
+
+    def _log_joint(self, sites, u, jitter: float, jacobian: bool, want_grad: bool = True):
+        """log p(y | theta) + log p(theta) [+ log |dtheta/du|] at theta = T(u) and its gradient
+        w.r.t. u.  Returns (value, grad) — (-inf, zeros) when K(theta) is not positive definite."""
+        theta = self._unpack(sites, u)
+        eng = self._engine()
+        yres = self.y_train - self._mean(self.X_train, theta)
+        lml, info = eng.factor(self._kind, theta["k_length"], theta["k_scale"], theta["noise"], jitter, yres)
+        if info != 0 or not np.isfinite(lml):
+            return -np.inf, np.zeros_like(u)
+        val = lml
+        grad = np.zeros_like(u)
+        if want_grad:
+            g_ell, g_scale, g_noise, alpha = eng.lml_grad()
+            glik = {"k_length": g_ell, "k_scale": np.array([g_scale]), "noise": np.array([g_noise])}
+        off = 0
+        for s in sites:
+            ui = u[off:off + s.size]
+            x = s.dist.transform(ui)
+            val += float(np.sum(s.dist.log_prob(x)))
+            if jacobian:
+                lj, dlj = s.dist.log_abs_det_jacobian(ui)
+                val += float(np.sum(lj))
+            if want_grad:
+                if s.name in glik:
+                    gx = np.asarray(glik[s.name], dtype=np.float64).reshape(-1)
+                else:  # mean-function parameter: d lml / d phi = sum_i alpha_i d m_i / d phi
+                    h = 1e-6 * max(1.0, abs(float(x[0])))
+                    tp, tm = dict(theta), dict(theta)
+                    tp[s.name] = float(x[0]) + h
+                    tm[s.name] = float(x[0]) - h
+                    dm = (self._mean(self.X_train, tp) - self._mean(self.X_train, tm)) / (2 * h)
+                    gx = np.array([float(alpha @ dm)])
+                gx = gx + s.dist.grad_log_prob(x)
+                gu = gx * s.dist.dx_du(ui)
+                if jacobian:
+                    gu = gu + dlj
+                grad[off:off + s.size] = gu
+            off += s.size
+        return val, grad
+
+    def _init_unconstrained(self, sites, rng, num_samples: int = 10):
+        """init_to_median(num_samples=10) (gp.py:207): per-site median of prior draws."""
+        parts = []
+        for s in sites:
+            draws = s.dist.sample(rng, (num_samples, s.size))
+            parts.append(s.dist.inverse(np.median(draws, axis=0)))
+        return np.concatenate(parts)
+
+    # ------------------------------------------------------------------------------------------
+    # fit  (gp.py:166-220)
+    # ------------------------------------------------------------------------------------------
+    def fit(
+        self,
+        rng_key,
+        X: np.ndarray,
+        y: np.ndarray,
+        num_warmup: int = 2000,
+        num_samples: int = 2000,
+        num_chains: int = 1,
+        chain_method: str = "sequential",
+        progress_bar: bool = True,
+        print_summary: bool = True,
+        device=None,
+        **kwargs: float,
+    ) -> None:
+        """Run Hamiltonian Monte Carlo (NUTS) to infer the GP parameters.  `device` is a GPU
+        ordinal (None: $LOCAL_RANK or 0).  **jitter: diagonal jitter (default 1e-6)."""
+        X, y = self._set_data(X, y)
+        self._device = device if isinstance(device, int) else None
+        self.X_train = X
+        self.y_train = y
+        jitter = float(kwargs.get("jitter", 1e-6))
+        rng = rng_from_key(rng_key)
+        sites = self._sites()
+
+        def potential(u):
+            v, g = self._log_joint(sites, u, jitter, jacobian=True)
+            return (-v, -g) if np.isfinite(v) else (np.inf, np.zeros_like(u))
+
+        chains, stats = [], []
+        for c in range(num_chains):
+            u0 = None
+            for _ in range(100):  # like NumPyro: redraw until the initial potential is finite
+                u0 = self._init_unconstrained(sites, rng)
+                if np.isfinite(potential(u0)[0]):
+                    break
+            prog = _Progress(progress_bar, f"chain {c + 1}/{num_chains}" if num_chains > 1 else "sample")
+            res = run_nuts(potential, u0, num_warmup, num_samples, rng, progress=prog)
+            prog.close()
+            chains.append(res["draws"])
+            stats.append({k: v for k, v in res.items() if k != "draws"})
+        draws = np.stack(chains)  # (chains, S, dim)
+        samples = {}
+        off = 0
+        for s in sites:
+            ui = draws[:, :, off:off + s.size]
+            x = s.dist.transform(ui)
+            samples[s.name] = x if s.shape else x[..., 0]
+            off += s.size
+        self._samples = samples
+        self._chain_shape = draws.shape[:2]
+        self.mcmc = _MCMCResult(self, stats)
+        if print_summary:
+            self._print_summary()
+
+    def get_samples(self, chain_dim: bool = False) -> Dict[str, np.ndarray]:
+        """Posterior samples (gp.py:249-251): leading axis S, or (chains, S) when chain_dim."""
+        if self._samples is None:
+            raise RuntimeError("call fit() first")
+        if chain_dim:
+            return dict(self._samples)
+        return {k: v.reshape((-1,) + v.shape[2:]) for k, v in self._samples.items()}
+
+    # ------------------------------------------------------------------------------------------
+    # posterior for one sample  (gp.py:253-293)
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _scalar(v) -> float:
+        return float(np.asarray(v, dtype=np.float64).reshape(-1)[0])
+
+    def get_mvn_posterior(self, X_new: np.ndarray, params: Dict[str, np.ndarray], noiseless: bool = False,
+                          **kwargs: float) -> Tuple[np.ndarray, np.ndarray]:
+        """Mean and covariance of the multivariate normal posterior for a single sample of GP
+        parameters (gp.py:253-277)."""
+        X_new = self._set_data(X_new)
+        jitter = float(kwargs.get("jitter", 1e-6))
+        noise = self._scalar(params["noise"])
+        noise_p = noise * (1 - int(bool(noiseless)))
+        y_residual = self.y_train - self._mean(self.X_train, params)
+        eng = self._engine()
+        lml, info = eng.factor(self._kind, params["k_length"], self._scalar(params["k_scale"]), noise, jitter,
+                               y_residual)
+        mean, cov, _ = eng.posterior(X_new, noise_p, jitter, want_cov=True)
+        if info != 0:
+            mean = np.full_like(mean, np.nan)
+            cov = np.full_like(cov, np.nan)
+        if self.mean_fn is not None:
+            mean = mean + self._mean(X_new, params)
+        return mean, cov
+
+    def _predict(self, rng_key, X_new: np.ndarray, params: Dict[str, np.ndarray], n: int, noiseless: bool = False,
+                 **kwargs: float) -> Tuple[np.ndarray, np.ndarray]:
+        """Prediction with a single sample of GP parameters (gp.py:279-293)."""
+        y_mean, K = self.get_mvn_posterior(X_new, params, noiseless, **kwargs)
+        eps = rng_from_key(rng_key).standard_normal((n, y_mean.shape[0]))
+        if not np.all(np.isfinite(K)):
+            return y_mean, np.full((n, y_mean.shape[0]), np.nan)
+        draws, info = self._engine().mvn_draw(eps)  # mean-function-free draw: loc + L eps
+        if self.mean_fn is not None:
+            draws = draws + self._mean(self._set_data(X_new), params)[None, :]
+        return y_mean, draws
+
+    # ------------------------------------------------------------------------------------------
+    # predict  (gp.py:295-399)
+    # ------------------------------------------------------------------------------------------
+    def _predict_in_batches(self, rng_key, X_new, batch_size=100, batch_dim=0, samples=None, n=1, filter_nans=False,
+                            predict_fn=None, noiseless=False, device=None, **kwargs):
+        if predict_fn is None:
+            predict_fn = lambda xi: self.predict(rng_key, xi, samples, n, filter_nans, noiseless, device, **kwargs)
+        y_out1, y_out2 = [], []
+        for Xi in split_in_batches(X_new, batch_size, dim=batch_dim):
+            out1, out2 = predict_fn(Xi)
+            y_out1.append(out1)
+            y_out2.append(out2)
+        return y_out1, y_out2
+
+    def predict_in_batches(self, rng_key, X_new, batch_size=100, samples=None, n=1, filter_nans=False,
+                           predict_fn=None, noiseless=False, device=None, **kwargs):
+        """predict() over slices of X_new (gp.py:325-349); same rng_key for every slice."""
+        y_pred, y_sampled = self._predict_in_batches(rng_key, X_new, batch_size, 0, samples, n, filter_nans,
+                                                     predict_fn, noiseless, device, **kwargs)
+        return np.concatenate(y_pred, 0), np.concatenate(y_sampled, -1)
+
+    def predict(self, rng_key, X_new: np.ndarray, samples: Optional[Dict[str, np.ndarray]] = None, n: int = 1,
+                filter_nans: bool = False, noiseless: bool = False, device=None,
+                **kwargs: float) -> Tuple[np.ndarray, np.ndarray]:
+        """
+        Make prediction at X_new points using posterior samples for GP parameters (gp.py:351-399).
+
+        Returns the centre of mass of the sampled means (M,) and all sampled predictions (S, n, M).
+        """
+        X_new = self._set_data(X_new)
+        if samples is None:
+            samples = self.get_samples(chain_dim=False)
+        if isinstance(device, int):
+            self._device = device
+        jitter = float(kwargs.get("jitter", 1e-6))
+        S = len(next(iter(samples.values())))
+        d, M = self.kernel_dim, X_new.shape[0]
+        ells = np.asarray(samples["k_length"], dtype=np.float64).reshape(S, -1)
+        ells = np.ascontiguousarray(np.broadcast_to(ells, (S, d)))
+        scales = np.asarray(samples["k_scale"], dtype=np.float64).reshape(S)
+        noises = np.asarray(samples["noise"], dtype=np.float64).reshape(S)
+        mean_shift = None
+        if self.mean_fn is not None:
+            per = [{k: np.asarray(v)[s] for k, v in samples.items()} for s in range(S)]
+            yres = np.stack([self.y_train - self._mean(self.X_train, p) for p in per])
+            mean_shift = np.stack([self._mean(X_new, p) for p in per])
+        else:
+            yres = self.y_train
+        eps = rng_from_key(rng_key).standard_normal((S, n, M))
+        means, y_sampled, infos = self._engine().predict_sweep(self._kind, ells, scales, noises, yres, X_new,
+                                                               noiseless, jitter, eps)
+        if mean_shift is not None:
+            means = means + mean_shift
+            y_sampled = y_sampled + mean_shift[:, None, :]
+        if filter_nans:
+            keep = ~np.isnan(y_sampled).any(axis=(1, 2))
+            y_sampled = y_sampled[keep]
+        return means.mean(0), y_sampled
+
+    def sample_from_prior(self, rng_key, X: np.ndarray, num_samples: int = 10):
+        """Samples from the prior predictive distribution at X (gp.py:401-408)."""
+        X = self._set_data(X)
+        rng = rng_from_key(rng_key)
+        eng = _lib.get_engine(self._device)
+        out = np.empty((num_samples, X.shape[0]))
+        for i in range(num_samples):
+            theta = {s.name: (s.dist.sample(rng, s.shape) if s.shape else float(s.dist.sample(rng))) for s in self._sites()}
+            K = eng.gram(self._kind, X, X, theta["k_length"], theta["k_scale"], theta["noise"] + 1e-6, True)
+            L, info = eng.potrf(K)
+            out[i] = self._mean(X, theta) + L @ rng.standard_normal(X.shape[0]) if info == 0 else np.nan
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # data plumbing  (gp.py:410-432)
+    # ------------------------------------------------------------------------------------------
+    def _set_data(self, X, y=None):
+        X = np.asarray(X, dtype=np.float64)
+        X = X if X.ndim > 1 else X[:, None]
+        X = np.ascontiguousarray(X)
+        if y is not None:
+            return X, np.ascontiguousarray(np.asarray(y, dtype=np.float64).squeeze())
+        return X
+
+    def _set_training_data(self, X_train_new=None, y_train_new=None, device=None) -> None:
+        if X_train_new is not None:
+            self.X_train = self._set_data(X_train_new)
+        if y_train_new is not None:
+            self.y_train = np.ascontiguousarray(np.asarray(y_train_new, dtype=np.float64).squeeze())
+        if isinstance(device, int):
+            self._device = device
+
+    def _print_summary(self):
+        samples = self.get_samples(chain_dim=True)
+        print_summary(samples)
+
+
+class _MCMCResult:
+    """Stand-in for `self.mcmc` (the reference stores the numpyro MCMC object)."""
+
+    def __init__(self, model, stats):
+        self._model, self.stats = model, stats
+
+    def get_samples(self, group_by_chain: bool = False):
+        return self._model.get_samples(chain_dim=group_by_chain)
+
+    def get_extra_fields(self):
+        return self.stats
+
+
+class _Progress:
+    def __init__(self, enabled: bool, label: str):
+        self.enabled, self.label, self.last = enabled, label, -1
+
+    def __call__(self, it, total, info):
+        if not self.enabled:
+            return
+        pct = (it + 1) * 100 // total
+        if pct != self.last and (pct % 5 == 0 or it + 1 == total):
+            self.last = pct
+            extra = ", ".join(f"{k}={v:.3g}" if isinstance(v, float) else f"{k}={v}" for k, v in info.items())
+            sys.stdout.write(f"\r{self.label}: {pct:3d}% [{it + 1}/{total}] {extra}   ")
+            sys.stdout.flush()
+
+    def close(self):
+        if self.enabled:
+            sys.stdout.write("\n")
+
+
+def print_summary(samples: Dict[str, np.ndarray]) -> None:
+    """Plain-text posterior summary (the reference prints numpyro.diagnostics.print_summary)."""
+    print(f"\n{'':>16s}{'mean':>10s}{'std':>10s}{'median':>10s}{'5.0%':>10s}{'95.0%':>10s}")
+    for name, v in samples.items():
+        flat = np.asarray(v).reshape((-1,) + np.asarray(v).shape[2:])
+        cols = flat.reshape(flat.shape[0], -1)
+        for j in range(cols.shape[1]):
+            c = cols[:, j]
+            label = name if cols.shape[1] == 1 else f"{name}[{j}]"
+            print(f"{label:>16s}{c.mean():10.2f}{c.std():10.2f}{np.median(c):10.2f}"
+                  f"{np.quantile(c, 0.05):10.2f}{np.quantile(c, 0.95):10.2f}")
+    print()

@@ -1,0 +1,135 @@
+"""
+viGP — variational-inference exact GP with the reference's surface (gpax/models/vigp.py:28-192):
+SVI (Adam, b1 = 0.5) with a Delta (MAP) or mean-field Normal guide; predict returns
+(mean, variance).  The ELBO's likelihood term and gradient are the same device lml / gradient
+pass ExactGP uses; predict computes diag(cov) directly (gpx_posterior `var`) instead of forming
+an M x M covariance to take its diagonal (vigp.py:184-185), and predict_in_batches factors K
+once instead of re-inverting it for every slice (vigp.py:129-151).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import numpy as np
+
+from ..infer import dist
+from ..infer.svi import fit_delta, fit_normal
+from ..utils.utils import rng_from_key, split_in_batches
+from .gp import ExactGP, _Progress
+
+
+class viGP(ExactGP):
+    """
+    Gaussian process via stochastic variational inference
+
+    Args: as ExactGP, plus
+        guide: 'delta' (MAP, default) or 'normal' (mean-field AutoNormal)
+    """
+
+    def __init__(self, input_dim: int, kernel: str, mean_fn: Optional[Callable] = None, kernel_prior=None,
+                 mean_fn_prior=None, noise_prior=None, noise_prior_dist: Optional[dist.Distribution] = None,
+                 lengthscale_prior_dist: Optional[dist.Distribution] = None, guide: str = 'delta') -> None:
+        super().__init__(input_dim, kernel, mean_fn, kernel_prior, mean_fn_prior, noise_prior, noise_prior_dist,
+                         lengthscale_prior_dist)
+        self.guide_type = 'normal' if guide == 'normal' else 'delta'
+        self.svi = None
+        self.kernel_params = None
+        self.loss = None
+
+    def _init_delta(self, sites):
+        return np.concatenate([s.dist.inverse(np.full(s.size, s.dist.median(), dtype=np.float64)) for s in sites])
+
+    def _run_svi(self, sites, rng, num_steps, step_size, jitter, progress_bar, extra=None):
+        """Shared by viGP and viSparseGP (`extra` = additional unconstrained parameters and their
+        objective hook, used for the inducing points)."""
+        prog = _Progress(progress_bar, "svi")
+        if self.guide_type == 'delta':
+            obj = lambda u: self._log_joint(sites, u, jitter, jacobian=False)
+            u, losses = fit_delta(obj, self._init_delta(sites), num_steps, step_size, prog)
+            scale = None
+        else:
+            dim = sum(s.size for s in sites)
+            obj = lambda u: self._log_joint(sites, u, jitter, jacobian=True)
+            u, scale, losses = fit_normal(obj, dim, num_steps, step_size, rng, progress=prog)
+        prog.close()
+        return u, scale, losses
+
+    def fit(self, rng_key, X: np.ndarray, y: np.ndarray, num_steps: int = 1000, step_size: float = 5e-3,
+            progress_bar: bool = True, print_summary: bool = True, device=None, **kwargs: float) -> None:
+        """Run variational inference to learn the GP (hyper)parameters (vigp.py:77-123)."""
+        X, y = self._set_data(X, y)
+        self._device = device if isinstance(device, int) else None
+        self.X_train = X
+        self.y_train = y
+        jitter = float(kwargs.get("jitter", 1e-6))
+        sites = self._sites()
+        u, scale, losses = self._run_svi(sites, rng_from_key(rng_key), num_steps, step_size, jitter, progress_bar)
+        self._store_guide(sites, u, scale, losses)
+        if print_summary:
+            self._print_summary()
+
+    def _store_guide(self, sites, u, scale, losses):
+        self._svi_sites = sites
+        self.kernel_params = {"auto_loc": u, "auto_scale": scale}
+        self.loss = losses
+        self.svi = self  # the reference keeps the numpyro SVI object; `svi is not None` after fit
+
+    def get_samples(self) -> Dict[str, np.ndarray]:
+        """Guide median in the constrained space (vigp.py:125-127)."""
+        if self.kernel_params is None:
+            raise RuntimeError("call fit() first")
+        theta = self._unpack(self._svi_sites, self.kernel_params["auto_loc"])
+        return {k: np.asarray(v) for k, v in theta.items()}
+
+    def predict_in_batches(self, rng_key, X_new: np.ndarray, batch_size: int = 100,
+                           samples: Optional[Dict[str, np.ndarray]] = None, predict_fn=None, noiseless: bool = False,
+                           device=None, **kwargs: float) -> Tuple[np.ndarray, np.ndarray]:
+        """predict() over slices of X_new (vigp.py:129-151).  K is factored once for all slices."""
+        X_new = self._set_data(X_new)
+        if samples is None:
+            samples = self.get_samples()
+        jitter = float(kwargs.get("jitter", 1e-6))
+        if predict_fn is None:
+            self._factor_at(samples, jitter)
+            predict_fn = lambda xi: self._posterior_mean_var(xi, samples, noiseless, jitter)
+        y_pred, y_var = [], []
+        for Xi in split_in_batches(X_new, batch_size, dim=0):
+            m, v = predict_fn(Xi)
+            y_pred.append(m)
+            y_var.append(v)
+        return np.concatenate(y_pred, 0), np.concatenate(y_var, 0)
+
+    def _factor_at(self, params, jitter):
+        noise = self._scalar(params["noise"])
+        y_residual = self.y_train - self._mean(self.X_train, params)
+        return self._engine().factor(self._kind, params["k_length"], self._scalar(params["k_scale"]), noise, jitter,
+                                     y_residual)
+
+    def _posterior_mean_var(self, X_new, params, noiseless, jitter):
+        noise_p = self._scalar(params["noise"]) * (1 - int(bool(noiseless)))
+        mean, _, var = self._engine().posterior(X_new, noise_p, jitter, want_cov=False, want_var=True)
+        if self.mean_fn is not None:
+            mean = mean + self._mean(X_new, params)
+        return mean, var
+
+    def predict(self, rng_key, X_new: np.ndarray, samples: Optional[Dict[str, np.ndarray]] = None,
+                noiseless: bool = False, device=None, **kwargs: float) -> Tuple[np.ndarray, np.ndarray]:
+        """Posterior mean and variance at X_new (vigp.py:153-185)."""
+        X_new = self._set_data(X_new)
+        if isinstance(device, int):
+            self._device = device
+        if samples is None:
+            samples = self.get_samples()
+        jitter = float(kwargs.get("jitter", 1e-6))
+        lml, info = self._factor_at(samples, jitter)
+        mean, var = self._posterior_mean_var(X_new, samples, noiseless, jitter)
+        if info != 0:
+            mean, var = np.full_like(mean, np.nan), np.full_like(var, np.nan)
+        return mean, var
+
+    def _print_summary(self) -> None:
+        params_map = self.get_samples()
+        print('\nInferred GP parameters')
+        for (k, vals) in params_map.items():
+            spaces = " " * (15 - len(k))
+            print(k, spaces, np.around(vals, 4))

@@ -1,0 +1,119 @@
+"""
+Host-side helpers mirroring gpax/utils/utils.py (the seven on the exact-GP path).
+
+PRNG keys: the reference passes JAX threefry keys; those streams cannot be reproduced without
+JAX, so a "key" here is an opaque seed object — get_keys(seed) returns two uint32[2] arrays
+derived with numpy.random.SeedSequence, and every consumer turns a key into a
+numpy.random.Generator with `rng_from_key` (ints, Generators and any array-like are accepted).
+"""
+from typing import Dict, List, Union
+
+import numpy as np
+
+
+def enable_x64():
+    """gpax/utils/utils.py:19-21.  The MI355X path is fp64 end to end; kept for API parity."""
+    return None
+
+
+def get_keys(seed: int = 0):
+    """gpax/utils/utils.py:24-30: two independent keys for inference and prediction."""
+    ss = np.random.SeedSequence(int(seed))
+    k1, k2 = ss.spawn(2)
+    return k1.generate_state(2, dtype=np.uint32), k2.generate_state(2, dtype=np.uint32)
+
+
+def rng_from_key(rng_key) -> np.random.Generator:
+    if isinstance(rng_key, np.random.Generator):
+        return rng_key
+    if rng_key is None:
+        return np.random.default_rng()
+    arr = np.asarray(rng_key)
+    if arr.ndim == 0:
+        return np.random.default_rng(int(arr) & 0xFFFFFFFFFFFFFFFF)
+    return np.random.default_rng([int(v) & 0xFFFFFFFF for v in arr.reshape(-1)])
+
+
+def split_key(rng_key, num: int = 2):
+    """jax.random.split analogue on opaque keys."""
+    rng = rng_from_key(rng_key)
+    return [rng.integers(0, 2 ** 32, size=2, dtype=np.uint32) for _ in range(num)]
+
+
+def split_in_batches(X_new: np.ndarray, batch_size: int = 100, dim: int = 0):
+    """gpax/utils/utils.py:33-51.  The reference raises UnboundLocalError when the array is
+    shorter than one batch (its loop variable is never bound); here that case returns the
+    single short batch."""
+    if dim not in [0, 1]:
+        raise NotImplementedError("'dim' must be equal to 0 or 1")
+    n = X_new.shape[dim]
+    num_batches = n // batch_size
+    X_split = []
+    for i in range(num_batches):
+        X_i = X_new[i * batch_size:(i + 1) * batch_size] if dim == 0 else X_new[:, i * batch_size:(i + 1) * batch_size]
+        X_split.append(X_i)
+    rest = num_batches * batch_size
+    X_i = X_new[rest:] if dim == 0 else X_new[:, rest:]
+    if X_i.shape[dim] > 0:
+        X_split.append(X_i)
+    return X_split
+
+
+def split_dict(data: Dict[str, np.ndarray], chunk_size: int) -> List[Dict[str, np.ndarray]]:
+    """gpax/utils/utils.py:54-81"""
+    N = len(next(iter(data.values())))
+    num_chunks = int(np.ceil(N / chunk_size))
+    result = []
+    for i in range(num_chunks):
+        start_idx = i * chunk_size
+        end_idx = min((i + 1) * chunk_size, N)
+        result.append({key: value[start_idx:end_idx] for key, value in data.items()})
+    return result
+
+
+def random_sample_dict(data: Dict[str, np.ndarray], num_samples: int, rng_key) -> Dict[str, np.ndarray]:
+    """gpax/utils/utils.py:84-102: the same random subset of every array."""
+    num_data_points = len(next(iter(data.values())))
+    indices = rng_from_key(rng_key).permutation(num_data_points)[:num_samples]
+    return {key: value[indices] for key, value in data.items()}
+
+
+def preprocess_sparse_image(sparse_image: np.ndarray):
+    """gpax/utils/utils.py:150-168: zeros = missing pixels.  Returns (X_train (N,D), y (N,),
+    X_full (prod(shape), D)) in the image dtype."""
+    sparse_image = np.asarray(sparse_image)
+    dtype = sparse_image.dtype
+    non_zero_indices = np.nonzero(sparse_image)
+    gp_input = np.column_stack(non_zero_indices)
+    targets = sparse_image[non_zero_indices]
+    full_indices = np.array(np.meshgrid(*[np.arange(dim) for dim in sparse_image.shape])).T.reshape(
+        -1, sparse_image.ndim)
+    return gp_input.astype(dtype), targets.astype(dtype), full_indices.astype(dtype)
+
+
+def initialize_inducing_points(X, ratio=0.1, method='uniform', key=None):
+    """gpax/utils/utils.py:171-212.  'uniform' uses evenly spaced indices (the reference's int8
+    index dtype overflows beyond 128 points, utils.py:191; full-width integers here)."""
+    if not 0 < ratio < 1:
+        raise ValueError("The 'ratio' value must be between 0 and 1")
+    X = np.asarray(X)
+    n_samples = X.shape[0]
+    n_inducing = int(n_samples * ratio)
+    if method == 'uniform':
+        indices = np.linspace(0, n_samples - 1, n_inducing).astype(np.int64)
+        inducing_points = X[indices]
+    elif method == 'random':
+        if key is None:
+            raise ValueError("A JAX random key must be provided for random selection")
+        indices = rng_from_key(key).choice(n_samples, size=(n_inducing,), replace=False)
+        inducing_points = X[indices]
+    elif method == 'kmeans':
+        try:
+            from sklearn.cluster import KMeans
+        except ImportError as e:  # pragma: no cover
+            raise ImportError("You need to install `scikit-learn` to be able to use this feature.") from e
+        kmeans = KMeans(n_clusters=n_inducing, random_state=0, n_init=10).fit(X)
+        inducing_points = np.asarray(kmeans.cluster_centers_)
+    else:
+        raise ValueError("Method must be 'uniform', 'random', or 'kmeans'")
+    return inducing_points

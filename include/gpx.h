@@ -141,7 +141,8 @@ int gpx_sweep_resident(gpx_ctx* ctx, int kind, int S, const double* ells, const 
                        const double* noises, int noiseless, double jitter, int n_draws,
                        double* elapsed_ms);
 
-/* Raw MFMA fp64 ceiling microbenchmark (v_mfma_f64_16x16x4_f64 issue rate), TFLOP/s. */
+/* Raw MFMA fp64 ceiling microbenchmark (v_mfma_f64_16x16x4_f64 issue rate).  tflops must hold 3
+ * doubles: [0] sustained TFLOP/s, [1] shader cycles per MFMA per wave, [2] effective shader MHz. */
 int gpx_mfma_f64_peak(gpx_ctx* ctx, double* tflops);
 
 /* Plain GEMM entry used by the unit tests of the MFMA tile kernel:

@@ -1,0 +1,103 @@
+"""A checker-backed stand-in for gpax_amd._lib.Engine, used ONLY by the CPU tests of the host-side
+logic (NUTS / SVI drivers, model plumbing, sharding).  It implements the Engine methods with
+oracle/cpu_ref.py so those code paths can run where no GPU exists.  It lives under tests/ on
+purpose: the product has no CPU fallback."""
+import numpy as np
+import scipy.linalg as sla
+
+from gpax_amd._lib import broadcast_lengthscale
+from oracle import cpu_ref as ref
+
+_NAMES = {0: "RBF", 1: "Matern"}
+
+
+class OracleEngine:
+    device = 0
+
+    def __init__(self):
+        self.N = self.d = self.M = 0
+        self._post = None
+
+    def set_train(self, X):
+        self.X = np.asarray(X, dtype=np.float64)
+        self.N, self.d = self.X.shape
+
+    def gram(self, kind, X, Z, ell, scale, diag_add, add_diag):
+        X, Z = np.asarray(X, dtype=np.float64), np.asarray(Z, dtype=np.float64)
+        p = {"k_length": broadcast_lengthscale(ell, X.shape[1]), "k_scale": scale}
+        K = ref.get_kernel(_NAMES[kind])(X, Z, p, noise=0.0, jitter=0.0)
+        if add_diag:
+            K = K + diag_add * np.eye(X.shape[0])
+        return K
+
+    def potrf(self, A):
+        try:
+            return np.linalg.cholesky(A), 0
+        except np.linalg.LinAlgError:
+            return np.full_like(A, np.nan), 1
+
+    def factor(self, kind, ell, scale, noise, jitter, yres):
+        self._theta = dict(kind=kind, p={"k_length": broadcast_lengthscale(ell, self.d), "k_scale": float(scale),
+                                         "noise": float(noise)}, jitter=float(jitter))
+        self._yres = np.asarray(yres, dtype=np.float64)
+        K = self.gram(kind, self.X, self.X, ell, scale, noise + jitter, True)
+        try:
+            self._L = np.linalg.cholesky(K)
+        except np.linalg.LinAlgError:
+            self._L = None
+            return float("nan"), 1
+        w = sla.solve_triangular(self._L, self._yres, lower=True)
+        self._w = w
+        lml = -0.5 * w @ w - np.log(np.diag(self._L)).sum() - 0.5 * self.N * ref.LOG_2PI
+        return float(lml), 0
+
+    def lml_grad(self):
+        t = self._theta
+        return ref.exactgp_log_likelihood_grad(self.X, self._yres, t["p"], kernel=_NAMES[t["kind"]],
+                                               jitter=t["jitter"], yres=self._yres)
+
+    def posterior(self, Xnew, noise_p, jitter, want_cov=True, want_var=False):
+        t = self._theta
+        Xnew = np.asarray(Xnew, dtype=np.float64)
+        self.M = Xnew.shape[0]
+        if self._L is None:
+            nanv = np.full(self.M, np.nan)
+            self._post = (nanv, np.full((self.M, self.M), np.nan))
+            return nanv, (np.full((self.M, self.M), np.nan) if want_cov else None), (nanv if want_var else None)
+        kfn = ref.get_kernel(_NAMES[t["kind"]])
+        k_pX = kfn(Xnew, self.X, t["p"], jitter=0.0)
+        if Xnew.shape == self.X.shape:  # the reference's shape rule would add a diagonal here; k_pX never has one
+            k_pX = k_pX - 0.0 * np.eye(self.N)
+        V = sla.solve_triangular(self._L, k_pX.T, lower=True)
+        mean = V.T @ self._w
+        k_pp = kfn(Xnew, Xnew, t["p"], noise_p, jitter=jitter)
+        cov = k_pp - V.T @ V
+        self._post = (mean, cov)
+        return mean, (cov if want_cov else None), (np.diag(cov).copy() if want_var else None)
+
+    def mvn_draw(self, eps):
+        mean, cov = self._post
+        if np.isnan(cov).any():
+            return np.full((np.asarray(eps).shape[0], mean.shape[0]), np.nan), 1
+        out = ref.mvn_sample(mean, cov, np.asarray(eps))
+        return out, int(np.isnan(out).any())
+
+    def predict_sweep(self, kind, ells, scales, noises, yres, Xnew, noiseless, jitter, eps):
+        ells = np.asarray(ells, dtype=np.float64)
+        S = ells.shape[0]
+        Xnew = np.asarray(Xnew, dtype=np.float64)
+        M = Xnew.shape[0]
+        n = 0 if eps is None else np.asarray(eps).shape[1]
+        yres = np.asarray(yres, dtype=np.float64)
+        means, samples, infos = np.empty((S, M)), np.empty((S, n, M)), np.zeros(S, dtype=np.int32)
+        for s in range(S):
+            ys = yres if yres.ndim == 1 else yres[s]
+            lml, info = self.factor(kind, ells[s], scales[s], noises[s], jitter, ys)
+            m, cov, _ = self.posterior(Xnew, 0.0 if noiseless else noises[s], jitter)
+            means[s] = m
+            infos[s] = info
+            if n:
+                samples[s], bad = self.mvn_draw(eps[s])
+                if bad and not info:
+                    infos[s] = -1
+        return means, samples, infos

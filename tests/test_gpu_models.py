@@ -1,0 +1,93 @@
+"""GPU: the Python model surface end to end on the real engine (plumbing config C1 of BASELINE.json:
+ExactGP(1, 'RBF') on N=512 synthetic 1-D), parity with the oracle on deterministic quantities."""
+import numpy as np
+import pytest
+
+from gpax_amd import _lib, dist
+from gpax_amd.kernels import MaternKernel, RBFKernel
+from gpax_amd.models import ExactGP, viGP
+from gpax_amd.utils import get_keys
+from oracle import cpu_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def real_engine(engine):
+    _lib.set_engine(engine)
+    yield
+    _lib.set_engine(None)
+
+
+def test_kernel_callables_on_gpu():
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 5, (40, 2))
+    p = {"k_length": np.array([1.0, 2.0]), "k_scale": 1.5}
+    np.testing.assert_allclose(RBFKernel(X, X, p, noise=0.1), ref.RBFKernel(X, X, p, noise=0.1), rtol=1e-10)
+    np.testing.assert_allclose(MaternKernel(X, X[:7], p), ref.MaternKernel(X, X[:7], p), rtol=1e-10, atol=1e-12)
+
+
+def test_c1_exactgp_n512_fit_predict():
+    X, y, Xn, p = ref.synthetic_problem(512, 1, 100, seed=0)
+    m = ExactGP(1, "RBF")
+    m.fit(get_keys()[0], X, y, num_warmup=60, num_samples=60, progress_bar=False, print_summary=False)
+    s = m.get_samples()
+    assert s["k_length"].shape == (60, 1)
+    # the posterior concentrates near the generating noise level (0.1) for N=512
+    assert 0.05 < np.median(s["noise"]) < 0.2
+    ym, ys = m.predict(get_keys()[1], Xn, n=1)
+    assert ym.shape == (100,) and ys.shape == (60, 1, 100) and np.isfinite(ys).all()
+    f_true = np.sin(Xn[:, 0])
+    assert np.sqrt(np.mean((ym - f_true) ** 2)) < 0.15
+    # parity of the sweep with the oracle at the sampled thetas (deterministic given theta, eps)
+    sub = {k: v[:4] for k, v in s.items()}
+    mean_ref = np.stack([ref.get_mvn_posterior(X, y, Xn, {k: v[i] for k, v in sub.items()}, route="chol")[0]
+                         for i in range(4)])
+    ym4, _ = m.predict(get_keys()[1], Xn, samples=sub, n=1)
+    np.testing.assert_allclose(ym4, mean_ref.mean(0), rtol=1e-7, atol=1e-9)
+
+
+def test_log_joint_gradient_matches_finite_differences_on_gpu():
+    X, y, _, _ = ref.synthetic_problem(150, 2, 4, seed=2)
+    m = ExactGP(2, "Matern", noise_prior_dist=dist.HalfNormal(0.5))
+    m.X_train, m.y_train = m._set_data(X, y)
+    sites = m._sites()
+    u = np.array([0.1, -0.3, 0.2, -1.5])
+    v, g = m._log_joint(sites, u, 1e-6, True)
+    for i in range(4):
+        h = 1e-5
+        up, um = u.copy(), u.copy()
+        up[i] += h
+        um[i] -= h
+        fd = (m._log_joint(sites, up, 1e-6, True, False)[0] - m._log_joint(sites, um, 1e-6, True, False)[0]) / (2 * h)
+        assert abs(fd - g[i]) <= 1e-6 * max(1.0, abs(fd))
+
+
+@pytest.mark.parametrize("guide", ["delta", "normal"])
+def test_vigp_on_gpu(guide):
+    X, y, Xn, _ = ref.synthetic_problem(300, 2, 50, seed=4)
+    m = viGP(2, "Matern", guide=guide)
+    m.fit(get_keys()[0], X, y, num_steps=100, step_size=0.05, progress_bar=False, print_summary=False)
+    s = m.get_samples()
+    mean, var = m.predict(get_keys()[1], Xn)
+    m_ref, v_ref = ref.vigp_predict(X, y, Xn, s, kernel="Matern")
+    np.testing.assert_allclose(mean, m_ref, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(var, v_ref, rtol=1e-7, atol=1e-9)
+    mb, vb = m.predict_in_batches(get_keys()[1], Xn, batch_size=16)
+    np.testing.assert_allclose(mb, mean, rtol=1e-12)
+    np.testing.assert_allclose(vb, var, rtol=1e-12)
+    if guide == "delta":
+        assert m.loss[-1] < m.loss[0]
+
+
+def test_get_mvn_posterior_on_gpu_matches_reference_inverse_route():
+    X, y, Xn, p = ref.synthetic_problem(200, 2, 30, seed=6)
+    m = ExactGP(2, "RBF")
+    m.X_train, m.y_train = m._set_data(X, y)
+    params = {"k_length": p["k_length"], "k_scale": np.array([p["k_scale"]]), "noise": np.array([p["noise"]])}
+    mean, cov = m.get_mvn_posterior(Xn, params, noiseless=True, jitter=1e-5)
+    m_ref, c_ref = ref.get_mvn_posterior(X, y, Xn, p, True, kernel="RBF", jitter=1e-5, route="inv")
+    np.testing.assert_allclose(mean, m_ref, rtol=1e-8)
+    np.testing.assert_allclose(cov, c_ref, rtol=1e-6, atol=1e-9)
+    ymean, ydraw = m._predict(get_keys()[1], Xn, params, 3)
+    assert ydraw.shape == (3, 30)

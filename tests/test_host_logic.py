@@ -1,0 +1,232 @@
+"""CPU: the host-side model classes (ExactGP / viGP surface, NUTS / SVI drivers, plumbing) run
+against a checker-backed engine injected from tests/oracle_engine.py.  Mirrors the reference's
+own assertions (gpax/tests/test_gp.py, test_vigp.py, test_utils.py, test_kernels.py): shapes,
+types, determinism, sensitivity — plus parity of deterministic quantities with the oracle."""
+import numpy as np
+import pytest
+
+import gpax_amd
+from gpax_amd import _lib, dist
+from gpax_amd.models import ExactGP, viGP
+from gpax_amd.utils import (get_keys, initialize_inducing_points, preprocess_sparse_image, random_sample_dict,
+                            split_dict, split_in_batches)
+from oracle import cpu_ref as ref
+from tests.oracle_engine import OracleEngine
+
+
+@pytest.fixture(autouse=True)
+def oracle_engine():
+    eng = OracleEngine()
+    _lib.set_engine(eng)
+    yield eng
+    _lib.set_engine(None)
+
+
+def get_dummy_data(n=8, seed=0):
+    rng = np.random.default_rng(seed)
+    X = np.linspace(1, 2, n) + 0.1 * rng.standard_normal(n)
+    y = 10 * X ** 2 * 0.1
+    return X, y
+
+
+@pytest.mark.parametrize("kernel", ["RBF", "Matern"])
+@pytest.mark.parametrize("dim", [1, 2])
+def test_fit_get_samples_shapes(kernel, dim):
+    rng_key = get_keys()[0]
+    X, y = get_dummy_data()
+    if dim == 2:
+        X = np.stack([X, X[::-1]], 1)
+    m = ExactGP(dim, kernel)
+    m.fit(rng_key, X, y, num_warmup=30, num_samples=40, progress_bar=False, print_summary=False)
+    assert m.mcmc is not None
+    s = m.get_samples()
+    assert set(s) == {"k_length", "k_scale", "noise"}
+    assert s["k_length"].shape == (40, dim) and s["k_scale"].shape == (40,) and s["noise"].shape == (40,)
+    assert all(np.all(v > 0) for v in s.values())
+    s2 = m.get_samples(chain_dim=True)
+    assert s2["k_length"].shape == (1, 40, dim)
+
+
+def test_fit_same_key_same_samples_and_jitter_sensitivity():
+    X, y = get_dummy_data()
+    outs = []
+    for jit in [1e-6, 1e-6, 1e-5]:
+        m = ExactGP(1, "RBF")
+        m.fit(get_keys()[0], X, y, num_warmup=20, num_samples=20, progress_bar=False, print_summary=False, jitter=jit)
+        outs.append(m.get_samples()["k_length"])
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert not np.array_equal(outs[0], outs[2])
+
+
+def test_two_chains_and_custom_priors():
+    X, y = get_dummy_data()
+    m = ExactGP(1, "Matern", noise_prior_dist=dist.HalfNormal(0.1), lengthscale_prior_dist=dist.Gamma(2, 5))
+    m.fit(get_keys()[0], X, y, num_warmup=20, num_samples=25, num_chains=2, progress_bar=False, print_summary=True)
+    assert m.get_samples(chain_dim=True)["k_length"].shape == (2, 25, 1)
+    assert m.get_samples()["noise"].shape == (50,)
+    assert np.median(m.get_samples()["noise"]) < 1.0
+
+
+def test_unsupported_inputs_raise_clearly():
+    with pytest.raises(NotImplementedError):
+        ExactGP(1, "Periodic")
+    with pytest.raises(NotImplementedError):
+        ExactGP(1, lambda a, b, c: None)
+    with pytest.raises(NotImplementedError):
+        ExactGP(1, "RBF", kernel_prior=lambda: {})
+
+
+@pytest.mark.parametrize("noiseless", [False, True])
+def test_get_mvn_posterior_matches_oracle_and_invariants(noiseless):
+    X, y, Xn, p = ref.synthetic_problem(40, 2, 12, seed=3)
+    m = ExactGP(2, "RBF")
+    m.X_train, m.y_train = m._set_data(X, y)
+    params = {"k_length": np.array([[1.0, 1.25]]), "k_scale": np.array([1.3]), "noise": np.array([0.1])}
+    mean, cov = m.get_mvn_posterior(Xn, params, noiseless)
+    assert mean.shape == (12,) and cov.shape == (12, 12)
+    m_ref, c_ref = ref.get_mvn_posterior(X, y, Xn, p, noiseless, kernel="RBF", route="inv")
+    np.testing.assert_allclose(mean, m_ref, rtol=1e-9)
+    np.testing.assert_allclose(cov, c_ref, rtol=1e-8, atol=1e-10)
+    mean2, cov2 = m.get_mvn_posterior(Xn, params, noiseless)
+    np.testing.assert_array_equal(mean, mean2)
+    np.testing.assert_array_equal(cov, cov2)
+
+
+def test_predict_shapes_negative_variances_do_not_crash():
+    # gpax/tests/test_gp.py:173-206: "samples" drawn from N(0,1)
+    X, y = get_dummy_data()
+    rng = np.random.default_rng(1)
+    samples = {"k_length": rng.standard_normal((100, 1)), "k_scale": rng.standard_normal(100),
+               "noise": rng.standard_normal(100)}
+    samples["k_length"] = np.abs(samples["k_length"]) + 0.1
+    m = ExactGP(1, "RBF")
+    m.X_train, m.y_train = m._set_data(X, y)
+    Xn = np.linspace(1, 2, 5)
+    for n in [1, 10]:
+        y_mean, y_sampled = m.predict(get_keys()[1], Xn, samples, n=n)
+        assert y_mean.shape == (5,) and y_sampled.shape == (100, n, 5)
+    _, ys = m.predict(get_keys()[1], Xn, samples, n=1, filter_nans=True)
+    assert ys.shape[0] < 100 and not np.isnan(ys).any()
+
+
+def test_predict_in_batches_equals_predict_on_means():
+    X, y, Xn, _ = ref.synthetic_problem(30, 1, 8, seed=5)
+    samples = ref.synthetic_theta_samples(6, 1)
+    m = ExactGP(1, "Matern")
+    m.X_train, m.y_train = m._set_data(X, y)
+    key = get_keys()[1]
+    ym, ys = m.predict(key, Xn, samples, n=2)
+    for bs in [2, 3, 8]:
+        ymb, ysb = m.predict_in_batches(key, Xn, bs, samples, n=2)
+        assert ymb.shape == (8,) and ysb.shape == (6, 2, 8)
+        np.testing.assert_allclose(ymb, ym, rtol=1e-9)
+
+
+def test_predict_with_mean_function_and_prior():
+    X, y, Xn, _ = ref.synthetic_problem(30, 1, 8, seed=6)
+    y = y + 2.0 * X[:, 0]
+    mean_fn = lambda x, p: p["a"] * x[:, 0]
+    m = ExactGP(1, "RBF", mean_fn=mean_fn, mean_fn_prior={"a": dist.Normal(2.0, 0.5)})
+    m.fit(get_keys()[0], X, y, num_warmup=30, num_samples=30, progress_bar=False, print_summary=False)
+    s = m.get_samples()
+    assert "a" in s and s["a"].shape == (30,) and abs(np.median(s["a"]) - 2.0) < 1.0
+    ym, ys = m.predict(get_keys()[1], Xn, n=1)
+    assert ym.shape == (8,) and ys.shape == (30, 1, 8)
+    # parity of the mean-function chain rule with finite differences of the log joint
+    sites = m._sites()
+    u = np.array([0.1, -0.2, -1.0, 1.9])
+    v, g = m._log_joint(sites, u, 1e-6, True)
+    for i in range(4):
+        h = 1e-6
+        up, um = u.copy(), u.copy()
+        up[i] += h
+        um[i] -= h
+        fd = (m._log_joint(sites, up, 1e-6, True, False)[0] - m._log_joint(sites, um, 1e-6, True, False)[0]) / (2 * h)
+        assert abs(fd - g[i]) <= 1e-5 * max(1.0, abs(fd))
+
+
+def test_sample_from_prior_shape():
+    m = ExactGP(1, "RBF")
+    out = m.sample_from_prior(get_keys()[0], np.linspace(0, 1, 9), num_samples=4)
+    assert out.shape == (4, 9)
+
+
+@pytest.mark.parametrize("guide", ["delta", "normal"])
+def test_vigp_fit_predict(guide):
+    X, y, Xn, p = ref.synthetic_problem(40, 1, 10, seed=8)
+    m = viGP(1, "Matern", guide=guide)
+    m.fit(get_keys()[0], X, y, num_steps=60, step_size=0.05, progress_bar=False, print_summary=(guide == "delta"))
+    assert m.svi is not None
+    s = m.get_samples()
+    assert set(s) == {"k_length", "k_scale", "noise"} and s["k_length"].shape == (1,)
+    mean, var = m.predict(get_keys()[1], Xn)
+    assert mean.shape == (10,) and var.shape == (10,) and np.all(var > 0)
+    m_ref, v_ref = ref.vigp_predict(X, y, Xn, {k: np.asarray(v) for k, v in s.items()}, kernel="Matern")
+    np.testing.assert_allclose(mean, m_ref, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(var, v_ref, rtol=1e-7, atol=1e-10)
+    mb, vb = m.predict_in_batches(get_keys()[1], Xn, batch_size=3)
+    np.testing.assert_allclose(mb, mean, rtol=1e-10)
+    np.testing.assert_allclose(vb, var, rtol=1e-10)
+    if guide == "delta":  # MAP improves the objective
+        assert np.nanmin(m.loss[-10:]) < m.loss[0]
+    # broadcastable parameter shapes (gpax/tests/test_vigp.py:68-99)
+    params = {"k_length": np.array([[1.0]]), "k_scale": np.array([1.0]), "noise": np.array([0.1])}
+    mean2, var2 = m.predict(get_keys()[1], Xn, samples=params)
+    assert mean2.shape == (10,) and var2.shape == (10,)
+
+
+def test_vigp_same_key_identical_and_guides_differ():
+    X, y, Xn, _ = ref.synthetic_problem(25, 1, 5, seed=9)
+    res = []
+    for guide in ["delta", "delta", "normal"]:
+        m = viGP(1, "RBF", guide=guide)
+        m.fit(get_keys()[0], X, y, num_steps=20, progress_bar=False, print_summary=False)
+        res.append(m.get_samples()["k_length"])
+    np.testing.assert_array_equal(res[0], res[1])
+    assert not np.array_equal(res[0], res[2])
+
+
+def test_kernel_callables_follow_the_protocol():
+    from gpax_amd.kernels import MaternKernel, RBFKernel, get_kernel
+    rng = np.random.default_rng(0)
+    x1, x2 = rng.standard_normal((5, 2)), rng.standard_normal((5, 2))
+    for k in [RBFKernel, MaternKernel]:
+        for ell in [1.0, np.array([1.0, 2.0]), np.array([1.0]), np.array([[1.0]])]:
+            K = k(x1, x2, {"k_length": ell, "k_scale": 1.0})
+            assert isinstance(K, np.ndarray) and K.shape == (5, 5)
+    assert get_kernel("RBF") is RBFKernel and get_kernel(MaternKernel) is MaternKernel
+    with pytest.raises(KeyError):
+        get_kernel("Nope")
+    K = RBFKernel(x1, x1, {"k_length": 1.0, "k_scale": 1.0}, noise=0.3, jitter=1e-6)
+    Kr = ref.RBFKernel(x1, x1, {"k_length": 1.0, "k_scale": 1.0}, noise=0.3, jitter=1e-6)
+    np.testing.assert_allclose(K, Kr, rtol=1e-12)
+
+
+def test_utils_match_reference_behaviour():
+    g = np.load("tests/golden/utils.npz")
+    for tag in ["img34", "img16"]:
+        a, b, c = preprocess_sparse_image(g[tag])
+        np.testing.assert_array_equal(a, g[tag + "_X"])
+        np.testing.assert_array_equal(b, g[tag + "_y"])
+        np.testing.assert_array_equal(c, g[tag + "_full"])
+    assert [len(q) for q in split_in_batches(np.arange(10), 4)] == [4, 4, 2]
+    assert [q.shape for q in split_in_batches(np.zeros((2, 7)), 3, dim=1)] == [(2, 3), (2, 3), (2, 1)]
+    assert len(split_in_batches(np.arange(3), 4)) == 1
+    with pytest.raises(NotImplementedError):
+        split_in_batches(np.arange(3), 2, dim=2)
+    d = {"a": np.arange(10), "b": np.arange(20).reshape(10, 2)}
+    assert [len(q["a"]) for q in split_dict(d, 4)] == [4, 4, 2]
+    sub = random_sample_dict(d, 3, get_keys()[0])
+    assert sub["a"].shape == (3,) and np.array_equal(sub["b"][:, 0] // 2, sub["a"])
+    X = np.arange(40.0).reshape(20, 2)
+    assert initialize_inducing_points(X, 0.25, "uniform").shape == (5, 2)
+    assert initialize_inducing_points(X, 0.25, "random", key=get_keys()[0]).shape == (5, 2)
+    with pytest.raises(ValueError):
+        initialize_inducing_points(X, 1.5)
+    with pytest.raises(ValueError):
+        initialize_inducing_points(X, 0.5, "random")
+    with pytest.raises(ValueError):
+        initialize_inducing_points(X, 0.5, "bogus")
+    k1, k2 = get_keys(1)
+    assert not np.array_equal(k1, k2) and np.array_equal(get_keys(1)[0], k1)
+    assert gpax_amd.utils.enable_x64() is None

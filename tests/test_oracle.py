@@ -1,0 +1,160 @@
+"""CPU: pin the oracle.  The reference holds no numeric vectors on this path and cannot be imported
+here (no jax), so the restatement is checked against INDEPENDENT computations of the same
+quantities and against the committed golden fixtures."""
+import os
+import subprocess
+import sys
+
+import mpmath
+import numpy as np
+import pytest
+import scipy.stats
+
+from oracle import cpu_ref as ref
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def mp_kernel(name, x, z, ell, scale):
+    mpmath.mp.dps = 50
+    r2 = sum(((mpmath.mpf(float(a)) - mpmath.mpf(float(b))) / mpmath.mpf(float(l))) ** 2 for a, b, l in zip(x, z, ell))
+    if name == "RBF":
+        return mpmath.mpf(scale) * mpmath.exp(-r2 / 2)
+    r = mpmath.sqrt(r2 + mpmath.mpf("1e-12"))
+    s5 = mpmath.sqrt(5) * r
+    return mpmath.mpf(scale) * (1 + s5 + mpmath.mpf(5) / 3 * r2) * mpmath.exp(-s5)
+
+
+@pytest.mark.parametrize("name", ["RBF", "Matern"])
+def test_gram_vs_mpmath_direct_formula(name):
+    rng = np.random.default_rng(0)
+    X, Z = rng.uniform(0, 10, (12, 3)), rng.uniform(0, 10, (9, 3))
+    ell = np.array([0.8, 1.5, 2.2])
+    K = ref.get_kernel(name)(X, Z, {"k_length": ell, "k_scale": 1.7})
+    for i in range(12):
+        for j in range(9):
+            exact = float(mp_kernel(name, X[i], Z[j], ell, 1.7))
+            assert abs(K[i, j] - exact) <= 1e-12 * max(abs(exact), 1e-3)
+
+
+def test_diagonal_rule_is_shape_equality_not_identity():
+    # kernels.py:63: the (noise + jitter) diagonal is added iff X.shape == Z.shape
+    rng = np.random.default_rng(1)
+    X, Z = rng.uniform(0, 1, (6, 2)), rng.uniform(0, 1, (6, 2))
+    p = {"k_length": 1.0, "k_scale": 1.0}
+    K0 = ref.RBFKernel(X, Z, p, noise=0.0, jitter=0.0)
+    K1 = ref.RBFKernel(X, Z, p, noise=0.5, jitter=1e-6)
+    np.testing.assert_allclose(K1 - K0, (0.5 + 1e-6) * np.eye(6), atol=1e-15)
+    K2 = ref.RBFKernel(X, Z[:5], p, noise=0.5)
+    np.testing.assert_allclose(K2, K0[:, :5], atol=0)
+
+
+def test_matern_diagonal_uses_sqrt_eps():
+    X = np.zeros((3, 2))
+    K = ref.MaternKernel(X, X, {"k_length": 1.0, "k_scale": 2.0}, noise=0.0, jitter=0.0)
+    r = np.sqrt(1e-12)
+    assert np.allclose(K, 2.0 * (1 + np.sqrt(5) * r) * np.exp(-np.sqrt(5) * r), rtol=1e-15)
+    assert K[0, 0] < 2.0
+
+
+@pytest.mark.parametrize("name", ["RBF", "Matern"])
+def test_lml_vs_scipy_multivariate_normal(name):
+    X, y, _, p = ref.synthetic_problem(120, 2, 4, seed=3)
+    K = ref.get_kernel(name)(X, X, p, p["noise"], jitter=1e-6)
+    expect = scipy.stats.multivariate_normal(mean=np.zeros(120), cov=K, allow_singular=False).logpdf(y)
+    got = ref.exactgp_log_likelihood(X, y, p, kernel=name)
+    assert abs(got - expect) <= 1e-10 * abs(expect)
+
+
+@pytest.mark.parametrize("name", ["RBF", "Matern"])
+def test_gradient_vs_central_differences(name):
+    X, y, _, p = ref.synthetic_problem(80, 2, 4, seed=5)
+    g_ell, g_s, g_n, alpha = ref.exactgp_log_likelihood_grad(X, y, p, kernel=name)
+    base = np.concatenate([p["k_length"], [p["k_scale"], p["noise"]]])
+
+    def f(t):
+        return ref.exactgp_log_likelihood(X, y, {"k_length": t[:2], "k_scale": t[2], "noise": t[3]}, kernel=name)
+
+    fd = np.empty(4)
+    for i in range(4):
+        h = 1e-6 * base[i]
+        a, b = base.copy(), base.copy()
+        a[i] += h
+        b[i] -= h
+        fd[i] = (f(a) - f(b)) / (2 * h)
+    np.testing.assert_allclose(np.concatenate([g_ell, [g_s, g_n]]), fd, rtol=2e-7)
+    K = ref.get_kernel(name)(X, X, p, p["noise"], jitter=1e-6)
+    np.testing.assert_allclose(K @ alpha, y, rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["RBF", "Matern"])
+@pytest.mark.parametrize("noiseless", [False, True])
+def test_posterior_inverse_route_equals_cholesky_route(name, noiseless):
+    X, y, Xn, p = ref.synthetic_problem(256, 2, 100, seed=7)
+    m1, c1 = ref.get_mvn_posterior(X, y, Xn, p, noiseless, kernel=name, route="inv")
+    m2, c2 = ref.get_mvn_posterior(X, y, Xn, p, noiseless, kernel=name, route="chol")
+    assert np.linalg.norm(m1 - m2) <= 1e-11 * np.linalg.norm(m1)
+    assert np.linalg.norm(c1 - c2) <= 1e-11 * np.linalg.norm(c1)
+
+
+def test_posterior_with_mean_function():
+    X, y, Xn, p = ref.synthetic_problem(60, 1, 25, seed=2)
+    p = dict(p, a=0.7)
+    mean_fn = lambda x, prm: prm["a"] * x[:, 0]
+    m, c = ref.get_mvn_posterior(X, y + 0.7 * X[:, 0], Xn, p, mean_fn=mean_fn, mean_fn_has_params=True)
+    m0, c0 = ref.get_mvn_posterior(X, y, Xn, p)
+    np.testing.assert_allclose(m, m0 + 0.7 * Xn[:, 0], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(c, c0, rtol=0, atol=0)
+
+
+def test_lowrank_mvn_vs_dense():
+    rng = np.random.default_rng(0)
+    W, D, y = rng.standard_normal((50, 7)), rng.uniform(0.1, 1, 50), rng.standard_normal(50)
+    dense = scipy.stats.multivariate_normal(mean=np.zeros(50), cov=W @ W.T + np.diag(D)).logpdf(y)
+    assert abs(ref.lowrank_mvn_log_prob(y, np.zeros(50), W, D) - dense) <= 1e-10 * abs(dense)
+
+
+def test_sparse_posterior_tends_to_exact_when_inducing_equals_train():
+    X, y, Xn, p = ref.synthetic_problem(40, 1, 15, seed=1)
+    m_s, c_s = ref.sparse_posterior(X, y, X.copy(), Xn, p, kernel="RBF", jitter=1e-8)
+    m_e, c_e = ref.get_mvn_posterior(X, y, Xn, p, kernel="RBF", jitter=1e-6)
+    np.testing.assert_allclose(m_s, m_e, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(c_s, c_e, rtol=1e-3, atol=1e-4)
+
+
+def test_golden_fixtures_match_oracle():
+    g = load("gram")
+    for c in range(int(g["ncases"])):
+        kind, scale, noise, jitter = g[f"c{c}_meta"]
+        name = "RBF" if kind == 0 else "Matern"
+        ell = g[f"c{c}_ell"]
+        K = ref.get_kernel(name)(g[f"c{c}_X"], g[f"c{c}_Z"], {"k_length": ell, "k_scale": scale}, noise=noise,
+                                 jitter=jitter)
+        np.testing.assert_array_equal(K, g[f"c{c}_K"])
+    p = load("posterior")
+    for c in range(0, int(p["ncases"]), 5):
+        kind, noiseless, jitter = p[f"c{c}_meta"]
+        th = p[f"c{c}_theta"]
+        prm = {"k_length": th[:-2], "k_scale": th[-2], "noise": th[-1]}
+        m, cv = ref.get_mvn_posterior(p[f"c{c}_X"], p[f"c{c}_y"], p[f"c{c}_Xn"], prm, bool(noiseless),
+                                      kernel="RBF" if kind == 0 else "Matern", jitter=jitter)
+        np.testing.assert_allclose(m, p[f"c{c}_mean"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(cv, p[f"c{c}_cov"], rtol=1e-10, atol=1e-12)
+
+
+def test_utils_restatement():
+    u = load("utils")
+    a, b, c = ref.preprocess_sparse_image(u["img34"])
+    np.testing.assert_array_equal(a, [[0, 1], [1, 0], [2, 3]])
+    np.testing.assert_array_equal(b, [1.5, 0.25, -2.0])
+    assert c.shape == (12, 2) and tuple(c[1]) == (0, 1) and tuple(c[4]) == (1, 0)  # row-major order
+    parts = ref.split_in_batches(np.arange(10), 4)
+    assert [len(q) for q in parts] == [4, 4, 2]
+    with pytest.raises(UnboundLocalError):
+        ref.split_in_batches(np.arange(3), 4)  # the reference's bug (utils.py:48), restated
+    chunks = ref.split_dict({"a": np.arange(10), "b": np.arange(20).reshape(10, 2)}, 4)
+    assert [len(q["a"]) for q in chunks] == [4, 4, 2] and chunks[1]["b"].shape == (4, 2)
