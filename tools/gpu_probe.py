@@ -17,6 +17,16 @@ def main():
     out = {"device": eng.device_info()}
     out["mfma_f64_peak_tflops"] = eng.mfma_f64_peak()
     print(out, flush=True)
+    # pure GEMM main-loop efficiency (device time via the profile events)
+    rng = np.random.default_rng(0)
+    for (Mg, Ng, Kg) in [(4096, 4096, 512), (4096, 4096, 4096), (8192, 8192, 512)]:
+        A = rng.standard_normal((Mg, Kg)); B = rng.standard_normal((Ng, Kg))
+        eng.gemm_nt(A, B)
+        eng.profile_enable(True); eng.profile_reset()
+        eng.gemm_nt(A, B)
+        n, ms, work = eng.profile_read(1)
+        eng.profile_enable(False)
+        print(f"gemm {Mg}x{Ng}x{Kg}: {ms:.3f} ms  {2.0*Mg*Ng*Kg/(ms*1e-3)/1e12:.1f} TF", flush=True)
     for N in sizes:
         d, M = 2, 1024
         kind = 0 if N <= 4096 else 1
