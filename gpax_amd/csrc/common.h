@@ -192,7 +192,6 @@ struct GemmArgs {
   int kupper;  // k range ends at (tj_off + bx + 1) * 128 (B lower triangular, e.g. chol factor)
   int kchunk;  // split-K chunk (multiple of 16), 0 = no split
   int64_t c_split_stride;
-  int tiles_m, tiles_n, tri_patches; // filled by launch_gemm_nt (XCD-aware patch mapping)
 };
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
                    int prof_cls, double work);

@@ -32,33 +32,7 @@ constexpr size_t GEMM_LDS_BYTES = size_t(4) * TILE_DOUBLES * sizeof(double); // 
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  // XCD-aware tile mapping (speed only, never correctness): workgroup b is observed to run on
-  // XCD b % 8, each XCD has a private 4 MiB L2, and 64 workgroups of this kernel are resident
-  // per XCD (32 CUs x 2).  So the 64 consecutive workgroups an XCD receives are mapped onto one
-  // 8x8 patch of output tiles: every A and B row-panel slice is then shared by 8 co-resident
-  // workgroups through that XCD's L2 instead of being re-fetched from Infinity Cache / HBM.
-  int bx, by;
-  {
-    const int b = blockIdx.x;
-    const int xcd = b & 7, q = b >> 3;
-    const int inner = q & 63;
-    const int sp = (q >> 6) * 8 + xcd; // patch index
-    int spi, spj;
-    if (g.tri_patches) { // patches of the lower triangle, row-major: sp = spi (spi + 1) / 2 + spj
-      spi = (int)((sqrt(8.0 * sp + 1.0) - 1.0) * 0.5);
-      while ((spi + 1) * (spi + 2) / 2 <= sp) ++spi;
-      while (spi * (spi + 1) / 2 > sp) --spi;
-      spj = sp - spi * (spi + 1) / 2;
-    } else {
-      const int pn = (g.tiles_n + 7) >> 3;
-      spi = sp / pn;
-      spj = sp - spi * pn;
-    }
-    by = spi * 8 + (inner >> 3);
-    bx = spj * 8 + (inner & 7);
-    if (by >= g.tiles_m || bx >= g.tiles_n) return;
-  }
-  const int bz = blockIdx.z;
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   const int ti = g.ti_off + by, tj = g.tj_off + bx;
   if (g.lower && tj > ti) return;
 
@@ -191,15 +165,9 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
                                      (int)GEMM_LDS_BYTES));
     attr_set = true;
   }
-  GemmArgs a = g;
-  a.tiles_m = tiles_m;
-  a.tiles_n = tiles_n;
-  const int pm = (tiles_m + 7) / 8, pn = (tiles_n + 7) / 8;
-  a.tri_patches = (g.lower && tiles_m == tiles_n && g.ti_off == g.tj_off) ? 1 : 0;
-  const int npatch = a.tri_patches ? pm * (pm + 1) / 2 : pm * pn;
-  dim3 grid(((npatch + 7) / 8) * 8 * 64, 1, splits > 0 ? splits : 1);
+  dim3 grid(tiles_n, tiles_m, splits > 0 ? splits : 1);
   ProfScope ps(ctx, prof_cls, work);
-  gemm_nt_kernel<<<grid, 256, GEMM_LDS_BYTES, ctx->stream>>>(a);
+  gemm_nt_kernel<<<grid, 256, GEMM_LDS_BYTES, ctx->stream>>>(g);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
