@@ -38,16 +38,26 @@ double kdiag_value(const KernelParams& kp) {
 }
 
 // Gram (lower tiles) + augmentation + blocked Cholesky + lml reductions; all async.
-int dev_factor(gpx_ctx* ctx) {
+// fused: the k_pX rows of the resident X_new ride below the square matrix (rows Np ..), so the
+// factorisation also leaves Vt = k_pX L^-T there (see potrf_lower).
+int dev_factor(gpx_ctx* ctx, bool fused) {
   const int N = ctx->N, Np = ctx->Np;
+  const int extra = fused ? ctx->Mp / TILE : 0;
+  if (fused) GPX_TRY(ensure(ctx, ctx->K, (size_t)(Np + ctx->Mp) * ctx->ldk * sizeof(double)));
   double* K = ctx->K.d();
   GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->X.d(), N, N, ctx->X.d(), N, Np,
                              ctx->noise + ctx->jitter, 1, 1, K, ctx->ldk));
   GPX_TRY(launch_augment(ctx, K, ctx->ldk, N, Np, ctx->yres.d()));
+  if (fused) {
+    // k_pX = kernel(X_new, X_train, params, jitter=0.0): no diagonal term (gp.py:268)
+    GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->Xnew.d(), ctx->M, ctx->Mp, ctx->X.d(), N, Np, 0.0,
+                               0, 0, K + (int64_t)Np * ctx->ldk, ctx->ldk));
+  }
   GPX_HIP(ctx, hipMemsetAsync(sc_int(ctx) + SI_TRAIN, 0, sizeof(int), ctx->stream));
-  GPX_TRY(potrf_lower(ctx, K, ctx->ldk, Np, ctx->Linv.d(), sc_int(ctx) + SI_TRAIN));
+  GPX_TRY(potrf_lower(ctx, K, ctx->ldk, Np, extra, ctx->Linv.d(), sc_int(ctx) + SI_TRAIN));
   GPX_TRY(launch_lml_terms(ctx, K, ctx->ldk, N, ctx->scal.d() + SC_QUAD));
   ctx->factored = true;
+  ctx->fused_vt = fused;
   ctx->have_post = false;
   return 0;
 }
@@ -100,7 +110,6 @@ int set_xnew(gpx_ctx* ctx, const double* Xnew, int M) {
   ctx->ldv = pick_ld(ctx->Np);
   ctx->ldc = pick_ld(ctx->Mp);
   GPX_TRY(ensure(ctx, ctx->Xnew, (size_t)M * ctx->d * sizeof(double)));
-  GPX_TRY(ensure(ctx, ctx->Vt, (size_t)ctx->Mp * ctx->ldv * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->mean, (size_t)ctx->Mp * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->var, (size_t)ctx->Mp * sizeof(double)));
   GPX_HIP(ctx, hipMemcpyAsync(ctx->Xnew.d(), Xnew, (size_t)M * ctx->d * sizeof(double),
@@ -114,15 +123,22 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov) {
   const int nt = (N + TILE - 1) / TILE;
   const int mt = Mp / TILE;
   const double* K = ctx->K.d();
-  double* Vt = ctx->Vt.d();
   KernelParams kp = ctx->theta;
-  // k_pX = kernel(X_new, X_train, params, jitter=0.0): no diagonal term (gp.py:268)
-  GPX_TRY(launch_gram_padded(ctx, kp, ctx->Xnew.d(), M, Mp, ctx->X.d(), N, nt * TILE, 0.0, 0, 0, Vt,
-                             ctx->ldv));
-  GPX_TRY(trsm_right_lt(ctx, Vt, ctx->ldv, mt, K, ctx->ldk, ctx->Linv.d(), nt, 0));
+  double* Vt;
+  int64_t ldv;
+  if (ctx->fused_vt) { // already solved during the factorisation
+    Vt = ctx->K.d() + (int64_t)ctx->Np * ctx->ldk;
+    ldv = ctx->ldk;
+  } else {
+    GPX_TRY(ensure(ctx, ctx->Vt, (size_t)ctx->Mp * ctx->ldv * sizeof(double)));
+    Vt = ctx->Vt.d();
+    ldv = ctx->ldv;
+    // k_pX = kernel(X_new, X_train, params, jitter=0.0): no diagonal term (gp.py:268)
+    GPX_TRY(launch_gram_padded(ctx, kp, ctx->Xnew.d(), M, Mp, ctx->X.d(), N, nt * TILE, 0.0, 0, 0, Vt, ldv));
+    GPX_TRY(trsm_right_lt(ctx, Vt, ldv, mt, K, ctx->ldk, ctx->Linv.d(), nt, 0));
+  }
   const double kd = kdiag_value(kp) + ctx->noise_p + ctx->jitter;
-  GPX_TRY(launch_rowdot(ctx, Vt, ctx->ldv, M, N, K + (int64_t)N * ctx->ldk, kd, ctx->mean.d(),
-                        ctx->var.d(), 0));
+  GPX_TRY(launch_rowdot(ctx, Vt, ldv, M, N, K + (int64_t)N * ctx->ldk, kd, ctx->mean.d(), ctx->var.d(), 0));
   ctx->cov_factored = false;
   if (want_cov) {
     GPX_TRY(ensure(ctx, ctx->Cov, (size_t)Mp * ctx->ldc * sizeof(double)));
@@ -139,9 +155,9 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov) {
     GPX_TRY(ensure(ctx, ctx->SplitK, (size_t)splits * stride * sizeof(double)));
     GemmArgs g{};
     g.A = Vt;
-    g.lda = ctx->ldv;
+    g.lda = ldv;
     g.B = Vt;
-    g.ldb = ctx->ldv;
+    g.ldb = ldv;
     g.C = ctx->SplitK.d();
     g.ldc = ldp;
     g.K = ktot;
@@ -165,7 +181,7 @@ int dev_draw(gpx_ctx* ctx, int n_pad, int n) {
   if (!ctx->cov_factored) {
     GPX_TRY(ensure(ctx, ctx->CovLinv, (size_t)mt * TILE * TILE * sizeof(double)));
     GPX_HIP(ctx, hipMemsetAsync(sc_int(ctx) + SI_COV, 0, sizeof(int), ctx->stream));
-    GPX_TRY(potrf_lower(ctx, ctx->Cov.d(), ctx->ldc, Mp, ctx->CovLinv.d(), sc_int(ctx) + SI_COV));
+    GPX_TRY(potrf_lower(ctx, ctx->Cov.d(), ctx->ldc, Mp, 0, ctx->CovLinv.d(), sc_int(ctx) + SI_COV));
     ctx->cov_factored = true;
   }
   GemmArgs g{};
@@ -239,7 +255,13 @@ int gpx_init(int device, gpx_ctx** out) {
     ctx->err = std::string("libgpx is built for gfx950 only; device is ") + ctx->prop.gcnArchName;
     return -3;
   }
-  GPX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0; // numerically lower = higher priority
+    GPX_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, lo));
+    GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->pstream, hipStreamNonBlocking, hi));
+    ctx->s = ctx->stream;
+  }
   GPX_HIP(ctx, hipEventCreate(&ctx->ev0));
   GPX_HIP(ctx, hipEventCreate(&ctx->ev1));
   GPX_TRY(ensure(ctx, ctx->scal, 8192));
@@ -260,6 +282,9 @@ void gpx_destroy(gpx_ctx* ctx) {
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->evP) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->evU) (void)hipEventDestroy(e);
+    if (ctx->pstream) (void)hipStreamDestroy(ctx->pstream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   }
   delete ctx;
@@ -348,7 +373,7 @@ int gpx_factor(gpx_ctx* ctx, int kind, const double* ell, double scale, double n
   ctx->jitter = jitter;
   GPX_HIP(ctx, hipMemcpyAsync(ctx->yres.d(), yres, (size_t)ctx->N * sizeof(double),
                               hipMemcpyHostToDevice, ctx->stream));
-  GPX_TRY(dev_factor(ctx));
+  GPX_TRY(dev_factor(ctx, false));
   double h[2];
   int hinfo = 0;
   GPX_HIP(ctx, hipMemcpyAsync(h, ctx->scal.d() + SC_QUAD, 2 * sizeof(double), hipMemcpyDeviceToHost,
@@ -396,6 +421,7 @@ int gpx_posterior(gpx_ctx* ctx, const double* Xnew, int M, double noise_p, doubl
   ctx->noise_p = noise_p;
   const double saved_jitter = ctx->jitter;
   ctx->jitter = jitter;
+  ctx->fused_vt = false; // this X_new was not part of the factorisation: solve here
   int rc = dev_posterior(ctx, cov != nullptr);
   ctx->jitter = saved_jitter;
   GPX_TRY(rc);
@@ -505,7 +531,7 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
     if (strided)
       SWEEP_HIP(hipMemcpyAsync(ctx->yres.d(), dYres.d() + (int64_t)s * N, (size_t)N * sizeof(double),
                                hipMemcpyDeviceToDevice, ctx->stream));
-    SWEEP_TRY(dev_factor(ctx));
+    SWEEP_TRY(dev_factor(ctx, true));
     SWEEP_TRY(dev_posterior(ctx, n > 0));
     SWEEP_HIP(hipMemcpyAsync(dMeans.d() + (int64_t)s * M, ctx->mean.d(), (size_t)M * sizeof(double),
                              hipMemcpyDeviceToDevice, ctx->stream));
@@ -605,18 +631,18 @@ int gpx_time_stage(gpx_ctx* ctx, int stage, int reps, double* elapsed_ms) {
         ctx->factored = false;
         break;
       case GPX_STAGE_POTRF:
-        GPX_TRY(dev_factor(ctx));
+        GPX_TRY(dev_factor(ctx, false));
         break;
       case GPX_STAGE_FITSTEP:
-        GPX_TRY(dev_factor(ctx));
+        GPX_TRY(dev_factor(ctx, false));
         GPX_TRY(dev_grad(ctx));
         break;
       case GPX_STAGE_POSTERIOR:
-        GPX_TRY(dev_factor(ctx));
+        GPX_TRY(dev_factor(ctx, true));
         GPX_TRY(dev_posterior(ctx, true));
         break;
       case GPX_STAGE_PREDICT:
-        GPX_TRY(dev_factor(ctx));
+        GPX_TRY(dev_factor(ctx, true));
         GPX_TRY(dev_posterior(ctx, true));
         GPX_TRY(dev_draw(ctx, n_pad, 1));
         break;
@@ -651,7 +677,7 @@ int gpx_sweep_resident(gpx_ctx* ctx, int kind, int S, const double* ells, const 
     GPX_TRY(set_theta(ctx, kind, ctx->d, ells + (int64_t)s * ctx->d, scales[s]));
     ctx->noise = noises[s];
     ctx->noise_p = noiseless ? 0.0 : noises[s];
-    GPX_TRY(dev_factor(ctx));
+    GPX_TRY(dev_factor(ctx, true));
     GPX_TRY(dev_posterior(ctx, n_draws > 0));
     if (n_draws > 0) GPX_TRY(dev_draw(ctx, n_pad, n_draws));
   }
@@ -720,7 +746,7 @@ int gpx_potrf(gpx_ctx* ctx, int n, const double* A, double* L, int* info) {
                                 (size_t)n * sizeof(double), n, hipMemcpyHostToDevice, ctx->stream));
   GPX_TRY(launch_pad_identity(ctx, ctx->tA.d(), ld, n, np));
   GPX_HIP(ctx, hipMemsetAsync(sc_int(ctx) + SI_TRAIN, 0, sizeof(int), ctx->stream));
-  GPX_TRY(potrf_lower(ctx, ctx->tA.d(), ld, np, ctx->tB.d(), sc_int(ctx) + SI_TRAIN));
+  GPX_TRY(potrf_lower(ctx, ctx->tA.d(), ld, np, 0, ctx->tB.d(), sc_int(ctx) + SI_TRAIN));
   int hinfo = 0;
   GPX_HIP(ctx, hipMemcpy2DAsync(L, (size_t)n * sizeof(double), ctx->tA.d(), ld * sizeof(double),
                                 (size_t)n * sizeof(double), n, hipMemcpyDeviceToHost, ctx->stream));

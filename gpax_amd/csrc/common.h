@@ -73,7 +73,10 @@ struct ProfAcc {
 
 struct gpx_ctx {
   int device = -1;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;  // main stream (API copies, trailing updates)
+  hipStream_t pstream = nullptr; // high-priority panel stream (lookahead)
+  hipStream_t s = nullptr;       // stream the launch helpers currently target
+  std::vector<hipEvent_t> evP, evU; // per-outer-block panel / next-panel-update events
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   hipDeviceProp_t prop;
@@ -93,6 +96,7 @@ struct gpx_ctx {
   gpx::KernelParams theta{};
   double noise = 0, jitter = 0;
   bool factored = false;
+  bool fused_vt = false; // rows Np.. of K hold k_pX L^-T from a fused factorisation
 
   // ---- posterior state ------------------------------------------------------------------
   int M = 0, Mp = 0;
@@ -148,6 +152,7 @@ struct ProfScope {
   gpx_ctx* ctx;
   int cls;
   hipEvent_t a = nullptr, b = nullptr;
+  hipStream_t st = nullptr;
   ProfScope(gpx_ctx* c, int cls_, double work) : ctx(c), cls(cls_) {
     if (!ctx->prof_on) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
@@ -156,11 +161,12 @@ struct ProfScope {
     }
     ctx->prof[cls].launches += 1;
     ctx->prof[cls].work += work;
-    (void)hipEventRecord(a, ctx->stream);
+    st = ctx->s;
+    (void)hipEventRecord(a, st);
   }
   ~ProfScope() {
     if (!a) return;
-    (void)hipEventRecord(b, ctx->stream);
+    (void)hipEventRecord(b, st);
     ctx->prof[cls].pending.emplace_back(a, b);
   }
 };
@@ -202,7 +208,8 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
                      int info_base);
 
 // linalg.hip
-int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, double* dLinv, int* dInfo);
+int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,
+                int* dInfo);
 int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_p, const double* dL,
                   int64_t ldl, const double* dLinv, int nblk, int upper_rows);
 int launch_set_identity(gpx_ctx* ctx, double* dA, int64_t ld, int np);

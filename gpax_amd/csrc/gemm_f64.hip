@@ -167,7 +167,7 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   }
   dim3 grid(tiles_n, tiles_m, splits > 0 ? splits : 1);
   ProfScope ps(ctx, prof_cls, work);
-  gemm_nt_kernel<<<grid, 256, GEMM_LDS_BYTES, ctx->stream>>>(g);
+  gemm_nt_kernel<<<grid, 256, GEMM_LDS_BYTES, ctx->s>>>(g);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -209,9 +209,9 @@ int mfma_peak(gpx_ctx* ctx, double* tflops) {
   for (int bpc = 1; bpc <= 4; bpc *= 2) {
     const int blocks = ctx->prop.multiProcessorCount * bpc;
     double* probe = ctx->scal.d() + 64;
-    mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(probe, iters); // warm-up / clock ramp
+    mfma_peak_kernel<<<blocks, 256, 0, ctx->s>>>(probe, iters); // warm-up / clock ramp
     GPX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    mfma_peak_kernel<<<blocks, 256, 0, ctx->stream>>>(probe, iters);
+    mfma_peak_kernel<<<blocks, 256, 0, ctx->s>>>(probe, iters);
     GPX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     GPX_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0.f;

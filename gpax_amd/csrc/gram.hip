@@ -134,10 +134,10 @@ int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, i
   // full 8 n m.
   ProfScope ps(ctx, GPX_PROF_GRAM, 8.0 * (double)n * (double)m);
   if (kp.kind == GPX_KERNEL_RBF)
-    gram_dispatch<GPX_KERNEL_RBF>(kp, grid, ctx->stream, dX, n, n_pad, dZ, m, m_pad, diag_add,
+    gram_dispatch<GPX_KERNEL_RBF>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
                                   add_diag, lower_only, dOut, ld);
   else
-    gram_dispatch<GPX_KERNEL_MATERN52>(kp, grid, ctx->stream, dX, n, n_pad, dZ, m, m_pad, diag_add,
+    gram_dispatch<GPX_KERNEL_MATERN52>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
                                        add_diag, lower_only, dOut, ld);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void augment_kernel(double* __restrict__ K, in
 
 int launch_augment(gpx_ctx* ctx, double* dK, int64_t ld, int N, int Np, const double* dy) {
   dim3 grid(min(64, (Np + 255) / 256), Np - N);
-  augment_kernel<<<grid, 256, 0, ctx->stream>>>(dK, ld, N, Np, dy);
+  augment_kernel<<<grid, 256, 0, ctx->s>>>(dK, ld, N, Np, dy);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void pad_identity_kernel(double* __restrict__ 
 int launch_pad_identity(gpx_ctx* ctx, double* dA, int64_t ld, int n, int np) {
   if (np == n) return 0;
   dim3 grid(min(64, (np + 255) / 256), np);
-  pad_identity_kernel<<<grid, 256, 0, ctx->stream>>>(dA, ld, n, np);
+  pad_identity_kernel<<<grid, 256, 0, ctx->s>>>(dA, ld, n, np);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -29,47 +29,111 @@ static inline GemmArgs gemm_args(const double* A, int64_t lda, const double* B, 
 // traffic / flop is 1/4 of a K = 128 update); inside an outer block the panel is advanced 128
 // columns at a time: potf2+inverse (1 workgroup) -> panel TRSM as GEMM with the inverse ->
 // update of the remaining columns of the outer block only.
-int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, double* dLinv, int* dInfo) {
-  const int nblk = np / TILE;
-  for (int ob = 0; ob < nblk; ob += OUTER_TILES) {
-    const int oe = (ob + OUTER_TILES < nblk) ? ob + OUTER_TILES : nblk;
-    for (int kb = ob; kb < oe; ++kb) {
-      double* Akk = dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE;
-      double* Li = dLinv + (int64_t)kb * TILE * TILE;
-      GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE));
-      const int below = nblk - kb - 1;
-      if (below <= 0) continue;
-      double* Apan = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)kb * TILE;
-      { // panel TRSM, in place: A[kb+1.., kb] <- A[kb+1.., kb] * Linv^T
-        GemmArgs g = gemm_args(Apan, lda, Li, TILE, Apan, lda, TILE, 1.0, 0.0);
-        GPX_TRY(launch_gemm_nt(ctx, g, below, 1, 0, GPX_PROF_GEMM_OTHER,
-                               2.0 * below * TILE * (double)TILE * TILE));
-      }
-      const int inner_cols = oe - kb - 1;
-      if (inner_cols > 0) { // update the rest of the outer block's columns (lower tiles)
-        double* Cin = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)(kb + 1) * TILE;
-        GemmArgs g = gemm_args(Apan, lda, Apan, lda, Cin, lda, TILE, -1.0, 1.0);
-        g.lower = 1;
-        g.ti_off = kb + 1;
-        g.tj_off = kb + 1;
-        GPX_TRY(launch_gemm_nt(ctx, g, below, inner_cols, 0, GPX_PROF_GEMM_OTHER,
-                               2.0 * below * inner_cols * (double)TILE * TILE * TILE));
-      }
+//
+// extra_tiles > 0: the matrix has extra_tiles*128 more ROWS below the square part (the k_pX
+// rows of the posterior).  They take part in every panel TRSM and trailing update, which is
+// exactly the right-looking solve of  X L^T = k_pX : after the sweep those rows hold
+// k_pX L^-T, at the trailing GEMM's efficiency and with no separate serial chain.
+//
+// Look-ahead on two streams.  For outer block k (columns [ob, oe)):
+//   P(k)  panel stream: potf2 / TRSM / inner updates of the block's own columns;
+//   U1(k) main stream : trailing update restricted to the NEXT outer block's columns;
+//   U2(k) main stream : trailing update of everything to the right of that.
+// P(k+1) only needs U1(k), so it runs concurrently with U2(k) — the latency-bound panel work
+// hides behind the big SYRK.  Order on the main stream U1(0) U2(0) U1(1) U2(1) ... keeps the
+// accumulation order of every C tile fixed, so results are run-to-run deterministic.
+static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob, int oe,
+                       double* dLinv, int* dInfo) {
+  for (int kb = ob; kb < oe; ++kb) {
+    double* Akk = dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE;
+    double* Li = dLinv + (int64_t)kb * TILE * TILE;
+    GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE));
+    const int below = nblk - kb - 1 + extra;
+    if (below <= 0) continue;
+    double* Apan = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)kb * TILE;
+    { // panel TRSM, in place: A[kb+1.., kb] <- A[kb+1.., kb] * Linv^T
+      GemmArgs g = gemm_args(Apan, lda, Li, TILE, Apan, lda, TILE, 1.0, 0.0);
+      GPX_TRY(launch_gemm_nt(ctx, g, below, 1, 0, GPX_PROF_GEMM_OTHER,
+                             2.0 * below * TILE * (double)TILE * TILE));
     }
-    const int rest = nblk - oe;
-    if (rest > 0) { // trailing update with K = (oe - ob) * 128, lower tiles only
-      const int K = (oe - ob) * TILE;
-      const double* Pan = dA + (int64_t)oe * TILE * lda + (int64_t)ob * TILE;
-      double* Ctr = dA + (int64_t)oe * TILE * lda + (int64_t)oe * TILE;
-      GemmArgs g = gemm_args(Pan, lda, Pan, lda, Ctr, lda, K, -1.0, 1.0);
+    const int inner_cols = oe - kb - 1;
+    if (inner_cols > 0) { // update the rest of the outer block's columns (lower tiles)
+      double* Cin = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)(kb + 1) * TILE;
+      GemmArgs g = gemm_args(Apan, lda, Apan, lda, Cin, lda, TILE, -1.0, 1.0);
       g.lower = 1;
-      g.ti_off = oe;
-      g.tj_off = oe;
-      const double n = (double)rest * TILE;
-      GPX_TRY(launch_gemm_nt(ctx, g, rest, rest, 0, GPX_PROF_GEMM_TRAILING, n * (n + 1.0) * K));
+      g.ti_off = kb + 1;
+      g.tj_off = kb + 1;
+      GPX_TRY(launch_gemm_nt(ctx, g, below, inner_cols, 0, GPX_PROF_GEMM_OTHER,
+                             2.0 * below * inner_cols * (double)TILE * TILE * TILE));
     }
   }
   return 0;
+}
+
+// C[rows r0.., cols c0..c1) -= Pan[rows, ob..oe) * Pan[cols, ob..oe)^T, lower tiles only.
+static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob,
+                           int oe, int r0, int c0, int c1) {
+  const int rows = nblk + extra - r0, cols = c1 - c0;
+  if (rows <= 0 || cols <= 0) return 0;
+  const int K = (oe - ob) * TILE;
+  const double* PanR = dA + (int64_t)r0 * TILE * lda + (int64_t)ob * TILE;
+  const double* PanC = dA + (int64_t)c0 * TILE * lda + (int64_t)ob * TILE;
+  double* Ctr = dA + (int64_t)r0 * TILE * lda + (int64_t)c0 * TILE;
+  GemmArgs g = gemm_args(PanR, lda, PanC, lda, Ctr, lda, K, -1.0, 1.0);
+  g.lower = 1;
+  g.ti_off = r0;
+  g.tj_off = c0;
+  // algorithmic flops: 2K per updated entry with column <= row
+  double entries = 0.0;
+  for (int t = 0; t < cols; ++t) {
+    const int first_row_tile = (c0 + t > r0) ? c0 + t : r0; // rows below the diagonal tile
+    const double full = (double)(nblk + extra - first_row_tile - (c0 + t >= r0 ? 1 : 0)) * TILE * TILE;
+    const double diag = (c0 + t >= r0) ? 0.5 * TILE * (TILE + 1.0) : 0.0;
+    entries += full + diag;
+  }
+  return launch_gemm_nt(ctx, g, rows, cols, 0, GPX_PROF_GEMM_TRAILING, 2.0 * K * entries);
+}
+
+int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,
+                int* dInfo) {
+  const int nblk = np / TILE;
+  const int nouter = (nblk + OUTER_TILES - 1) / OUTER_TILES;
+  while ((int)ctx->evP.size() < nouter + 1) {
+    hipEvent_t e1, e2;
+    GPX_HIP(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    GPX_HIP(ctx, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+    ctx->evP.push_back(e1);
+    ctx->evU.push_back(e2);
+  }
+  hipStream_t smain = ctx->stream, span = ctx->pstream;
+  // the panel stream starts after everything already queued on the main stream (Gram etc.)
+  GPX_HIP(ctx, hipEventRecord(ctx->evU[nouter], smain));
+  GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[nouter], 0));
+  int rc = 0;
+  for (int k = 0; k < nouter && rc >= 0; ++k) {
+    const int ob = k * OUTER_TILES;
+    const int oe = (ob + OUTER_TILES < nblk) ? ob + OUTER_TILES : nblk;
+    const int oe2 = (oe + OUTER_TILES < nblk) ? oe + OUTER_TILES : nblk;
+    // P(k) on the panel stream, after U1(k-1)
+    ctx->s = span;
+    if (k > 0) GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
+    rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo);
+    if (rc < 0) break;
+    GPX_HIP(ctx, hipEventRecord(ctx->evP[k], span));
+    // U1(k), U2(k) on the main stream, after P(k)
+    ctx->s = smain;
+    GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
+    if (oe < nblk) {
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, oe2);
+      if (rc < 0) break;
+      GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain));
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe2, oe2, nblk);
+    } else {
+      GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain));
+    }
+  }
+  ctx->s = smain;
+  return rc;
 }
 
 // ---- right-looking solve of  X * L^T = B  in place (B: rows_t*128 x nblk*128) --------------
@@ -125,7 +189,7 @@ __global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ 
 
 int launch_set_identity(gpx_ctx* ctx, double* dA, int64_t ld, int np) {
   dim3 grid(min(32, (np / 2 + 255) / 256), np);
-  set_identity_kernel<<<grid, 256, 0, ctx->stream>>>(dA, ld, np);
+  set_identity_kernel<<<grid, 256, 0, ctx->s>>>(dA, ld, np);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -172,7 +236,7 @@ __global__ __launch_bounds__(1024) void lml_terms_kernel(const double* __restric
 }
 
 int launch_lml_terms(gpx_ctx* ctx, const double* dL, int64_t ld, int N, double* dOut2) {
-  lml_terms_kernel<<<1, 1024, 0, ctx->stream>>>(dL, ld, N, dOut2);
+  lml_terms_kernel<<<1, 1024, 0, ctx->s>>>(dL, ld, N, dOut2);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -208,7 +272,7 @@ int launch_rowdot(gpx_ctx* ctx, const double* dV, int64_t ldv, int rows, int col
                   const double* dw, double kdiag, double* dmean, double* dvar,
                   int col_start_by_row) {
   if (rows <= 0) return 0;
-  rowdot_kernel<<<(rows + 3) / 4, 256, 0, ctx->stream>>>(dV, ldv, rows, cols, dw, kdiag, dmean,
+  rowdot_kernel<<<(rows + 3) / 4, 256, 0, ctx->s>>>(dV, ldv, rows, cols, dw, kdiag, dmean,
                                                          dvar, col_start_by_row);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
@@ -261,7 +325,7 @@ int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXne
                         const double* dPart, int splits, int64_t split_stride, int64_t ldp,
                         double diag_add, double* dCov, int64_t ldc) {
   dim3 grid((Mp + 63) / 64, (Mp + 15) / 16);
-  cov_finalize_kernel<<<grid, 256, 0, ctx->stream>>>(kp, dXnew, M, Mp, dPart, splits, split_stride,
+  cov_finalize_kernel<<<grid, 256, 0, ctx->s>>>(kp, dXnew, M, Mp, dPart, splits, split_stride,
                                                      ldp, diag_add, dCov, ldc);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
@@ -349,13 +413,13 @@ int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX,
   const int nt = (N + GC_TILE - 1) / GC_TILE;
   const int nblocks = nt * (nt + 1) / 2;
   *nblocks_out = nblocks;
-  grad_contract_kernel<<<nblocks, 256, 0, ctx->stream>>>(kp, dX, N, dKinv, ld, dalpha, dpart);
+  grad_contract_kernel<<<nblocks, 256, 0, ctx->s>>>(kp, dX, N, dKinv, ld, dalpha, dpart);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
 
 int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals, double* dout) {
-  grad_reduce_kernel<<<1, 256, 0, ctx->stream>>>(dpart, nblocks, nvals, dout);
+  grad_reduce_kernel<<<1, 256, 0, ctx->s>>>(dpart, nblocks, nvals, dout);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -371,7 +435,7 @@ __global__ __launch_bounds__(256) void add_mean_kernel(double* __restrict__ D, i
 int launch_add_mean(gpx_ctx* ctx, double* ddraws, int64_t ld, int n, int M, const double* dmean) {
   if (n <= 0) return 0;
   dim3 grid((M + 255) / 256, n);
-  add_mean_kernel<<<grid, 256, 0, ctx->stream>>>(ddraws, ld, n, M, dmean);
+  add_mean_kernel<<<grid, 256, 0, ctx->s>>>(ddraws, ld, n, M, dmean);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }

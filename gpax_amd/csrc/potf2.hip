@@ -21,7 +21,7 @@ namespace gpx {
 
 constexpr int PB = 128;
 constexpr int PT_LD = PB + 1;
-constexpr size_t POTF2_LDS_BYTES = (size_t)(PB * PT_LD + 2 * PB + PB) * sizeof(double);
+constexpr size_t POTF2_LDS_BYTES = (size_t)(64 * PT_LD + 2 * PB + PB) * sizeof(double);
 
 template <int JB>
 __device__ __forceinline__ void potf2_block(double (&S)[8][8], double* colbuf, double* dsv,
@@ -78,8 +78,8 @@ __device__ __forceinline__ void potf2_block(double (&S)[8][8], double* colbuf, d
 __global__ __launch_bounds__(256, 1) void potf2_inv_kernel(double* A, int64_t lda, double* Linv,
                                                            int* info, int info_base) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* T = lds;                   // PB x PT_LD transpose staging
-  double* colbuf = lds + PB * PT_LD; // 2 x PB
+  double* T = lds;                   // 64 x PT_LD transpose staging (one half at a time)
+  double* colbuf = lds + 64 * PT_LD; // 2 x PB
   double* dsv = colbuf + 2 * PB;     // PB pivots (d_j before sqrt)
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
@@ -105,34 +105,41 @@ __global__ __launch_bounds__(256, 1) void potf2_inv_kernel(double* A, int64_t ld
   potf2_block<7>(S, colbuf, dsv, tx, ty, bad);
   __syncthreads();
 
-  // deferred column scaling; write L (lower, zeros above) and stage L^-1 through LDS
+  // deferred column scaling; write L (lower, zeros above) and stage L^-1 through LDS in two
+  // 64-row halves (66 KB: leaves room for a GEMM workgroup on the same CU during look-ahead)
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    const int i = tx + 16 * b;
-    const double piv = sqrt(dsv[i]);
-    const double ip = 1.0 / piv;
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      const int r = ty + 16 * a;
-      double lval, xval;
-      if (r > i) {
-        lval = S[a][b] * ip;
-        xval = 0.0;
-      } else if (r == i) {
-        lval = piv;
-        xval = ip;
-      } else {
-        lval = 0.0;
-        xval = S[a][b] * ip; // = Linv[i][r]
+    for (int bb = 0; bb < 4; ++bb) {
+      const int b = half * 4 + bb;
+      const int i = tx + 16 * b;
+      const double piv = sqrt(dsv[i]);
+      const double ip = 1.0 / piv;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int r = ty + 16 * a;
+        double lval, xval;
+        if (r > i) {
+          lval = S[a][b] * ip;
+          xval = 0.0;
+        } else if (r == i) {
+          lval = piv;
+          xval = ip;
+        } else {
+          lval = 0.0;
+          xval = S[a][b] * ip; // = Linv[i][r]
+        }
+        A[(int64_t)r * lda + i] = lval;
+        T[(i - 64 * half) * PT_LD + r] = xval;
       }
-      A[(int64_t)r * lda + i] = lval;
-      T[i * PT_LD + r] = xval;
     }
-  }
-  __syncthreads();
-  {
-    const int col = tid & 127;
-    for (int row = tid >> 7; row < PB; row += 2) Linv[row * PB + col] = T[row * PT_LD + col];
+    __syncthreads();
+    {
+      const int col = tid & 127;
+      for (int row = tid >> 7; row < 64; row += 2)
+        Linv[(row + 64 * half) * PB + col] = T[row * PT_LD + col];
+    }
+    __syncthreads();
   }
   if (tid == 0 && bad != 0 && info != nullptr) {
     if (*info == 0) *info = info_base + bad;
@@ -150,7 +157,7 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
   }
   // algorithmic flops: factor n^3/3 + triangular inverse n^3/3
   ProfScope ps(ctx, GPX_PROF_POTF2, 2.0 * PB * (double)PB * PB / 3.0);
-  potf2_inv_kernel<<<1, 256, POTF2_LDS_BYTES, ctx->stream>>>(dA, lda, dLinv, dInfo, info_base);
+  potf2_inv_kernel<<<1, 256, POTF2_LDS_BYTES, ctx->s>>>(dA, lda, dLinv, dInfo, info_base);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
