@@ -1,0 +1,74 @@
+"""CPU, world_size = 2 and 3 (gloo): the sample-sharded sweep gathers exactly the single-process
+result.  The engine here is the checker-backed stand-in (no GPU in this container); on the GPU box
+the same code path runs with the real engine under the nccl (RCCL) backend."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from gpax_amd.parallel import shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for S in [0, 1, 7, 8, 1000]:
+        for world in [1, 2, 3, 8]:
+            blocks = [shard_range(S, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == S
+            assert all(b[1] == c[0] for b, c in zip(blocks[:-1], blocks[1:]))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem():
+    from oracle import cpu_ref as ref
+
+    N, d, M, S, n = 60, 2, 17, 5, 2
+    X, y, Xn, _ = ref.synthetic_problem(N, d, M, seed=3)
+    samples = ref.synthetic_theta_samples(S, d, seed=1)
+    eps = np.random.default_rng(2).standard_normal((S, n, M))
+    return X, y, Xn, samples, eps
+
+
+def _worker(rank, world, port, outdir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpax_amd.parallel import Communicator, predict_sharded
+    from tests.oracle_engine import OracleEngine
+
+    comm = Communicator()
+    args = _problem() if rank == 0 else (None, None, None, None, None)
+    res = predict_sharded(OracleEngine(), 1, *args, False, 1e-6, comm)
+    if rank == 0:
+        means, draws, infos = res
+        np.savez(os.path.join(outdir, "out.npz"), means=means, draws=draws, infos=infos)
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sweep_equals_single_process(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    from oracle import cpu_ref as ref
+
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "out.npz")
+    X, y, Xn, samples, eps = _problem()
+    _, yy, means = ref.predict(X, y, Xn, samples, eps, False, kernel="Matern", route="chol")
+    np.testing.assert_allclose(got["means"], means, rtol=1e-10)
+    np.testing.assert_allclose(got["draws"], yy, rtol=1e-9, atol=1e-12)
+    assert got["infos"].shape == (5,) and np.all(got["infos"] == 0)

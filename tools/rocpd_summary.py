@@ -25,22 +25,21 @@ def main():
         for name, cn, n, s, a in pmc:
             short = name if len(name) < 70 else name[:67] + "..."
             lines.append(f"| `{short}` | {cn} | {n} | {s:.6g} | {a:.6g} |")
-    # the Cholesky trailing SYRK launches of gemm_nt_kernel: square grids of (Np/128 - 4k) tiles
+    # the dominant kernel has its own symbol: gpx::gemm_nt_kernel<1> (Cholesky trailing SYRK)
     try:
-        rows = cur.execute("select grid_size_x/256, grid_size_y, grid_size_z, counter_name, value, duration "
-                           "from counters_collection where kernel_name like 'gpx::gemm_nt_kernel%'").fetchall()
+        rows = cur.execute("select counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection "
+                           "where kernel_name like '%gemm_nt_kernel<1>%' group by counter_name").fetchall()
     except Exception:
         rows = []
-    if rows:
-        gmax = max(r[0] for r in rows if r[0] == r[1] and r[2] == 1)
-        trail = [r for r in rows if r[0] == r[1] and r[2] == 1 and (gmax - r[0]) % 4 == 0]
-        if trail:
-            cname = trail[0][3]
-            n = len(trail)
-            tot = sum(r[4] for r in trail)
-            lines += ["", f"Cholesky trailing-update launches (square grids {gmax}, {gmax - 4}, ... tiles): "
-                          f"{n} dispatches, {cname} sum = {tot:.6g} KB, avg per launch = {tot / n:.6g} KB, "
-                          f"avg duration under PMC = {sum(r[5] for r in trail) / n / 1e3:.1f} us"]
+    for cname, n, tot, avg, dur in rows:
+        lines += ["", f"DOMINANT gemm_nt_kernel<1>: {n} dispatches, {cname} sum = {tot:.6g}, avg per launch = {avg:.6g}, "
+                      f"avg duration under PMC = {dur / 1e3:.1f} us"]
+        if len(sys.argv) > 3:
+            import json
+            import os
+            d = json.load(open(sys.argv[3])) if os.path.exists(sys.argv[3]) else {}
+            d[cname] = {"dispatches": n, "avg_per_launch": avg, "sum": tot}
+            json.dump(d, open(sys.argv[3], "w"), indent=1)
     text = "\n".join(lines) + "\n"
     if len(sys.argv) > 2:
         open(sys.argv[2], "a").write(text)
