@@ -11,10 +11,11 @@
 // owns a 64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 accumulator VGPRs).
 // A and B tiles are both "row x k" with k contiguous (that is what NT means in row-major), so
 // both fragments are read from LDS with the same pattern: lane l reads row (l & 15), k (l >> 4).
-// LDS rows are padded to 18 doubles: 18 r mod 32 is a permutation of the even residues, so the
-// 32 lanes of each ds_read_b64 half hit 32 distinct banks.  Global -> register -> LDS staging,
+// LDS rows are padded to 17 doubles (odd): the compiler fuses fragment reads into ds_read2_b64,
+// whose 16-lane groups then hit 16 distinct bank pairs (an even pad measured 2-way conflicts:
+// 42 -> 66 TF in tools/exp/gemm_variants.hip); the price is 8-byte instead of 16-byte LDS stores.  Global -> register -> LDS staging,
 // double-buffered in LDS with the next tile's global loads in flight during the MFMAs: one
-// barrier per k-step.  73.7 KB LDS + <256 VGPRs => 2 workgroups (8 waves) per CU.
+// barrier per k-step.  69.6 KB LDS + <256 VGPRs => 2 workgroups (8 waves) per CU.
 //
 // f64 MFMA fragment layout (differs from the f32 forms!):
 //   A: lane l holds A[i = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][j = l & 15];
@@ -26,7 +27,7 @@ namespace gpx {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDT = BK + 2; // padded LDS row (doubles)
+constexpr int LDT = BK + 1; // padded LDS row (doubles): odd => ds_read2_b64 fragment reads are conflict-free
 constexpr int TILE_DOUBLES = BM * LDT;
 constexpr size_t GEMM_LDS_BYTES = size_t(4) * TILE_DOUBLES * sizeof(double); // 2 bufs x (A,B)
 
@@ -87,15 +88,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   rb1 = *reinterpret_cast<const double2*>(Bp + b_step + (koff));           \
   rb2 = *reinterpret_cast<const double2*>(Bp + 2 * b_step + (koff));       \
   rb3 = *reinterpret_cast<const double2*>(Bp + 3 * b_step + (koff));
-#define GPX_STORE_TILE(dA, dB)                                             \
-  *reinterpret_cast<double2*>((dA) + st_off) = ra0;                        \
-  *reinterpret_cast<double2*>((dA) + st_off + 32 * LDT) = ra1;             \
-  *reinterpret_cast<double2*>((dA) + st_off + 64 * LDT) = ra2;             \
-  *reinterpret_cast<double2*>((dA) + st_off + 96 * LDT) = ra3;             \
-  *reinterpret_cast<double2*>((dB) + st_off) = rb0;                        \
-  *reinterpret_cast<double2*>((dB) + st_off + 32 * LDT) = rb1;             \
-  *reinterpret_cast<double2*>((dB) + st_off + 64 * LDT) = rb2;             \
-  *reinterpret_cast<double2*>((dB) + st_off + 96 * LDT) = rb3;
+#define GPX_ST2(p, v)  \
+  (p)[0] = (v).x;      \
+  (p)[1] = (v).y;
+#define GPX_STORE_TILE(dA, dB)                 \
+  GPX_ST2((dA) + st_off, ra0)                  \
+  GPX_ST2((dA) + st_off + 32 * LDT, ra1)       \
+  GPX_ST2((dA) + st_off + 64 * LDT, ra2)       \
+  GPX_ST2((dA) + st_off + 96 * LDT, ra3)       \
+  GPX_ST2((dB) + st_off, rb0)                  \
+  GPX_ST2((dB) + st_off + 32 * LDT, rb1)       \
+  GPX_ST2((dB) + st_off + 64 * LDT, rb2)       \
+  GPX_ST2((dB) + st_off + 96 * LDT, rb3)
     GPX_LOAD_TILE(0)
     GPX_STORE_TILE(sA0, sB0)
     __syncthreads();
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
 #undef GPX_LOAD_TILE
 #undef GPX_STORE_TILE
+#undef GPX_ST2
   }
 
   // epilogue: D[row = (lane >> 4) + 4 r][col = lane & 15] per 16x16 accumulator.  A wave
