@@ -61,6 +61,10 @@ def load_library() -> C.CDLL:
         "gpx_mvn_draw": (C.c_int, [vp, _dp, C.c_int, _dp, _ip]),
         "gpx_predict_sweep": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _dp,
                                         C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip]),
+        "gpx_sgp_bound": (C.c_int, [vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp, C.c_int, _dp, C.c_int,
+                                    _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+        "gpx_sgp_posterior": (C.c_int, [vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp, C.c_int, _dp, _dp,
+                                        C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
         "gpx_profile_enable": (C.c_int, [vp, C.c_int]),
         "gpx_profile_reset": (C.c_int, [vp]),
         "gpx_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64), _dp, _dp]),
@@ -80,7 +84,8 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = (
     "gpx_init gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train "
-    "gpx_factor gpx_lml_grad gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_profile_enable "
+    "gpx_factor gpx_lml_grad gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
+    "gpx_profile_enable "
     "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_sweep_resident gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf"
 ).split()
@@ -237,6 +242,45 @@ class Engine:
             int(bool(noiseless)), float(jitter), _ptr(eps_c), n, _ptr(means),
             _ptr(samples) if n else None, infos.ctypes.data_as(_ip)), "gpx_predict_sweep")
         return means, samples, infos
+
+    # -- sparse GP ------------------------------------------------------------------------------
+    def sgp_bound(self, kind: int, ell, scale: float, noise: float, jitter: float, Xu, yres, want_grad: bool = True):
+        """VFE bound of viSparseGP.model and (optionally) its gradient w.r.t. (ell, scale, noise, Xu)
+        plus d bound / d yres.  Returns (bound, info, grads-or-None)."""
+        ell = broadcast_lengthscale(ell, self.d)
+        Xu = _f64(Xu)
+        Mi = Xu.shape[0]
+        yres = _f64(yres, (self.N,))
+        bound, info = C.c_double(), C.c_int()
+        if want_grad:
+            g_ell, g_Xu, dy = np.empty(self.d), np.empty((Mi, self.d)), np.empty(self.N)
+            g_scale, g_noise = C.c_double(), C.c_double()
+            self._check(self._lib.gpx_sgp_bound(self._ctx, kind, _ptr(ell), float(scale), float(noise), float(jitter),
+                                                _ptr(Xu), Mi, _ptr(yres), 1, C.byref(bound), _ptr(g_ell),
+                                                C.byref(g_scale), C.byref(g_noise), _ptr(g_Xu), _ptr(dy),
+                                                C.byref(info)), "gpx_sgp_bound")
+            return bound.value, info.value, dict(k_length=g_ell, k_scale=g_scale.value, noise=g_noise.value, Xu=g_Xu,
+                                                 yres=dy)
+        self._check(self._lib.gpx_sgp_bound(self._ctx, kind, _ptr(ell), float(scale), float(noise), float(jitter),
+                                            _ptr(Xu), Mi, _ptr(yres), 0, C.byref(bound), None, None, None, None, None,
+                                            C.byref(info)), "gpx_sgp_bound")
+        return bound.value, info.value, None
+
+    def sgp_posterior(self, kind: int, ell, scale: float, noise: float, jitter: float, Xu, yres, Xnew, noise_p: float,
+                      want_cov: bool = True, want_var: bool = False):
+        ell = broadcast_lengthscale(ell, self.d)
+        Xu = _f64(Xu)
+        yres = _f64(yres, (self.N,))
+        Xnew = _f64(Xnew)
+        Ms = Xnew.shape[0]
+        mean = np.empty(Ms)
+        cov = np.empty((Ms, Ms)) if want_cov else None
+        var = np.empty(Ms) if want_var else None
+        info = C.c_int()
+        self._check(self._lib.gpx_sgp_posterior(self._ctx, kind, _ptr(ell), float(scale), float(noise), float(jitter),
+                                                _ptr(Xu), Xu.shape[0], _ptr(yres), _ptr(Xnew), Ms, float(noise_p),
+                                                _ptr(mean), _ptr(cov), _ptr(var), C.byref(info)), "gpx_sgp_posterior")
+        return mean, cov, var, info.value
 
     # -- measurement ----------------------------------------------------------------------------
     def profile_enable(self, on: bool):

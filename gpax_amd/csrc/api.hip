@@ -280,6 +280,7 @@ void gpx_destroy(gpx_ctx* ctx) {
                       &ctx->SplitK, &ctx->mean, &ctx->var,  &ctx->eps,    &ctx->draws, &ctx->tA,
                       &ctx->tB,   &ctx->tC};
     for (DevBuf* b : bufs) b->release();
+    sgp_release(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->evP) (void)hipEventDestroy(e);

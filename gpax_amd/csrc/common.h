@@ -114,6 +114,8 @@ struct gpx_ctx {
   bool have_post = false;
   bool cov_factored = false;
 
+  void* sgp = nullptr; // sparse-GP state (sparse.hip)
+
   // ---- generic scratch for unit-test entry points ---------------------------------------
   gpx::DevBuf tA, tB, tC;
 
@@ -224,6 +226,7 @@ int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX,
                          const double* dKinv, int64_t ld, const double* dalpha, double* dpart,
                          int* nblocks_out);
 int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals, double* dout);
+void sgp_release(gpx_ctx* ctx);
 int launch_add_mean(gpx_ctx* ctx, double* ddraws, int64_t ld, int n, int M, const double* dmean);
 
 } // namespace gpx

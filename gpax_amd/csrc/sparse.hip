@@ -1,0 +1,655 @@
+// sparse.hip — variational sparse GP (VFE / Titsias) on the same HIP primitives.
+//
+// Replaces gpax/models/sparse_gp.py:62-114 (viSparseGP.model: LowRankMultivariateNormal
+// log-density + trace-term factor, with learnable inducing points Xu) and
+// sparse_gp.py:173-223 (get_mvn_posterior), plus the reverse-mode gradient JAX provides for the
+// SVI loop (sparse_gp.py:151-166).
+//
+// Forward (Cholesky route, as the reference):
+//   Kuu = k(Xu,Xu) + jitter I = Luu Luu^T          W = Kfu Luu^-T   (N x M, right-looking TRSM)
+//   A = I + W^T W / s2 = LA LA^T  (M x M)           c = LA^-1 W^T y / s2
+//   F = -N/2 log 2pi - N/2 log s2 - sum log diag LA - y^T y / (2 s2) + c^T c / 2
+//       - max(0, N kd - |W|_F^2) / (2 s2)
+//   (matrix-determinant lemma / Woodbury form of LowRankMVN(W, s2 I).log_prob(y) - trace/2).
+// Posterior: V1 = Ksu Luu^-T, V2 = V1 LA^-T, mean = V2 c, cov = Kss - V1 V1^T + V2 V2^T.
+// Gradient: matrix adjoints G_uu = dF/dKuu, G_uf = dF/dKuf from the explicit inverses
+//   Ki = Kuu^-1 = Tu Tu^T (Tu = Luu^-T),  S1 = (Kuu + Kuf Kfu / s2)^-1 = Tu A^-1 Tu^T,
+//   m = S1 Kuf y:   G_uu = -S1/2 - m m^T/(2 s2^2) + Ki - Tu A Tu^T / 2,
+//                   G_uf^T = Kfu (Ki - S1)/s2 - (Kfu m) m^T / s2^3 + y m^T / s2^2,
+// contracted with dK/dtheta and dK/dXu evaluated on the fly (nothing N x M x d is stored).
+#include "common.h"
+
+namespace gpx {
+
+int launch_gram_padded(gpx_ctx*, const KernelParams&, const double*, int, int, const double*, int, int, double, int,
+                       int, double*, int64_t);
+
+// ---- small kernels ---------------------------------------------------------------------------
+
+// out (cols x rows, ldo) = in^T (rows x cols, ldi); 32x32 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, int64_t ldi, int rows,
+                                                        int cols, double* __restrict__ out, int64_t ldo) {
+  __shared__ double t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = by + r, j = bx + tx;
+    t[r][tx] = (i < rows && j < cols) ? in[(int64_t)i * ldi + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int j = bx + r, i = by + tx;
+    if (j < cols && i < rows) out[(int64_t)j * ldo + i] = t[tx][r];
+  }
+}
+
+static int launch_transpose(gpx_ctx* ctx, const double* in, int64_t ldi, int rows, int cols, double* out,
+                            int64_t ldo) {
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+  transpose_kernel<<<grid, 256, 0, ctx->s>>>(in, ldi, rows, cols, out, ldo);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// Full symmetric n x n:  out = diag_val * I + scale * sum_z P_z[max(i,j)][min(i,j)]   (i, j < n_valid),
+// identity elsewhere in the n_pad extent.
+__global__ __launch_bounds__(256) void sym_finalize_kernel(const double* __restrict__ P, int splits,
+                                                           int64_t split_stride, int64_t ldp, double scale,
+                                                           double diag_val, int n_valid, int n_pad,
+                                                           double* __restrict__ out, int64_t ldo) {
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+  if (j >= n_pad) return;
+  for (int t = 0; t < 4; ++t) {
+    const int i = i0 + t;
+    if (i >= n_pad) return;
+    double v;
+    if (i < n_valid && j < n_valid) {
+      const int hi = i > j ? i : j, lo = i > j ? j : i;
+      double acc = 0.0;
+      for (int z = 0; z < splits; ++z) acc += P[(int64_t)z * split_stride + (int64_t)hi * ldp + lo];
+      v = scale * acc + (i == j ? diag_val : 0.0);
+    } else {
+      v = (i == j) ? 1.0 : 0.0;
+    }
+    out[(int64_t)i * ldo + j] = v;
+  }
+}
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ double bsum(double v, double* red) {
+  v = wsum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) s += red[w];
+  return s;
+}
+
+// part[block] = sum of squares of rows [block*R, ...) of a rows x cols matrix (fixed order).
+__global__ __launch_bounds__(256) void sumsq_rows_kernel(const double* __restrict__ Amat, int64_t ld, int rows,
+                                                         int cols, double* __restrict__ part) {
+  __shared__ double red[16];
+  double s = 0.0;
+  const int r0 = blockIdx.x * 8;
+  for (int r = r0; r < r0 + 8 && r < rows; ++r) {
+    const double* a = Amat + (int64_t)r * ld;
+    for (int k = threadIdx.x; k < cols; k += 256) s = fma(a[k], a[k], s);
+  }
+  const double t = bsum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// Single-block scalar reductions used by the bound:
+//  out[0] = sum part[0..np)   (|W|_F^2)      out[1] = sum_{i<M} log LA[i][i]
+//  out[2] = sum_{i<M} c_i^2                   out[3] = sum_n y_n^2
+//  out[4] = sum_n y_n t_n (t may be null)     out[5] = sum_n t_n^2
+__global__ __launch_bounds__(1024) void sgp_scalars_kernel(const double* __restrict__ part, int np,
+                                                           const double* __restrict__ LA, int64_t lda, int M,
+                                                           const double* __restrict__ c,
+                                                           const double* __restrict__ y, int N,
+                                                           const double* __restrict__ t,
+                                                           double* __restrict__ out) {
+  __shared__ double red[16];
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+  for (int k = threadIdx.x; k < np; k += 1024) a0 += part[k];
+  for (int k = threadIdx.x; k < M; k += 1024) {
+    a1 += log(LA[(int64_t)k * lda + k]);
+    a2 = fma(c[k], c[k], a2);
+  }
+  for (int k = threadIdx.x; k < N; k += 1024) {
+    a3 = fma(y[k], y[k], a3);
+    if (t) {
+      a4 = fma(y[k], t[k], a4);
+      a5 = fma(t[k], t[k], a5);
+    }
+  }
+  double r;
+  r = bsum(a0, red); if (threadIdx.x == 0) out[0] = r;
+  r = bsum(a1, red); if (threadIdx.x == 0) out[1] = r;
+  r = bsum(a2, red); if (threadIdx.x == 0) out[2] = r;
+  r = bsum(a3, red); if (threadIdx.x == 0) out[3] = r;
+  r = bsum(a4, red); if (threadIdx.x == 0) out[4] = r;
+  r = bsum(a5, red); if (threadIdx.x == 0) out[5] = r;
+}
+
+// v[i] = a * x[i] + b * y[i]   (y may be null)
+__global__ __launch_bounds__(256) void axpby_kernel(double* v, double a, const double* x,
+                                                    double b, const double* y, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] = a * x[i] + (y ? b * y[i] : 0.0);
+}
+
+static int launch_axpby(gpx_ctx* ctx, double* v, double a, const double* x, double b, const double* y, int n) {
+  axpby_kernel<<<(n + 255) / 256, 256, 0, ctx->s>>>(v, a, x, b, y, n);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// C = a * A + b * B (+ diagonal handled by caller), full n x n
+__global__ __launch_bounds__(256) void mat_axpby_kernel(double* __restrict__ C, int64_t ldc, double a,
+                                                        const double* __restrict__ A, int64_t lda, double b,
+                                                        const double* __restrict__ B, int64_t ldb, int n) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j < n) C[(int64_t)i * ldc + j] = a * A[(int64_t)i * lda + j] + b * B[(int64_t)i * ldb + j];
+}
+
+// mirror the lower triangle into the upper (n x n)
+__global__ __launch_bounds__(256) void symmetrize_kernel(double* __restrict__ A, int64_t ld, int n) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j < n && j > i) A[(int64_t)i * ld + j] = A[(int64_t)j * ld + i];
+}
+
+__device__ __forceinline__ void kval_dk(int kind, double r2, double scale, double& kv, double& dk) {
+  if (kind == GPX_KERNEL_RBF) {
+    kv = scale * exp(-0.5 * r2);
+    dk = -0.5 * kv;
+  } else {
+    const double r = sqrt(r2 + MATERN_EPS);
+    const double e = exp(-SQRT5 * r);
+    kv = scale * (1.0 + SQRT5 * r + (5.0 / 3.0) * r2) * e;
+    dk = -(5.0 / 6.0) * scale * e * (1.0 + SQRT5 * r2 / r);
+  }
+}
+
+constexpr int SC_NV = 2 * GPX_MAX_DIM + 4;
+
+// Contraction of an adjoint  g[i][j] = G[i][j] + rcoef[i] * mvec[j]  (rows i index points P
+// (rows x d): Xu itself for G_uu, X_train for G_uf^T; columns j index the inducing points) with the
+// kernel derivatives evaluated on the fly.
+// Per block (64 rows x 64 cols) partials: [0..d) d/d ell, [d] d/d scale; the Xu-gradient is
+// accumulated per column in gxu_part[blockRow][col][m] (reduced over block rows afterwards in
+// fixed order => deterministic).
+__global__ __launch_bounds__(256) void sgp_contract_kernel(KernelParams kp, const double* __restrict__ Pts,
+                                                           int rows, const double* __restrict__ Xu, int M,
+                                                           const double* __restrict__ G, int64_t ldg,
+                                                           const double* __restrict__ rcoef,
+                                                           const double* __restrict__ mvec,
+                                                           double* __restrict__ part,
+                                                           double* __restrict__ gxu_part) {
+  __shared__ double red[16];
+  __shared__ double colacc[4][64][GPX_MAX_DIM];
+  const int d = kp.d;
+  const int bj = blockIdx.x, bi = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = bj * 64 + lane; // column = inducing point index
+  double acc[GPX_MAX_DIM + 2];
+  double gx[GPX_MAX_DIM];
+  for (int c = 0; c < d + 2; ++c) acc[c] = 0.0;
+  for (int c = 0; c < d; ++c) gx[c] = 0.0;
+  if (j < M) {
+    double xu[GPX_MAX_DIM];
+    for (int c = 0; c < d; ++c) xu[c] = Xu[(int64_t)j * d + c];
+    const double mj = mvec[j];
+    for (int t = 0; t < 16; ++t) {
+      const int i = bi * 64 + wave * 16 + t;
+      if (i >= rows) break;
+      const double g = fma(rcoef[i], mj, G[(int64_t)i * ldg + j]);
+      double r2 = 0.0, diff[GPX_MAX_DIM];
+      for (int c = 0; c < d; ++c) {
+        diff[c] = (xu[c] - Pts[(int64_t)i * d + c]) * kp.inv_ell[c]; // (xu - p)/ell
+        r2 = fma(diff[c], diff[c], r2);
+      }
+      double kv, dk;
+      kval_dk(kp.kind, r2, kp.scale, kv, dk);
+      for (int c = 0; c < d; ++c) {
+        acc[c] += g * dk * (-2.0 * diff[c] * diff[c] * kp.inv_ell[c]);
+        gx[c] += g * dk * (2.0 * diff[c] * kp.inv_ell[c]); // d k / d xu_c
+      }
+      acc[d] += g * kv / kp.scale;
+    }
+  }
+  for (int c = 0; c < d; ++c) colacc[wave][lane][c] = gx[c];
+  __syncthreads();
+  if (wave == 0 && j < M) {
+    for (int c = 0; c < d; ++c) {
+      const double s = colacc[0][lane][c] + colacc[1][lane][c] + colacc[2][lane][c] + colacc[3][lane][c];
+      gxu_part[((int64_t)bi * M + j) * GPX_MAX_DIM + c] = s;
+    }
+  }
+  const int64_t bid = (int64_t)bi * gridDim.x + bj;
+  for (int c = 0; c < d + 2; ++c) {
+    const double s = bsum(acc[c], red);
+    if (threadIdx.x == 0) part[bid * SC_NV + c] = s;
+  }
+}
+
+// out[c] = sum_b part[b][c]; gxu[j][c] (+)= factor * sum_bi gxu_part[bi][j][c]
+__global__ __launch_bounds__(256) void sgp_reduce_kernel(const double* __restrict__ part, int nblocks, int nv,
+                                                         double* __restrict__ out,
+                                                         const double* __restrict__ gxu_part, int nbi, int M,
+                                                         int d, double factor, int accumulate,
+                                                         double* __restrict__ gxu) {
+  __shared__ double red[16];
+  if (blockIdx.x == 0) {
+    for (int c = 0; c < nv; ++c) {
+      double s = 0.0;
+      for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(int64_t)b * SC_NV + c];
+      const double t = bsum(s, red);
+      if (threadIdx.x == 0) out[c] = t;
+    }
+  }
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < M * d; idx += gridDim.x * 256) {
+    const int j = idx / d, c = idx - j * d;
+    double s = 0.0;
+    for (int b = 0; b < nbi; ++b) s += gxu_part[((int64_t)b * M + j) * GPX_MAX_DIM + c];
+    s *= factor;
+    gxu[idx] = accumulate ? gxu[idx] + s : s;
+  }
+}
+
+// ---- helpers -----------------------------------------------------------------------------------
+
+static inline GemmArgs gargs(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                             int K, double alpha, double beta) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.K = K; g.alpha = alpha; g.beta = beta;
+  return g;
+}
+
+static int ens(gpx_ctx* ctx, DevBuf& b, size_t bytes) {
+  hipError_t e = b.ensure(bytes);
+  if (e != hipSuccess) return fail(ctx, "hipMalloc", e, __FILE__, __LINE__);
+  return 0;
+}
+
+// C (lower, then mirrored to full) = alpha * V V^T over K columns via split-K slabs; diag_val on the diagonal
+static int syrk_full(gpx_ctx* ctx, const double* V, int64_t ldv, int nt, int K, double scale, double diag_val,
+                     int n_valid, double* out, int64_t ldo) {
+  const int np = nt * TILE;
+  const int lower_tiles = nt * (nt + 1) / 2;
+  int splits = (512 + lower_tiles - 1) / lower_tiles;
+  const int max_splits = K / 256 > 0 ? K / 256 : 1;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int kchunk = round_up((K + splits - 1) / splits, TILE);
+  splits = (K + kchunk - 1) / kchunk;
+  const int64_t ldp = pick_ld(np), stride = (int64_t)np * ldp;
+  GPX_TRY(ens(ctx, ctx->SplitK, (size_t)splits * stride * sizeof(double)));
+  GemmArgs g = gargs(V, ldv, V, ldv, ctx->SplitK.d(), ldp, K, 1.0, 0.0);
+  g.lower = 1;
+  g.kchunk = kchunk;
+  g.c_split_stride = stride;
+  GPX_TRY(launch_gemm_nt(ctx, g, nt, nt, splits, GPX_PROF_GEMM_OTHER, (double)np * (np + 1.0) * K));
+  dim3 grid((np + 63) / 64, (np + 15) / 16);
+  sym_finalize_kernel<<<grid, 256, 0, ctx->s>>>(ctx->SplitK.d(), splits, stride, ldp, scale, diag_val, n_valid, np,
+                                                out, ldo);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// T = L^-T (upper, n x n) from the factor L and its diagonal-block inverses
+static int build_linv_t(gpx_ctx* ctx, const double* L, int64_t ldl, const double* Linv, int nt, double* T,
+                        int64_t ldt) {
+  GPX_TRY(launch_set_identity(ctx, T, ldt, nt * TILE));
+  return trsm_right_lt(ctx, T, ldt, nt, L, ldl, Linv, nt, 1);
+}
+
+} // namespace gpx
+
+using namespace gpx;
+
+// H = a * Ainv + b * Acopy + dval * I   (n x n, full)
+__global__ __launch_bounds__(256) void mat_combine_kernel(double* __restrict__ C, int64_t ldc, double a,
+                                                          const double* __restrict__ A, int64_t lda, double b,
+                                                          const double* __restrict__ B, int64_t ldb, double dval,
+                                                          int n) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j < n) {
+    double v = a * A[(int64_t)i * lda + j];
+    if (B) v += b * B[(int64_t)i * ldb + j];
+    if (i == j) v += dval;
+    C[(int64_t)i * ldc + j] = v;
+  }
+}
+
+struct SgpState {
+  int M = 0, Mp = 0, Ntp = 0;
+  int64_t ldu = 0, ldw = 0, ldt = 0;
+  gpx::DevBuf Xu, Kuu, LinvU, Wn, Wt, A, Acopy, LinvA, u, c, cpad, scal, part;
+  gpx::DevBuf B0, B1, B2, B3, B4, vvec, tvec, mvec, rcoef_u, rcoef_f, gxu_part, cpart, gXu, T1a, T1;
+  gpx::DevBuf Xs, V1, V2, mean, var, var2, Cov;
+  gpx::KernelParams kp{};
+  double noise = 0, jitter = 0;
+};
+
+static SgpState* sgp_state(gpx_ctx* ctx) {
+  if (!ctx->sgp) ctx->sgp = new SgpState();
+  return static_cast<SgpState*>(ctx->sgp);
+}
+
+namespace gpx {
+void sgp_release(gpx_ctx* ctx) {
+  if (!ctx->sgp) return;
+  SgpState* s = static_cast<SgpState*>(ctx->sgp);
+  DevBuf* bufs[] = {&s->Xu, &s->Kuu, &s->LinvU, &s->Wn, &s->Wt, &s->A, &s->Acopy, &s->LinvA, &s->u, &s->c, &s->cpad,
+                    &s->scal, &s->part, &s->B0, &s->B1, &s->B2, &s->B3, &s->B4, &s->vvec, &s->tvec, &s->mvec,
+                    &s->rcoef_u, &s->rcoef_f, &s->gxu_part, &s->cpart, &s->gXu, &s->T1a, &s->T1, &s->Xs, &s->V1,
+                    &s->V2, &s->mean, &s->var, &s->var2, &s->Cov};
+  for (DevBuf* b : bufs) b->release();
+  delete s;
+  ctx->sgp = nullptr;
+}
+} // namespace gpx
+
+static double kd_value(const KernelParams& kp) {
+  if (kp.kind == GPX_KERNEL_RBF) return kp.scale;
+  const double r = std::sqrt(MATERN_EPS);
+  return kp.scale * (1.0 + SQRT5 * r) * std::exp(-SQRT5 * r);
+}
+
+static int sgp_setup(gpx_ctx* ctx, SgpState* s, int kind, const double* ell, double scale, double noise,
+                     double jitter, const double* Xu, int Mi, const double* yres) {
+  if (ctx->N < 1) return bad_arg(ctx, "gpx_set_train must be called first");
+  if (kind != GPX_KERNEL_RBF && kind != GPX_KERNEL_MATERN52) return bad_arg(ctx, "kernel kind");
+  if (Mi < 1 || !Xu || !ell || !yres) return bad_arg(ctx, "sparse GP arguments");
+  const int d = ctx->d;
+  s->M = Mi;
+  s->Mp = round_up(Mi, TILE);
+  s->Ntp = round_up(ctx->N, TILE);
+  s->ldu = pick_ld(s->Mp);
+  s->ldw = pick_ld(s->Mp);
+  s->ldt = pick_ld(s->Ntp);
+  s->kp.kind = kind;
+  s->kp.d = d;
+  for (int c = 0; c < GPX_MAX_DIM; ++c) s->kp.inv_ell[c] = c < d ? 1.0 / ell[c] : 0.0;
+  s->kp.scale = scale;
+  s->noise = noise;
+  s->jitter = jitter;
+  GPX_TRY(ens(ctx, s->Xu, (size_t)Mi * d * 8));
+  GPX_HIP(ctx, hipMemcpyAsync(s->Xu.d(), Xu, (size_t)Mi * d * 8, hipMemcpyHostToDevice, ctx->stream));
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->yres.d(), yres, (size_t)ctx->N * 8, hipMemcpyHostToDevice, ctx->stream));
+  ctx->factored = false;
+  ctx->have_post = false;
+  return 0;
+}
+
+// Forward pass shared by the bound and the posterior (yres in ctx->yres on the device).
+static int sgp_forward(gpx_ctx* ctx, SgpState* s) {
+  const int N = ctx->N, M = s->M, Mp = s->Mp, Ntp = s->Ntp;
+  const int mt = Mp / TILE, ntl = Ntp / TILE;
+  const double s2 = s->noise;
+  const size_t mm = (size_t)Mp * s->ldu * 8;
+  GPX_TRY(ens(ctx, s->Kuu, mm));
+  GPX_TRY(ens(ctx, s->LinvU, (size_t)mt * TILE * TILE * 8));
+  GPX_TRY(ens(ctx, s->Wn, (size_t)Ntp * s->ldw * 8));
+  GPX_TRY(ens(ctx, s->Wt, (size_t)Mp * s->ldt * 8));
+  GPX_TRY(ens(ctx, s->A, mm));
+  GPX_TRY(ens(ctx, s->Acopy, mm));
+  GPX_TRY(ens(ctx, s->LinvA, (size_t)mt * TILE * TILE * 8));
+  GPX_TRY(ens(ctx, s->u, (size_t)Mp * 8));
+  GPX_TRY(ens(ctx, s->c, (size_t)Mp * 8));
+  GPX_TRY(ens(ctx, s->cpad, (size_t)TILE * s->ldu * 8));
+  GPX_TRY(ens(ctx, s->scal, 8192));
+  GPX_TRY(ens(ctx, s->part, (size_t)(Ntp / 8 + Mp / 8 + 32) * 8));
+  int* dinfo = s->scal.i() + 1024;
+  GPX_HIP(ctx, hipMemsetAsync(dinfo, 0, 2 * sizeof(int), ctx->stream));
+  // Kuu = kernel(Xu, Xu, params, **jitter): noise defaults to 0 (sparse_gp.py:92)
+  GPX_TRY(launch_gram_padded(ctx, s->kp, s->Xu.d(), M, Mp, s->Xu.d(), M, Mp, s->jitter, 1, 1, s->Kuu.d(), s->ldu));
+  GPX_TRY(launch_pad_identity(ctx, s->Kuu.d(), s->ldu, M, Mp));
+  GPX_TRY(potrf_lower(ctx, s->Kuu.d(), s->ldu, Mp, 0, s->LinvU.d(), dinfo));
+  // Kfu (N x M), then W = Kfu Luu^-T
+  GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->Wn.d(), s->ldw));
+  GPX_TRY(trsm_right_lt(ctx, s->Wn.d(), s->ldw, ntl, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, 0));
+  GPX_TRY(launch_transpose(ctx, s->Wn.d(), s->ldw, Ntp, Mp, s->Wt.d(), s->ldt));
+  // A = I + Wt Wt^T / s2 (kept in Acopy), factor
+  GPX_TRY(syrk_full(ctx, s->Wt.d(), s->ldt, mt, Ntp, 1.0 / s2, 1.0, M, s->A.d(), s->ldu));
+  GPX_HIP(ctx, hipMemcpyAsync(s->Acopy.d(), s->A.d(), mm, hipMemcpyDeviceToDevice, ctx->stream));
+  GPX_TRY(potrf_lower(ctx, s->A.d(), s->ldu, Mp, 0, s->LinvA.d(), dinfo + 1));
+  // u = Wt y ;  c^T = (u^T / s2) LA^-T  (one-tile-row right TRSM)
+  GPX_TRY(launch_rowdot(ctx, s->Wt.d(), s->ldt, M, N, ctx->yres.d(), 0.0, s->u.d(), nullptr, 0));
+  GPX_HIP(ctx, hipMemsetAsync(s->cpad.d(), 0, (size_t)TILE * s->ldu * 8, ctx->stream));
+  GPX_TRY(launch_axpby(ctx, s->cpad.d(), 1.0 / s2, s->u.d(), 0.0, nullptr, M));
+  GPX_TRY(trsm_right_lt(ctx, s->cpad.d(), s->ldu, 1, s->A.d(), s->ldu, s->LinvA.d(), mt, 0));
+  GPX_HIP(ctx, hipMemcpyAsync(s->c.d(), s->cpad.d(), (size_t)Mp * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+
+static int read_info(gpx_ctx* ctx, SgpState* s, int* out) {
+  int hinfo[2];
+  GPX_HIP(ctx, hipMemcpyAsync(hinfo, s->scal.i() + 1024, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hinfo[0] > s->M) hinfo[0] = 0;
+  if (hinfo[1] > s->M) hinfo[1] = 0;
+  *out = hinfo[0] != 0 ? hinfo[0] : (hinfo[1] != 0 ? -hinfo[1] : 0);
+  return 0;
+}
+
+extern "C" {
+
+int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, double noise, double jitter,
+                  const double* Xu, int Mi, const double* yres, int want_grad, double* bound,
+                  double* grad_ell, double* grad_scale, double* grad_noise, double* grad_Xu, double* dyres,
+                  int* info) {
+  if (!ctx || ctx->device < 0) return -1;
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  SgpState* s = sgp_state(ctx);
+  GPX_TRY(sgp_setup(ctx, s, kind, ell, scale, noise, jitter, Xu, Mi, yres));
+  GPX_TRY(sgp_forward(ctx, s));
+  const int N = ctx->N, d = ctx->d, M = s->M, Mp = s->Mp, Ntp = s->Ntp, mt = Mp / TILE;
+  const double s2 = noise, kd = kd_value(s->kp);
+  double* sc = s->scal.d();
+  const int npart = (N + 7) / 8;
+  sumsq_rows_kernel<<<npart, 256, 0, ctx->s>>>(s->Wn.d(), s->ldw, N, M, s->part.d());
+  GPX_HIP(ctx, hipGetLastError());
+  const size_t mm = (size_t)Mp * s->ldu * 8;
+  const double* tvec = nullptr;
+  int npartA = 0;
+  if (want_grad) {
+    GPX_TRY(ens(ctx, s->B0, mm)); GPX_TRY(ens(ctx, s->B1, mm)); GPX_TRY(ens(ctx, s->B2, mm));
+    GPX_TRY(ens(ctx, s->B3, mm)); GPX_TRY(ens(ctx, s->B4, mm));
+    GPX_TRY(ens(ctx, s->vvec, (size_t)Mp * 8)); GPX_TRY(ens(ctx, s->mvec, (size_t)Mp * 8));
+    GPX_TRY(ens(ctx, s->tvec, (size_t)Ntp * 8));
+    double* Tu = s->B0.d();
+    double* TA = s->B1.d();
+    GPX_TRY(build_linv_t(ctx, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, Tu, s->ldu)); // Tu = Luu^-T
+    GPX_TRY(build_linv_t(ctx, s->A.d(), s->ldu, s->LinvA.d(), mt, TA, s->ldu));   // TA = LA^-T
+    // v = TA c ; m = s2 Tu v ; t = s2 W v
+    GPX_TRY(launch_rowdot(ctx, TA, s->ldu, M, M, s->c.d(), 0.0, s->vvec.d(), nullptr, 1));
+    GPX_TRY(launch_rowdot(ctx, Tu, s->ldu, M, M, s->vvec.d(), 0.0, s->mvec.d(), nullptr, 1));
+    GPX_TRY(launch_axpby(ctx, s->mvec.d(), s2, s->mvec.d(), 0.0, nullptr, M));
+    GPX_TRY(launch_rowdot(ctx, s->Wn.d(), s->ldw, N, M, s->vvec.d(), 0.0, s->tvec.d(), nullptr, 0));
+    GPX_TRY(launch_axpby(ctx, s->tvec.d(), s2, s->tvec.d(), 0.0, nullptr, N));
+    tvec = s->tvec.d();
+    // tr(A^-1) = |TA|_F^2
+    npartA = (M + 7) / 8;
+    sumsq_rows_kernel<<<npartA, 256, 0, ctx->s>>>(TA, s->ldu, M, M, s->part.d() + npart);
+    GPX_HIP(ctx, hipGetLastError());
+  }
+  sgp_scalars_kernel<<<1, 1024, 0, ctx->s>>>(s->part.d(), npart, s->A.d(), s->ldu, M, s->c.d(), ctx->yres.d(), N,
+                                             tvec, sc);
+  if (want_grad) // second use of the same reducer for tr(A^-1): only out[0] of this call is meaningful
+    sgp_scalars_kernel<<<1, 1024, 0, ctx->s>>>(s->part.d() + npart, npartA, s->A.d(), s->ldu, 0, s->c.d(),
+                                               ctx->yres.d(), 0, nullptr, sc + 8);
+  GPX_HIP(ctx, hipGetLastError());
+  double h[16];
+  GPX_HIP(ctx, hipMemcpyAsync(h, sc, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  int bad = 0;
+  GPX_TRY(read_info(ctx, s, &bad));
+  const double wF2 = h[0], sumlogLA = h[1], cc = h[2], yy = h[3], yt = h[4], tt = h[5], trAinv = h[8];
+  const double trace_raw = N * kd - wF2;
+  const bool unclipped = trace_raw > 0.0; // jnp.clip(trace_term, a_min=0): zero value AND zero gradient when clipped
+  if (info) *info = bad;
+  if (bound) {
+    *bound = bad ? NAN
+                 : (-0.5 * N * 1.83787706640934548356 - 0.5 * N * std::log(s2) - sumlogLA - 0.5 * yy / s2 +
+                    0.5 * cc - (unclipped ? 0.5 * trace_raw / s2 : 0.0));
+  }
+  if (!want_grad) return 0;
+
+  // ---- matrix adjoints in whitened form ------------------------------------------------------
+  //   G_uu  = Tu H Tu^T - m m^T / (2 s2^2),   H = -Ainv/2 + (1/2 + [u]/2) I - [u] A/2
+  //   G_uf^T = W R Tu^T + rcoef_f m^T,        R = ([u] I - Ainv)/s2,  rcoef_f = y/s2^2 - t/s2^3
+  const double uu = unclipped ? 1.0 : 0.0;
+  double* Tu = s->B0.d();
+  double* TA = s->B1.d();
+  double* Ainv = s->B2.d();
+  {
+    GemmArgs g = gargs(TA, s->ldu, TA, s->ldu, Ainv, s->ldu, Mp, 1.0, 0.0);
+    g.lower = 1;
+    g.ktri = 1;
+    GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, 0, GPX_PROF_GEMM_OTHER, (double)Mp * Mp * Mp / 3.0));
+    dim3 gs((Mp + 255) / 256, Mp);
+    symmetrize_kernel<<<gs, 256, 0, ctx->s>>>(Ainv, s->ldu, Mp);
+    // H -> B3 ; R -> B4
+    mat_combine_kernel<<<gs, 256, 0, ctx->s>>>(s->B3.d(), s->ldu, -0.5, Ainv, s->ldu, -0.5 * uu, s->Acopy.d(),
+                                               s->ldu, 0.5 + 0.5 * uu, Mp);
+    mat_combine_kernel<<<gs, 256, 0, ctx->s>>>(s->B4.d(), s->ldu, -1.0 / s2, Ainv, s->ldu, 0.0, nullptr, 0, uu / s2,
+                                               Mp);
+    GPX_HIP(ctx, hipGetLastError());
+  }
+  { // E1 = Tu H -> B2 (Ainv dead) ; G0 = E1 Tu^T -> B3 (H dead after E1)
+    GemmArgs g = gargs(Tu, s->ldu, s->B3.d(), s->ldu, s->B2.d(), s->ldu, Mp, 1.0, 0.0);
+    GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, 0, GPX_PROF_GEMM_OTHER, 2.0 * Mp * (double)Mp * Mp));
+    GemmArgs h2 = gargs(s->B2.d(), s->ldu, Tu, s->ldu, s->B3.d(), s->ldu, Mp, 1.0, 0.0);
+    GPX_TRY(launch_gemm_nt(ctx, h2, mt, mt, 0, GPX_PROF_GEMM_OTHER, 2.0 * Mp * (double)Mp * Mp));
+  }
+  GPX_TRY(ens(ctx, s->T1a, (size_t)Ntp * s->ldw * 8));
+  GPX_TRY(ens(ctx, s->T1, (size_t)Ntp * s->ldw * 8));
+  { // T1a = W R ; T1 = T1a Tu^T
+    GemmArgs g = gargs(s->Wn.d(), s->ldw, s->B4.d(), s->ldu, s->T1a.d(), s->ldw, Mp, 1.0, 0.0);
+    GPX_TRY(launch_gemm_nt(ctx, g, Ntp / TILE, mt, 0, GPX_PROF_GEMM_OTHER, 2.0 * Ntp * (double)Mp * Mp));
+    GemmArgs h2 = gargs(s->T1a.d(), s->ldw, Tu, s->ldu, s->T1.d(), s->ldw, Mp, 1.0, 0.0);
+    GPX_TRY(launch_gemm_nt(ctx, h2, Ntp / TILE, mt, 0, GPX_PROF_GEMM_OTHER, 2.0 * Ntp * (double)Mp * Mp));
+  }
+  GPX_TRY(ens(ctx, s->rcoef_u, (size_t)Mp * 8));
+  GPX_TRY(ens(ctx, s->rcoef_f, (size_t)Ntp * 8));
+  GPX_TRY(launch_axpby(ctx, s->rcoef_u.d(), -0.5 / (s2 * s2), s->mvec.d(), 0.0, nullptr, M));
+  GPX_TRY(launch_axpby(ctx, s->rcoef_f.d(), 1.0 / (s2 * s2), ctx->yres.d(), -1.0 / (s2 * s2 * s2), s->tvec.d(), N));
+  const int nbj = (M + 63) / 64, nbi_u = (M + 63) / 64, nbi_f = (N + 63) / 64;
+  const int nbi_max = nbi_u > nbi_f ? nbi_u : nbi_f;
+  GPX_TRY(ens(ctx, s->cpart, (size_t)nbj * nbi_max * SC_NV * 8));
+  GPX_TRY(ens(ctx, s->gxu_part, (size_t)nbi_max * M * GPX_MAX_DIM * 8));
+  GPX_TRY(ens(ctx, s->gXu, (size_t)M * d * 8));
+  double* out_uu = sc + 32;
+  double* out_uf = sc + 32 + SC_NV;
+  {
+    dim3 g1(nbj, nbi_u);
+    sgp_contract_kernel<<<g1, 256, 0, ctx->s>>>(s->kp, s->Xu.d(), M, s->Xu.d(), M, s->B3.d(), s->ldu, s->rcoef_u.d(),
+                                                s->mvec.d(), s->cpart.d(), s->gxu_part.d());
+    sgp_reduce_kernel<<<64, 256, 0, ctx->s>>>(s->cpart.d(), nbj * nbi_u, d + 1, out_uu, s->gxu_part.d(), nbi_u, M, d,
+                                              2.0, 0, s->gXu.d());
+    dim3 g2(nbj, nbi_f);
+    sgp_contract_kernel<<<g2, 256, 0, ctx->s>>>(s->kp, ctx->X.d(), N, s->Xu.d(), M, s->T1.d(), s->ldw,
+                                                s->rcoef_f.d(), s->mvec.d(), s->cpart.d(), s->gxu_part.d());
+    sgp_reduce_kernel<<<64, 256, 0, ctx->s>>>(s->cpart.d(), nbj * nbi_f, d + 1, out_uf, s->gxu_part.d(), nbi_f, M, d,
+                                              1.0, 1, s->gXu.d());
+    GPX_HIP(ctx, hipGetLastError());
+  }
+  double hu[GPX_MAX_DIM + 2], hf[GPX_MAX_DIM + 2];
+  GPX_HIP(ctx, hipMemcpyAsync(hu, out_uu, (d + 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(ctx, hipMemcpyAsync(hf, out_uf, (d + 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (grad_Xu)
+    GPX_HIP(ctx, hipMemcpyAsync(grad_Xu, s->gXu.d(), (size_t)M * d * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (dyres) { // dF/dyres = -(y/s2 - t/s2^2)
+    GPX_TRY(launch_axpby(ctx, s->rcoef_f.d(), -1.0 / s2, ctx->yres.d(), 1.0 / (s2 * s2), s->tvec.d(), N));
+    GPX_HIP(ctx, hipMemcpyAsync(dyres, s->rcoef_f.d(), (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (grad_ell)
+    for (int c = 0; c < d; ++c) grad_ell[c] = hu[c] + hf[c];
+  if (grad_scale) *grad_scale = hu[d] + hf[d] - uu * 0.5 * N / s2 * (kd / scale);
+  if (grad_noise) {
+    const double trS1Phi = s2 * (M - trAinv);
+    *grad_noise = -0.5 * N / s2 + 0.5 * trS1Phi / (s2 * s2) + 0.5 * yy / (s2 * s2) - yt / (s2 * s2 * s2) +
+                  0.5 * tt / (s2 * s2 * s2 * s2) + uu * 0.5 * trace_raw / (s2 * s2);
+  }
+  if (bad) {
+    if (grad_ell) for (int c = 0; c < d; ++c) grad_ell[c] = NAN;
+    if (grad_scale) *grad_scale = NAN;
+    if (grad_noise) *grad_noise = NAN;
+  }
+  return 0;
+}
+
+/* viSparseGP.get_mvn_posterior, gpax/models/sparse_gp.py:173-223 (no mean function on the device;
+ * the host adds mean_fn(X_new)).  mean (Ms), cov (Ms*Ms or NULL), var (Ms or NULL). */
+int gpx_sgp_posterior(gpx_ctx* ctx, int kind, const double* ell, double scale, double noise, double jitter,
+                      const double* Xu, int Mi, const double* yres, const double* Xnew, int Ms, double noise_p,
+                      double* mean, double* cov, double* var, int* info) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (!Xnew || Ms < 1) return bad_arg(ctx, "sparse posterior arguments");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  SgpState* s = sgp_state(ctx);
+  GPX_TRY(sgp_setup(ctx, s, kind, ell, scale, noise, jitter, Xu, Mi, yres));
+  GPX_TRY(sgp_forward(ctx, s));
+  const int d = ctx->d, M = s->M, Mp = s->Mp, mt = Mp / TILE;
+  const int Msp = round_up(Ms, TILE), st = Msp / TILE;
+  GPX_TRY(ens(ctx, s->Xs, (size_t)Ms * d * 8));
+  GPX_TRY(ens(ctx, s->V1, (size_t)Msp * s->ldw * 8));
+  GPX_TRY(ens(ctx, s->V2, (size_t)Msp * s->ldw * 8));
+  GPX_TRY(ens(ctx, s->mean, (size_t)Msp * 8));
+  GPX_TRY(ens(ctx, s->var, (size_t)Msp * 8));
+  GPX_TRY(ens(ctx, s->var2, (size_t)Msp * 8));
+  GPX_HIP(ctx, hipMemcpyAsync(s->Xs.d(), Xnew, (size_t)Ms * d * 8, hipMemcpyHostToDevice, ctx->stream));
+  // V1 = Ksu Luu^-T ; V2 = V1 LA^-T
+  GPX_TRY(launch_gram_padded(ctx, s->kp, s->Xs.d(), Ms, Msp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->V1.d(), s->ldw));
+  GPX_TRY(trsm_right_lt(ctx, s->V1.d(), s->ldw, st, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, 0));
+  GPX_HIP(ctx, hipMemcpyAsync(s->V2.d(), s->V1.d(), (size_t)Msp * s->ldw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  GPX_TRY(trsm_right_lt(ctx, s->V2.d(), s->ldw, st, s->A.d(), s->ldu, s->LinvA.d(), mt, 0));
+  const double kdiag = kd_value(s->kp) + noise_p + jitter; // Kss = kernel(X_new, X_new, params, noise_p, **jitter)
+  GPX_TRY(launch_rowdot(ctx, s->V1.d(), s->ldw, Ms, M, s->c.d(), kdiag, nullptr, s->var.d(), 0));   // kd - |V1|^2
+  GPX_TRY(launch_rowdot(ctx, s->V2.d(), s->ldw, Ms, M, s->c.d(), 0.0, s->mean.d(), s->var2.d(), 0)); // mean, -|V2|^2
+  GPX_TRY(launch_axpby(ctx, s->var.d(), 1.0, s->var.d(), -1.0, s->var2.d(), Ms));
+  if (cov) {
+    // cov = Kss - V1 V1^T + V2 V2^T : two split-K SYRK slab sets, finalised against k_pp on the fly
+    const int64_t ldc = pick_ld(Msp);
+    GPX_TRY(ens(ctx, s->Cov, (size_t)Msp * ldc * 8));
+    const int64_t ldp = ldc, stride = (int64_t)Msp * ldp;
+    GPX_TRY(ens(ctx, ctx->SplitK, (size_t)2 * stride * 8));
+    GemmArgs g = gargs(s->V1.d(), s->ldw, s->V1.d(), s->ldw, ctx->SplitK.d(), ldp, Mp, 1.0, 0.0);
+    g.lower = 1;
+    GPX_TRY(launch_gemm_nt(ctx, g, st, st, 0, GPX_PROF_GEMM_OTHER, (double)Msp * Msp * Mp));
+    GemmArgs h2 = gargs(s->V2.d(), s->ldw, s->V2.d(), s->ldw, ctx->SplitK.d() + stride, ldp, Mp, -1.0, 0.0);
+    h2.lower = 1;
+    GPX_TRY(launch_gemm_nt(ctx, h2, st, st, 0, GPX_PROF_GEMM_OTHER, (double)Msp * Msp * Mp));
+    GPX_TRY(launch_cov_finalize(ctx, s->kp, s->Xs.d(), Ms, Msp, ctx->SplitK.d(), 2, stride, ldp, noise_p + jitter,
+                                s->Cov.d(), ldc));
+    GPX_HIP(ctx, hipMemcpy2DAsync(cov, (size_t)Ms * 8, s->Cov.d(), ldc * 8, (size_t)Ms * 8, Ms, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+  }
+  if (mean) GPX_HIP(ctx, hipMemcpyAsync(mean, s->mean.d(), (size_t)Ms * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (var) GPX_HIP(ctx, hipMemcpyAsync(var, s->var.d(), (size_t)Ms * 8, hipMemcpyDeviceToHost, ctx->stream));
+  int bad = 0;
+  GPX_TRY(read_info(ctx, s, &bad));
+  if (info) *info = bad;
+  if (bad) {
+    if (mean) for (int a = 0; a < Ms; ++a) mean[a] = NAN;
+    if (var) for (int a = 0; a < Ms; ++a) var[a] = NAN;
+    if (cov) for (int64_t a = 0; a < (int64_t)Ms * Ms; ++a) cov[a] = NAN;
+  }
+  return 0;
+}
+
+} // extern "C"

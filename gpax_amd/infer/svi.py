@@ -61,29 +61,34 @@ def fit_delta(objective_and_grad: Callable[[np.ndarray], Tuple[float, np.ndarray
 
 
 def fit_normal(logdensity_and_grad: Callable[[np.ndarray], Tuple[float, np.ndarray]], dim: int, num_steps: int,
-               step_size: float, rng: np.random.Generator, init_scale: float = 0.1, progress=None):
-    """Mean-field Normal guide on the unconstrained density (log joint + log|J|).
-    Returns (loc, scale, losses)."""
+               step_size: float, rng: np.random.Generator, init_scale: float = 0.1, progress=None,
+               point0: np.ndarray = None):
+    """Mean-field Normal guide on the unconstrained density (log joint + log|J|) of the first `dim`
+    variables; `point0` are additional point-estimated parameters (numpyro.param, e.g. the inducing
+    points) appended to the argument of `logdensity_and_grad`.  Returns (loc, scale, losses[, point])."""
+    npnt = 0 if point0 is None else int(np.size(point0))
     loc = rng.uniform(-2.0, 2.0, dim)
     rho = np.full(dim, _inv_softplus(init_scale))
-    x = np.concatenate([loc, rho])
-    opt = Adam(2 * dim, step_size)
+    x = np.concatenate([loc, rho] + ([np.ravel(point0).astype(np.float64)] if npnt else []))
+    opt = Adam(2 * dim + npnt, step_size)
     losses = np.empty(num_steps)
     for it in range(num_steps):
-        loc, rho = x[:dim], x[dim:]
+        loc, rho, pnt = x[:dim], x[dim:2 * dim], x[2 * dim:]
         sigma = _softplus(rho)
         e = rng.standard_normal(dim)
         u = loc + sigma * e
-        f, g = logdensity_and_grad(u)
+        f, g = logdensity_and_grad(np.concatenate([u, pnt]) if npnt else u)
         if not np.isfinite(f):
             losses[it] = np.nan
         else:
             entropy = np.sum(np.log(sigma)) + 0.5 * dim * (1 + math.log(2 * math.pi))
             losses[it] = -(f + entropy)
-            g_loc = g
-            g_sigma = g * e + 1.0 / sigma
+            g_loc = g[:dim]
+            g_sigma = g[:dim] * e + 1.0 / sigma
             g_rho = g_sigma / (1.0 + np.exp(-rho))
-            x = opt.step(x, -np.concatenate([g_loc, g_rho]))
+            x = opt.step(x, -np.concatenate([g_loc, g_rho, g[dim:]]))
         if progress is not None:
             progress(it, num_steps, dict(loss=losses[it]))
+    if npnt:
+        return x[:dim].copy(), _softplus(x[dim:2 * dim]), losses, x[2 * dim:].copy()
     return x[:dim].copy(), _softplus(x[dim:]), losses

@@ -113,6 +113,24 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
                       const double* Xnew, int M, int noiseless, double jitter,
                       const double* eps, int n, double* means, double* samples, int* infos);
 
+/* ---- variational sparse GP: viSparseGP, gpax/models/sparse_gp.py ----------------------------
+ * gpx_sgp_bound: the per-SVI-step objective of viSparseGP.model (sparse_gp.py:62-114): VFE bound =
+ * LowRankMultivariateNormal(loc, cov_factor=W, cov_diag=noise).log_prob(y) - trace_term/2 with
+ * W = (Luu^-1 Kuf)^T, for inducing points Xu (Mi x d) on the X uploaded by gpx_set_train, and (when
+ * want_grad) its analytic gradient w.r.t. (ell[d], scale, noise) and Xu (Mi*d) — replaces JAX
+ * autodiff through sparse_gp.py:92-114.  dyres (N, may be NULL) = d bound / d yres for the
+ * mean-function chain rule.  *info: >0 chol(Kuu) failed, <0 chol(capacitance) failed => NaN. */
+int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, double noise, double jitter,
+                  const double* Xu, int Mi, const double* yres, int want_grad, double* bound,
+                  double* grad_ell, double* grad_scale, double* grad_noise, double* grad_Xu, double* dyres,
+                  int* info);
+
+/* viSparseGP.get_mvn_posterior (sparse_gp.py:173-223): Woodbury posterior at Xnew (Ms x d).
+ * mean (Ms), cov (Ms*Ms or NULL), var (Ms or NULL).  noise_p = noise * (1 - noiseless). */
+int gpx_sgp_posterior(gpx_ctx* ctx, int kind, const double* ell, double scale, double noise, double jitter,
+                      const double* Xu, int Mi, const double* yres, const double* Xnew, int Ms, double noise_p,
+                      double* mean, double* cov, double* var, int* info);
+
 /* ---- measurement hooks (bench.py / profiles) ----------------------------------------------
  * When enabled, HIP events bracket every launch of the profiled kernel classes on the
  * library's own stream; gpx_profile_read returns launches, summed duration and summed

@@ -101,3 +101,54 @@ class OracleEngine:
                 if bad and not info:
                     infos[s] = -1
         return means, samples, infos
+
+    # ---- sparse GP (tests only; gradient by central differences of the oracle bound) -----------------
+    def sgp_bound(self, kind, ell, scale, noise, jitter, Xu, yres, want_grad=True):
+        name = _NAMES[kind]
+        ell = broadcast_lengthscale(ell, self.d)
+        Xu = np.asarray(Xu, dtype=np.float64)
+        yres = np.asarray(yres, dtype=np.float64)
+
+        def f(e, s, n, xu, yy=yres):
+            try:
+                return ref.sparse_bound(self.X, yy, xu, {"k_length": e, "k_scale": s, "noise": n}, kernel=name,
+                                        jitter=jitter)
+            except np.linalg.LinAlgError:
+                return float("nan")
+
+        b = f(ell, scale, noise, Xu)
+        if not np.isfinite(b):
+            return b, 1, None
+        if not want_grad:
+            return b, 0, None
+        h = 1e-6
+        g_ell = np.empty(self.d)
+        for m in range(self.d):
+            a, c = ell.copy(), ell.copy()
+            a[m] += h
+            c[m] -= h
+            g_ell[m] = (f(a, scale, noise, Xu) - f(c, scale, noise, Xu)) / (2 * h)
+        g_s = (f(ell, scale + h, noise, Xu) - f(ell, scale - h, noise, Xu)) / (2 * h)
+        g_n = (f(ell, scale, noise + h * noise, Xu) - f(ell, scale, noise - h * noise, Xu)) / (2 * h * noise)
+        g_xu = np.empty_like(Xu)
+        for idx in np.ndindex(*Xu.shape):
+            a, c = Xu.copy(), Xu.copy()
+            a[idx] += h
+            c[idx] -= h
+            g_xu[idx] = (f(ell, scale, noise, a) - f(ell, scale, noise, c)) / (2 * h)
+        K = ref.get_kernel(name)
+        p = {"k_length": ell, "k_scale": scale, "noise": noise}
+        Kuu = K(Xu, Xu, p, jitter=jitter)
+        Kuf = K(Xu, self.X, p)
+        Q = Kuf.T @ np.linalg.solve(Kuu, Kuf) + noise * np.eye(self.N)
+        dy = -np.linalg.solve(Q, yres)
+        return b, 0, dict(k_length=g_ell, k_scale=g_s, noise=g_n, Xu=g_xu, yres=dy)
+
+    def sgp_posterior(self, kind, ell, scale, noise, jitter, Xu, yres, Xnew, noise_p, want_cov=True, want_var=False):
+        p = {"k_length": broadcast_lengthscale(ell, self.d), "k_scale": scale, "noise": noise}
+        noiseless = noise_p == 0.0 and noise != 0.0
+        mean, cov = ref.sparse_posterior(self.X, np.asarray(yres, dtype=np.float64), np.asarray(Xu, dtype=np.float64),
+                                         np.asarray(Xnew, dtype=np.float64), p, noiseless, kernel=_NAMES[kind],
+                                         jitter=jitter)
+        mean = np.atleast_1d(mean)
+        return mean, (cov if want_cov else None), (np.diag(cov).copy() if want_var else None), 0

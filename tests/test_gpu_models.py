@@ -91,3 +91,29 @@ def test_get_mvn_posterior_on_gpu_matches_reference_inverse_route():
     np.testing.assert_allclose(cov, c_ref, rtol=1e-6, atol=1e-9)
     ymean, ydraw = m._predict(get_keys()[1], Xn, params, 3)
     assert ydraw.shape == (3, 30)
+
+
+@pytest.mark.parametrize("guide", ["delta", "normal"])
+def test_visparsegp_on_gpu(guide):
+    from gpax_amd.models import viSparseGP
+    from gpax_amd.utils import preprocess_sparse_image
+
+    rng = np.random.default_rng(3)
+    img = np.fromfunction(lambda i, j: np.sin(i / 6.0) * np.cos(j / 5.0) + 1.5, (48, 48))
+    sparse = img * (rng.uniform(size=img.shape) < 0.25)
+    X, y, X_full = preprocess_sparse_image(sparse)
+    m = viSparseGP(2, "Matern", guide=guide)
+    m.fit(get_keys()[0], X, y, inducing_points_ratio=0.2, num_steps=60, step_size=0.05, progress_bar=False,
+          print_summary=False)
+    assert m.Xu.shape == (int(len(X) * 0.2), 2)
+    mean, var = m.predict_in_batches(get_keys()[1], X_full, batch_size=1000)
+    assert mean.shape == (48 * 48,) and var.shape == (48 * 48,) and np.all(var > 0)
+    s = m.get_samples()
+    m_ref, c_ref = ref.sparse_posterior(X, y, m.Xu, X_full[:200], {k: np.asarray(v) for k, v in s.items()},
+                                        kernel="Matern")
+    np.testing.assert_allclose(mean[:200], m_ref, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(var[:200], np.diag(c_ref), rtol=1e-6, atol=1e-7)
+    if guide == "delta":
+        assert m.loss[-1] < m.loss[0]
+        rmse = np.sqrt(np.mean((mean - img.reshape(-1)) ** 2))
+        assert rmse < 0.25

@@ -1,0 +1,95 @@
+"""GPU parity of the variational sparse GP (viSparseGP rows A19-A21) vs the oracle and the golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as ref
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KINDS = [(0, "RBF"), (1, "Matern")]
+
+
+@pytest.mark.parametrize("kind,name", KINDS)
+def test_sparse_bound_and_posterior_golden(engine, kind, name):
+    g = np.load(os.path.join(GOLD, "sparse.npz"))
+    th = g["theta"]
+    engine.set_train(g["X"])
+    bound, info, _ = engine.sgp_bound(kind, th[:-2], th[-2], th[-1], 1e-6, g["Xu"], g["y"], want_grad=False)
+    assert info == 0
+    expect = float(g[f"{name}_bound"])
+    assert abs(bound - expect) <= 1e-9 * abs(expect)
+    for noiseless in [0, 1]:
+        noise_p = 0.0 if noiseless else th[-1]
+        mean, cov, var, info = engine.sgp_posterior(kind, th[:-2], th[-2], th[-1], 1e-6, g["Xu"], g["y"], g["Xn"],
+                                                    noise_p, want_cov=True, want_var=True)
+        assert info == 0
+        m_ref, c_ref = g[f"{name}_mean_{noiseless}"], g[f"{name}_cov_{noiseless}"]
+        # Kuu carries only the 1e-6 jitter (cond ~1e7): agreement is bounded by that conditioning
+        assert np.linalg.norm(mean - m_ref) <= 1e-7 * np.linalg.norm(m_ref)
+        assert np.abs(cov - c_ref).max() <= 1e-7 * th[-2]
+        assert np.abs(var - np.diag(c_ref)).max() <= 1e-7 * th[-2]
+
+
+@pytest.mark.parametrize("kind,name", KINDS)
+@pytest.mark.parametrize("N,d,Mi", [(150, 1, 12), (400, 2, 40), (700, 3, 150)])
+def test_sparse_gradient_matches_finite_differences_of_oracle(engine, kind, name, N, d, Mi):
+    X, y, _, p = ref.synthetic_problem(N, d, 4, seed=N + Mi)
+    rng = np.random.default_rng(1)
+    Xu = X[rng.choice(N, Mi, replace=False)] + 0.05 * rng.standard_normal((Mi, d))
+    engine.set_train(X)
+    jit = 1e-4  # keeps cond(Kuu) moderate so that central differences of the oracle are meaningful
+    bound, info, g = engine.sgp_bound(kind, p["k_length"], p["k_scale"], p["noise"], jit, Xu, y)
+    assert info == 0
+    f0 = ref.sparse_bound(X, y, Xu, p, kernel=name, jitter=jit)
+    assert abs(bound - f0) <= 1e-8 * abs(f0)
+
+    def f(ell, scale, noise, xu, yy=y):
+        return ref.sparse_bound(X, yy, xu, {"k_length": ell, "k_scale": scale, "noise": noise}, kernel=name, jitter=jit)
+
+    ell0, s0, n0 = np.asarray(p["k_length"], dtype=float), p["k_scale"], p["noise"]
+    scale_g = max(np.abs(g["k_length"]).max(), abs(g["k_scale"]), abs(g["noise"]))
+    for m in range(d):
+        h = 1e-5 * ell0[m]
+        a, b = ell0.copy(), ell0.copy()
+        a[m] += h
+        b[m] -= h
+        fd = (f(a, s0, n0, Xu) - f(b, s0, n0, Xu)) / (2 * h)
+        assert abs(fd - g["k_length"][m]) <= 2e-5 * scale_g
+    h = 1e-5 * s0
+    assert abs((f(ell0, s0 + h, n0, Xu) - f(ell0, s0 - h, n0, Xu)) / (2 * h) - g["k_scale"]) <= 2e-5 * scale_g
+    h = 1e-5 * n0
+    assert abs((f(ell0, s0, n0 + h, Xu) - f(ell0, s0, n0 - h, Xu)) / (2 * h) - g["noise"]) <= 2e-5 * scale_g
+    gx_scale = np.abs(g["Xu"]).max()
+    for (a_, m_) in [(0, 0), (Mi // 2, d - 1), (Mi - 1, 0)]:
+        h = 1e-5
+        xp, xm = Xu.copy(), Xu.copy()
+        xp[a_, m_] += h
+        xm[a_, m_] -= h
+        fd = (f(ell0, s0, n0, xp) - f(ell0, s0, n0, xm)) / (2 * h)
+        assert abs(fd - g["Xu"][a_, m_]) <= 5e-5 * max(gx_scale, 1.0)
+    for n_ in [0, N // 3]:
+        h = 1e-5
+        yp, ym = y.copy(), y.copy()
+        yp[n_] += h
+        ym[n_] -= h
+        fd = (f(ell0, s0, n0, Xu, yp) - f(ell0, s0, n0, Xu, ym)) / (2 * h)
+        assert abs(fd - g["yres"][n_]) <= 1e-5 * max(np.abs(g["yres"]).max(), 1.0)
+
+
+def test_sparse_c5_shape_runs_and_is_deterministic(engine):
+    # a scaled-down C5: image-like 2-D inputs, Matern, inducing ratio 0.125
+    rng = np.random.default_rng(3)
+    N, Mi = 4096, 512
+    X = rng.uniform(0, 64, (N, 2))
+    y = np.sin(X[:, 0] / 7) * np.cos(X[:, 1] / 5) + 0.05 * rng.standard_normal(N)
+    Xu = X[rng.choice(N, Mi, replace=False)]
+    engine.set_train(X)
+    b1, info, g1 = engine.sgp_bound(1, [8.0, 8.0], 1.0, 0.01, 1e-6, Xu, y)
+    b2, _, g2 = engine.sgp_bound(1, [8.0, 8.0], 1.0, 0.01, 1e-6, Xu, y)
+    assert info == 0 and np.isfinite(b1) and b1 == b2
+    np.testing.assert_array_equal(g1["Xu"], g2["Xu"])
+    full = ref.exactgp_log_likelihood(X, y, {"k_length": np.array([8.0, 8.0]), "k_scale": 1.0, "noise": 0.01},
+                                      kernel="Matern")
+    assert b1 <= full + 1e-6 * abs(full)  # the VFE bound never exceeds the exact log marginal likelihood

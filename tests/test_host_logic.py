@@ -7,7 +7,7 @@ import pytest
 
 import gpax_amd
 from gpax_amd import _lib, dist
-from gpax_amd.models import ExactGP, viGP
+from gpax_amd.models import ExactGP, viGP, viSparseGP
 from gpax_amd.utils import (get_keys, initialize_inducing_points, preprocess_sparse_image, random_sample_dict,
                             split_dict, split_in_batches)
 from oracle import cpu_ref as ref
@@ -230,3 +230,26 @@ def test_utils_match_reference_behaviour():
     k1, k2 = get_keys(1)
     assert not np.array_equal(k1, k2) and np.array_equal(get_keys(1)[0], k1)
     assert gpax_amd.utils.enable_x64() is None
+
+
+@pytest.mark.parametrize("guide", ["delta", "normal"])
+def test_visparsegp_fit_predict(guide):
+    # gpax/tests/test_sparsegp.py:26-64: Xu is an array, is optimised, posterior shapes
+    X, y, Xn, _ = ref.synthetic_problem(24, 1, 7, seed=4)
+    key = get_keys()[0]
+    m1 = viSparseGP(1, "Matern", guide=guide)
+    m1.fit(key, X, y, inducing_points_ratio=0.2, num_steps=1, progress_bar=False, print_summary=False)
+    m2 = viSparseGP(1, "Matern", guide=guide)
+    m2.fit(key, X, y, inducing_points_ratio=0.2, num_steps=25, step_size=0.05, progress_bar=False, print_summary=False)
+    assert isinstance(m2.Xu, np.ndarray) and m2.Xu.shape == (4, 1)
+    assert not np.allclose(m1.Xu, m2.Xu)
+    mean, var = m2.predict(get_keys()[1], Xn)
+    assert mean.shape == (7,) and var.shape == (7,)
+    mean2, cov = m2.get_mvn_posterior(Xn, m2.get_samples())
+    assert cov.shape == (7, 7)
+    np.testing.assert_allclose(mean, mean2, rtol=1e-10)
+    np.testing.assert_allclose(var, np.diag(cov), rtol=1e-8)
+    mb, vb = m2.predict_in_batches(get_keys()[1], Xn, batch_size=3)
+    np.testing.assert_allclose(mb, mean, rtol=1e-10)
+    if guide == "delta":
+        assert np.nanmin(m2.loss[-5:]) < m2.loss[0]
