@@ -151,6 +151,15 @@ def main():
                          ("posterior", _lib.STAGE_POSTERIOR), ("predict", _lib.STAGE_PREDICT)]:
             eng.time_stage(st, 1)
             stages[name + "_ms"] = eng.time_stage(st, 2) / 2
+        # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/r01/traffic.json; FETCH_SIZE doubled per the gfx950 correction, MI355X_MICROARCH.md §HBM)
+        traffic, traffic_note = None, None
+        tj = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+        if os.path.exists(tj) and (N, d, M) == (16384, 2, 1024):
+            t = json.load(open(tj))
+            if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+                traffic = (2.0 * t["FETCH_SIZE"]["avg_per_launch"] + t["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
+                traffic_note = "bytes per launch, profiles/r01/{fetch,write}.md: (2*FETCH_SIZE + WRITE_SIZE) KB"
         post_flops = N ** 3 / 3 + N * N * M + N * M * M + 2 * N * N + 2 * N * M + M ** 3 / 3 + M * M
         out = {
             "metric": f"exactgp_posteriors_per_sec_N{N}_d{d}",
@@ -175,7 +184,9 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
+                "alg_bytes_per_launch_avg": (flops / n_l / (2.0 * 512) * 16.0) if n_l else None,
                 "launches": n_l,
                 "avg_launch_ms": ms / n_l if n_l else None,
                 "alg_flops_per_launch_avg": flops / n_l if n_l else None,

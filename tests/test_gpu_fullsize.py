@@ -1,0 +1,90 @@
+"""GPU: BASELINE.json's full-size configurations through size-independent properties (the oracle is too
+slow there): K alpha = y round trip, determinism, posterior-at-training-points identity, sweep linearity
+in y, VFE bound <= exact lml, sharded == unsharded."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def test_c3_matern_n16384_roundtrip(engine):
+    N, d = 16384, 2
+    X, y, Xn, p = ref.synthetic_problem(N, d, 1024, seed=0)
+    engine.set_train(X)
+    lml, info = engine.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+    assert info == 0 and np.isfinite(lml)
+    sub = np.arange(0, N, 64)
+    mean, cov, var = engine.posterior(X[sub], p["noise"], 1e-6, want_cov=True, want_var=True)
+    lml2, _ = engine.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+    assert lml2 == lml  # bit-identical across runs (fixed accumulation order, also under look-ahead)
+    g_ell, g_scale, g_noise, alpha = engine.lml_grad()
+    # posterior mean at training inputs = y - (noise + jitter) alpha
+    assert relerr(mean, y[sub] - (p["noise"] + 1e-6) * alpha[sub]) < 1e-8
+    K_rows = ref.MaternKernel(X[sub], X, p)
+    K_rows[np.arange(len(sub)), sub] += p["noise"] + 1e-6
+    assert relerr(K_rows @ alpha, y[sub]) < 1e-8
+    # lml from alpha: -1/2 y.alpha - ... consistency of the quadratic term with the gradient pass
+    assert np.all(var > 0) and np.allclose(var, np.diag(cov), rtol=1e-9, atol=1e-12)
+    # d lml / d noise = 1/2 (alpha.alpha - tr K^-1) must be negative-ish finite and reproducible
+    lml3, _ = engine.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+    g2 = engine.lml_grad()
+    assert g2[2] == g_noise and np.array_equal(g2[0], g_ell)
+    # finite-difference check of one gradient component at full size (two extra factorisations)
+    h = 1e-4
+    lp, _ = engine.factor(1, p["k_length"], p["k_scale"], p["noise"] * (1 + h), 1e-6, y)
+    lm, _ = engine.factor(1, p["k_length"], p["k_scale"], p["noise"] * (1 - h), 1e-6, y)
+    fd = (lp - lm) / (2 * h * p["noise"])
+    assert abs(fd - g_noise) <= 1e-5 * abs(g_noise)
+
+
+def test_c4_sweep_n8192_d3_properties(engine):
+    N, d, M, S = 8192, 3, 1024, 3
+    X, y, Xn, _ = ref.synthetic_problem(N, d, M, seed=0)
+    th = ref.synthetic_theta_samples(S, d, seed=1)
+    eps = np.random.default_rng(2).standard_normal((S, 1, M))
+    engine.set_train(X)
+    m1, d1, i1 = engine.predict_sweep(0, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps)
+    m2, d2, i2 = engine.predict_sweep(0, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps)
+    assert np.all(i1 == 0)
+    np.testing.assert_array_equal(m1, m2)
+    np.testing.assert_array_equal(d1, d2)
+    # the posterior mean is linear in y; the draw noise (draw - mean) does not depend on y
+    m3, d3, _ = engine.predict_sweep(0, th["k_length"], th["k_scale"], th["noise"], 2.0 * y, Xn, False, 1e-6, eps)
+    assert relerr(m3, 2.0 * m1) < 1e-10
+    assert relerr(d3 - m3[:, None, :], d1 - m1[:, None, :]) < 1e-9
+    # sweep == per-sample factor + posterior (non-fused path: separate TRSM of k_pX)
+    engine.factor(0, th["k_length"][1], th["k_scale"][1], th["noise"][1], 1e-6, y)
+    mean, cov, _ = engine.posterior(Xn, th["noise"][1], 1e-6)
+    assert relerr(m1[1], mean) < 1e-10
+    # noiseless sweep: same means
+    m4, _, _ = engine.predict_sweep(0, th["k_length"], th["k_scale"], th["noise"], y, Xn, True, 1e-6, None)
+    assert relerr(m4, m1) < 1e-12
+
+
+def test_c5_sparse_512x512_image_shapes(engine):
+    rng = np.random.default_rng(3)
+    H = W = 512
+    ii, jj = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    img = 1.5 + np.sin(ii / 40.0) * np.cos(jj / 55.0)
+    keep = rng.uniform(size=img.shape) < 0.0625
+    X = np.column_stack(np.nonzero(keep)).astype(np.float64)
+    y = img[keep]
+    N = X.shape[0]
+    Mi = 2048
+    Xu = X[rng.choice(N, Mi, replace=False)]
+    engine.set_train(X)
+    ell, scale, noise = [30.0, 30.0], 1.0, 1e-2
+    b, info, g = engine.sgp_bound(1, ell, scale, noise, 1e-6, Xu, y - y.mean())
+    assert info == 0 and np.isfinite(b) and np.isfinite(g["Xu"]).all()
+    lml, info2 = engine.factor(1, ell, scale, noise, 1e-6, y - y.mean())
+    assert info2 == 0 and b <= lml + 1e-6 * abs(lml)
+    Xs = np.column_stack([ii.reshape(-1), jj.reshape(-1)]).astype(np.float64)[:1000]
+    mean, _, var, info3 = engine.sgp_posterior(1, ell, scale, noise, 1e-6, Xu, y - y.mean(), Xs, noise, False, True)
+    assert info3 == 0 and mean.shape == (1000,) and np.all(var > 0)
+    assert np.sqrt(np.mean((mean + y.mean() - img.reshape(-1)[:1000]) ** 2)) < 0.1
