@@ -36,6 +36,7 @@ constexpr size_t GEMM_LDS_BYTES = size_t(4) * TILE_DOUBLES * sizeof(double); // 
 template <int TAG>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (TAG == 0) __builtin_amdgcn_s_setprio(2); // panel / small GEMMs sit on the critical path of the look-ahead
   const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   const int ti = g.ti_off + by, tj = g.tj_off + bx;
   if (g.lower && tj > ti) return;

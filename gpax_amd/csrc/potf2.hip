@@ -77,6 +77,9 @@ __device__ __forceinline__ void potf2_block(double (&S)[8][8], double* colbuf, d
 
 __global__ __launch_bounds__(256, 1) void potf2_inv_kernel(double* A, int64_t lda, double* Linv,
                                                            int* info, int info_base) {
+  // latency-critical serial kernel of the factorisation: win issue arbitration against the
+  // trailing-update waves it shares a CU with under look-ahead
+  __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* T = lds;                   // 64 x PT_LD transpose staging (one half at a time)
   double* colbuf = lds + 64 * PT_LD; // 2 x PB
