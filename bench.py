@@ -86,7 +86,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ and "RANK" in os.environ:  # launched by torch.distributed.run (any N, also 1)
         # torch first: its bundled HIP runtime must be the one libgpx binds to (same SONAME)
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
