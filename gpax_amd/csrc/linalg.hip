@@ -37,11 +37,11 @@ static inline GemmArgs gemm_args(const double* A, int64_t lda, const double* B, 
 //
 // Look-ahead on two streams.  For outer block k (columns [ob, oe)):
 //   P(k)  panel stream: potf2 / TRSM / inner updates of the block's own columns;
-//   U1(k) main stream : trailing update restricted to the NEXT outer block's columns;
+//   U1(k) panel stream: trailing update restricted to the NEXT outer block's columns;
 //   U2(k) main stream : trailing update of everything to the right of that.
 // P(k+1) only needs U1(k), so it runs concurrently with U2(k) — the latency-bound panel work
-// hides behind the big SYRK.  Order on the main stream U1(0) U2(0) U1(1) U2(1) ... keeps the
-// accumulation order of every C tile fixed, so results are run-to-run deterministic.
+// hides behind the big SYRK, and U2(k) follows U2(k-1) with no gap.  Every C tile still receives
+// its updates in a fixed order (U2(k-1) before U1(k) by event), so results are bit-reproducible.
 static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob, int oe,
                        double* dLinv, int* dInfo) {
   for (int kb = ob; kb < oe; ++kb) {
@@ -72,7 +72,7 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
 
 // C[rows r0.., cols c0..c1) -= Pan[rows, ob..oe) * Pan[cols, ob..oe)^T, lower tiles only.
 static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob,
-                           int oe, int r0, int c0, int c1) {
+                           int oe, int r0, int c0, int c1, int prof_cls) {
   const int rows = nblk + extra - r0, cols = c1 - c0;
   if (rows <= 0 || cols <= 0) return 0;
   const int K = (oe - ob) * TILE;
@@ -91,7 +91,7 @@ static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int 
     const double diag = (c0 + t >= r0) ? 0.5 * TILE * (TILE + 1.0) : 0.0;
     entries += full + diag;
   }
-  return launch_gemm_nt(ctx, g, rows, cols, 0, GPX_PROF_GEMM_TRAILING, 2.0 * K * entries);
+  return launch_gemm_nt(ctx, g, rows, cols, 0, prof_cls, 2.0 * K * entries);
 }
 
 int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,
@@ -114,21 +114,22 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     const int ob = k * OUTER_TILES;
     const int oe = (ob + OUTER_TILES < nblk) ? ob + OUTER_TILES : nblk;
     const int oe2 = (oe + OUTER_TILES < nblk) ? oe + OUTER_TILES : nblk;
-    // P(k) on the panel stream, after U1(k-1)
+    // P(k) on the panel stream (it follows U1(k-1) there, in stream order)
     ctx->s = span;
-    if (k > 0) GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
     rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo);
     if (rc < 0) break;
     GPX_HIP(ctx, hipEventRecord(ctx->evP[k], span));
-    // U1(k), U2(k) on the main stream, after P(k)
-    ctx->s = smain;
     GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
     if (oe < nblk) {
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, oe2);
+      // U1(k): next panel's columns, on the PANEL stream (it is what P(k+1) waits for), after
+      // U2(k-1) which also wrote those columns.  U2(k) starts on the main stream at the same time:
+      // disjoint C tiles, so the big SYRKs run back to back with no U1 gap between them.
+      if (k > 0) GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
+      // (profiled / prioritised with the panel GEMMs: it is latency-critical and overlaps U2)
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, oe2, GPX_PROF_GEMM_OTHER);
       if (rc < 0) break;
-      GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain));
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe2, oe2, nblk);
-    } else {
+      ctx->s = smain;
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe2, oe2, nblk, GPX_PROF_GEMM_TRAILING);
       GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain));
     }
   }
