@@ -17,6 +17,8 @@
 // A non-positive pivot makes sqrt() produce NaN (propagates, like JAX) and sets *info.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace gpx {
 
 constexpr int PB = 128;
@@ -149,20 +151,243 @@ __global__ __launch_bounds__(256, 1) void potf2_inv_kernel(double* A, int64_t ld
   }
 }
 
-int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo,
-                     int info_base) {
-  static bool attr_set = false;
-  if (!attr_set) {
+} // namespace gpx
+
+// =================================================================================================
+// potf2_tile_kernel — the same 128x128 factor + inverse, re-blocked at 16x16 tiles so that all
+// O(n^3) work runs on v_mfma_f64_16x16x4_f64 and only the 16x16 diagonal tiles are factored with
+// scalar code (one wave, 16 column steps each).  8 panel steps x 4 barriers instead of 128 column
+// steps; ~37 KB LDS (co-resident with a GEMM workgroup under look-ahead).
+//
+// Tiles live in REGISTERS as MFMA accumulators, owned statically by the 4 waves: the 36 lower
+// Cholesky tiles C(i,j) and the 28 strictly-lower residual tiles R(i,c) of the forward substitution
+// L X = I (R(i,i) = I implicit).  Panel p:
+//   A  owners dump column-p tiles C(i,p), i >= p, and row-p residual tiles R(p,c), c < p, to LDS
+//   B  wave 0 factors the diagonal tile (fused factor + inverse, as potf2_inv_kernel at 16x16)
+//   C  TRSM tiles L(i,p) = C(i,p) Linv_pp^T (i > p) and inverse row X(p,c) = Linv_pp R(p,c) (c < p)
+//   D  C(i,j) -= L(i,p) L(j,p)^T  (i >= j > p);   R(i,c) -= L(i,p) X(p,c)  (i > p, c <= p)
+// =================================================================================================
+namespace gpx {
+
+typedef double pd4_t __attribute__((ext_vector_type(4)));
+
+constexpr int TS = 16;
+constexpr int TLD = 17;
+constexpr int TSZ = TS * TLD; // doubles per LDS tile
+constexpr size_t POTF2_TILE_LDS = (size_t)(17 * TSZ + 64) * sizeof(double);
+
+__device__ __forceinline__ void lower_tile(int idx, int& i, int& j) { // idx = i (i + 1) / 2 + j
+  i = (idx >= 28) ? 7 : (idx >= 21) ? 6 : (idx >= 15) ? 5 : (idx >= 10) ? 4 : (idx >= 6) ? 3 : (idx >= 3) ? 2 : (idx >= 1) ? 1 : 0;
+  j = idx - i * (i + 1) / 2;
+}
+__device__ __forceinline__ void strict_tile(int idx, int& i, int& c) { // idx = i (i - 1) / 2 + c, i > c
+  i = (idx >= 21) ? 7 : (idx >= 15) ? 6 : (idx >= 10) ? 5 : (idx >= 6) ? 4 : (idx >= 3) ? 3 : (idx >= 1) ? 2 : 1;
+  c = idx - i * (i - 1) / 2;
+}
+
+__device__ __forceinline__ void acc_to_lds(const pd4_t& a, double* T, int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) T[((lane >> 4) + 4 * r) * TLD + (lane & 15)] = a[r];
+}
+
+// acc += sgn * TA * TB^T   (TA[m][k], TB[n][k], 16x16 row-major tiles with leading dimension TLD)
+__device__ __forceinline__ pd4_t mma_nt(pd4_t acc, const double* TA, const double* TB, int lane, double sgn) {
+  const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const double a = sgn * TA[fr * TLD + fk + 4 * kk];
+    const double b = TB[fr * TLD + fk + 4 * kk];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// acc += sgn * TA * TB     (TA[m][k], TB[k][n])
+__device__ __forceinline__ pd4_t mma_nn(pd4_t acc, const double* TA, const double* TB, int lane, double sgn) {
+  const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const double a = sgn * TA[fr * TLD + fk + 4 * kk];
+    const double b = TB[(fk + 4 * kk) * TLD + fr];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// One wave: factor the 16x16 tile D (lower read) in place -> L (zeros above), inverse -> Dinv.
+// Lane (r = lane & 15, q = lane >> 4) owns S[r][4q .. 4q+3]; fused update rule as potf2_block.
+__device__ __forceinline__ void diag16(double* D, double* Dinv, double* col /* 2 x 16 */, int lane, int& bad,
+                                       int base) {
+  const int r = lane & 15, q = lane >> 4;
+  double e[4], mypiv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = 4 * q + t;
+    e[t] = (r >= i) ? D[r * TLD + i] : 0.0;
+    mypiv[t] = 1.0;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double* cb = col + (j & 1) * 16;
+    if (q == (j >> 2)) cb[r] = e[j & 3];
+    // one wave: the LDS queue is in order, so the reads below see the write; the asm only stops the
+    // compiler from caching / reordering the accesses (no volatile: the six reads share one wait)
+    asm volatile("" ::: "memory");
+    const double dj = cb[j];
+    const double crr = cb[r];
+    const double c0 = cb[4 * q + 0], c1 = cb[4 * q + 1], c2 = cb[4 * q + 2], c3 = cb[4 * q + 3];
+    asm volatile("" ::: "memory");
+    const double cr = (r == j) ? 1.0 : crr;
+    double ip2 = __builtin_amdgcn_rcp(dj);
+    ip2 = fma(fma(-dj, ip2, 1.0), ip2, ip2);
+    ip2 = fma(fma(-dj, ip2, 1.0), ip2, ip2);
+    if (q == (j >> 2)) mypiv[j & 3] = dj;
+    if (!(dj > 0.0) && bad == 0) bad = base + j + 1;
+    const double cc[4] = {c0 * ip2, c1 * ip2, c2 * ip2, c3 * ip2};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = 4 * q + t;
+      const bool on = (i > j) && (r >= i || r <= j);
+      if (on) e[t] = fma(-cr, cc[t], e[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = 4 * q + t;
+    const double piv = sqrt(mypiv[t]);
+    const double ip = 1.0 / piv;
+    double lval, xval;
+    if (r > i) {
+      lval = e[t] * ip;
+      xval = 0.0;
+    } else if (r == i) {
+      lval = piv;
+      xval = ip;
+    } else {
+      lval = 0.0;
+      xval = e[t] * ip; // = Linv[i][r]
+    }
+    D[r * TLD + i] = lval;
+    Dinv[i * TLD + r] = xval;
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t lda, double* Linv, int* info,
+                                                            int info_base) {
+  __builtin_amdgcn_s_setprio(3);
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* Pbuf = lds;            // 8 tiles: column-p panel (raw -> L)
+  double* Rrow = lds + 8 * TSZ;  // 8 tiles: residual row p (raw -> inverse row X(p, c))
+  double* Dinv = lds + 16 * TSZ; // inverse of the diagonal tile
+  double* col = lds + 17 * TSZ;  // 16 + 16 scratch doubles of the diagonal-tile factor
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int crow = lane >> 4, ccol = lane & 15; // accumulator layout: rows crow + 4 r, column ccol
+
+  // zero the strictly-upper 16x16 tiles of both outputs (the diagonal tiles are written whole later)
+  for (int idx = w; idx < 28; idx += 4) {
+    int i, c;
+    strict_tile(idx, i, c); // tile (c, i) is above the diagonal
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      A[(int64_t)(c * TS + crow + 4 * r) * lda + i * TS + ccol] = 0.0;
+      Linv[(c * TS + crow + 4 * r) * PB + i * TS + ccol] = 0.0;
+    }
+  }
+
+  pd4_t C[9], R[7];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    int i, j;
+    lower_tile(4 * t + w, i, j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[t][r] = A[(int64_t)(i * TS + crow + 4 * r) * lda + j * TS + ccol];
+  }
+#pragma unroll
+  for (int u = 0; u < 7; ++u) R[u] = pd4_t{0.0, 0.0, 0.0, 0.0};
+  int bad = 0;
+
+  for (int p = 0; p < 8; ++p) {
+    // ---- A: dump column p of C and row p of R -----------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      int i, j;
+      lower_tile(4 * t + w, i, j);
+      if (j == p) acc_to_lds(C[t], Pbuf + i * TSZ, lane);
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      int i, c;
+      strict_tile(4 * u + w, i, c);
+      if (i == p) acc_to_lds(R[u], Rrow + c * TSZ, lane);
+    }
+    __syncthreads();
+    // ---- B: diagonal tile -----------------------------------------------------------------------
+    if (w == 0) {
+      diag16(Pbuf + p * TSZ, Dinv, col, lane, bad, p * TS);
+      const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = 4 * q + t;
+        A[(int64_t)(p * TS + r) * lda + p * TS + i] = Pbuf[p * TSZ + r * TLD + i];
+        Linv[(p * TS + r) * PB + p * TS + i] = Dinv[r * TLD + i];
+      }
+    }
+    __syncthreads();
+    // ---- C: panel TRSM and inverse row ----------------------------------------------------------
+    for (int m = w; m < 7; m += 4) {
+      if (m < 7 - p) { // L(i,p) = C(i,p) Linv_pp^T
+        const int i = p + 1 + m;
+        pd4_t x = mma_nt(pd4_t{0.0, 0.0, 0.0, 0.0}, Pbuf + i * TSZ, Dinv, lane, 1.0);
+        acc_to_lds(x, Pbuf + i * TSZ, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(int64_t)(i * TS + crow + 4 * r) * lda + p * TS + ccol] = x[r];
+      } else { // X(p,c) = Linv_pp R(p,c)
+        const int c = m - (7 - p);
+        pd4_t x = mma_nn(pd4_t{0.0, 0.0, 0.0, 0.0}, Dinv, Rrow + c * TSZ, lane, 1.0);
+        acc_to_lds(x, Rrow + c * TSZ, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Linv[(p * TS + crow + 4 * r) * PB + c * TS + ccol] = x[r];
+      }
+    }
+    __syncthreads();
+    // ---- D: trailing updates --------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      int i, j;
+      lower_tile(4 * t + w, i, j);
+      if (j > p) C[t] = mma_nt(C[t], Pbuf + i * TSZ, Pbuf + j * TSZ, lane, -1.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      int i, c;
+      strict_tile(4 * u + w, i, c);
+      if (i > p && c <= p) R[u] = mma_nn(R[u], Pbuf + i * TSZ, (c == p) ? Dinv : Rrow + c * TSZ, lane, -1.0);
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && bad != 0 && info != nullptr) {
+    if (*info == 0) *info = info_base + bad;
+  }
+}
+
+} // namespace gpx
+
+namespace gpx {
+int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo, int info_base) {
+  static int use_tile = -1;
+  if (use_tile < 0) {
+    const char* e = getenv("GPX_POTF2");
+    use_tile = (e && e[0] == 'c') ? 0 : 1; // GPX_POTF2=column selects the column-by-column kernel
     GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)POTF2_LDS_BYTES));
-    attr_set = true;
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS_BYTES));
   }
   // algorithmic flops: factor n^3/3 + triangular inverse n^3/3
   ProfScope ps(ctx, GPX_PROF_POTF2, 2.0 * PB * (double)PB * PB / 3.0);
-  potf2_inv_kernel<<<1, 256, POTF2_LDS_BYTES, ctx->s>>>(dA, lda, dLinv, dInfo, info_base);
+  if (use_tile)
+    potf2_tile_kernel<<<1, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base);
+  else
+    potf2_inv_kernel<<<1, 256, POTF2_LDS_BYTES, ctx->s>>>(dA, lda, dLinv, dInfo, info_base);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
-
 } // namespace gpx
