@@ -22,28 +22,41 @@
 //   D: lane l, register r holds D[row = (l >> 4) + 4 r][col = l & 15].
 #include "common.h"
 
+#include <cstdlib>
+
 namespace gpx {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BK = 16;
 constexpr int LDT = BK + 1; // padded LDS row (doubles): odd => ds_read2_b64 fragment reads are conflict-free
-constexpr int TILE_DOUBLES = BM * LDT;
-constexpr size_t GEMM_LDS_BYTES = size_t(4) * TILE_DOUBLES * sizeof(double); // 2 bufs x (A,B)
 
-// TAG only gives the Cholesky trailing update (TAG = 1) its own symbol, so that rocprofv3
-// kernel statistics separate the dominant kernel from the small panel GEMMs (TAG = 0).
-template <int TAG>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
+template <int MT, int NT>
+constexpr size_t gemm_lds_bytes() {
+  return size_t(2) * (32 * MT + 32 * NT) * LDT * sizeof(double); // 2 buffers x (A tile + B tile)
+}
+
+// TAG only gives the Cholesky trailing update (TAG = 1) its own symbol, so that rocprofv3 kernel
+// statistics separate the dominant kernel from the small panel GEMMs (TAG = 0).
+// MT x NT = 16x16 MFMA tiles per wave; the workgroup (2x2 waves) covers a (32 MT) x (32 NT) tile:
+//   <4,4> 128x128  throughput shape (trailing updates, big sweeps)
+//   <2,4>  64x128  in-place panel TRSM (needs the full 128-column width in one workgroup)
+//   <2,2>  64x64   latency shape: small grids on the critical chain of the look-ahead — 4x more
+//                  workgroups, each with a 4x shorter K loop
+template <int TAG, int MT, int NT>
+__global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(GemmArgs g) {
+  constexpr int BM = 32 * MT, BN = 32 * NT;
+  constexpr int TA = BM * LDT, TB = BN * LDT;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // panel / small GEMMs sit on the critical path of the look-ahead
   const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  const int ti = g.ti_off + by, tj = g.tj_off + bx;
-  if (g.lower && tj > ti) return;
+  // element coordinates of this tile in the caller's global tile frame (offsets given in 128-tiles)
+  const int row0 = g.ti_off * 128 + by * BM, col0 = g.tj_off * 128 + bx * BN;
+  if (g.lower && col0 > row0 + BM - 1) return; // entirely above the diagonal
 
   int kb = 0, ke = g.K;
-  if (g.ktri) kb = ti * BM;
-  if (g.kupper) ke = min(ke, (tj + 1) * BN);
+  if (g.ktri) kb = row0 & ~(BK - 1);            // A rows are zero left of the diagonal (upper-triangular operand)
+  if (g.kupper) ke = min(ke, col0 + BN);        // B rows are zero right of the diagonal (lower-triangular factor)
   double* C = g.C;  // may alias A (in-place panel TRSM): no restrict here
   if (g.kchunk > 0) {
     kb = max(kb, bz * g.kchunk);
@@ -64,45 +77,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   const int64_t a_step = 32 * g.lda, b_step = 32 * g.ldb;
 
   double* sA0 = smem;
-  double* sB0 = smem + TILE_DOUBLES;
-  double* sA1 = smem + 2 * TILE_DOUBLES;
-  double* sB1 = smem + 3 * TILE_DOUBLES;
+  double* sB0 = smem + TA;
+  double* sA1 = smem + TA + TB;
+  double* sB1 = smem + 2 * TA + TB;
 
-  d4_t acc[4][4];
+  d4_t acc[MT][NT];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int n = 0; n < NT; ++n) acc[m][n] = d4_t{0.0, 0.0, 0.0, 0.0};
 
-  const int a_frag_off = (wr * 64 + fr) * LDT + fk;
-  const int b_frag_off = (wc * 64 + fr) * LDT + fk;
+  const int a_frag_off = (wr * 16 * MT + fr) * LDT + fk;
+  const int b_frag_off = (wc * 16 * NT + fr) * LDT + fk;
   const int st_off = lr * LDT + lc;
 
   if (nk > 0) {
-    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define GPX_LOAD_TILE(koff)                                                \
-  ra0 = *reinterpret_cast<const double2*>(Ap + (koff));                    \
-  ra1 = *reinterpret_cast<const double2*>(Ap + a_step + (koff));           \
-  ra2 = *reinterpret_cast<const double2*>(Ap + 2 * a_step + (koff));       \
-  ra3 = *reinterpret_cast<const double2*>(Ap + 3 * a_step + (koff));       \
-  rb0 = *reinterpret_cast<const double2*>(Bp + (koff));                    \
-  rb1 = *reinterpret_cast<const double2*>(Bp + b_step + (koff));           \
-  rb2 = *reinterpret_cast<const double2*>(Bp + 2 * b_step + (koff));       \
-  rb3 = *reinterpret_cast<const double2*>(Bp + 3 * b_step + (koff));
-#define GPX_ST2(p, v)  \
-  (p)[0] = (v).x;      \
-  (p)[1] = (v).y;
-#define GPX_STORE_TILE(dA, dB)                 \
-  GPX_ST2((dA) + st_off, ra0)                  \
-  GPX_ST2((dA) + st_off + 32 * LDT, ra1)       \
-  GPX_ST2((dA) + st_off + 64 * LDT, ra2)       \
-  GPX_ST2((dA) + st_off + 96 * LDT, ra3)       \
-  GPX_ST2((dB) + st_off, rb0)                  \
-  GPX_ST2((dB) + st_off + 32 * LDT, rb1)       \
-  GPX_ST2((dB) + st_off + 64 * LDT, rb2)       \
-  GPX_ST2((dB) + st_off + 96 * LDT, rb3)
-    GPX_LOAD_TILE(0)
-    GPX_STORE_TILE(sA0, sB0)
+    double2 ra[MT], rb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ra[i] = *reinterpret_cast<const double2*>(Ap + i * a_step);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) rb[i] = *reinterpret_cast<const double2*>(Bp + i * b_step);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      sA0[st_off + 32 * i * LDT] = ra[i].x;
+      sA0[st_off + 32 * i * LDT + 1] = ra[i].y;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      sB0[st_off + 32 * i * LDT] = rb[i].x;
+      sB0[st_off + 32 * i * LDT + 1] = rb[i].y;
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       const double* cA = (kt & 1) ? sA1 : sA0;
@@ -111,80 +115,105 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
       double* nB = (kt & 1) ? sB0 : sB1;
       // prefetch the next k-tile (the last iteration re-reads its own tile: in bounds, unused)
       const int koff = ((kt + 1 < nk) ? (kt + 1) : kt) * BK;
-      GPX_LOAD_TILE(koff)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) ra[i] = *reinterpret_cast<const double2*>(Ap + i * a_step + koff);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) rb[i] = *reinterpret_cast<const double2*>(Bp + i * b_step + koff);
 #pragma unroll
       for (int kk = 0; kk < BK / 4; ++kk) {
-        double af[4], bf[4];
+        double af[MT], bf[NT];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) af[m] = cA[a_frag_off + m * 16 * LDT + kk * 4];
+        for (int m = 0; m < MT; ++m) af[m] = cA[a_frag_off + m * 16 * LDT + kk * 4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) bf[n] = cB[b_frag_off + n * 16 * LDT + kk * 4];
+        for (int n = 0; n < NT; ++n) bf[n] = cB[b_frag_off + n * 16 * LDT + kk * 4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < 4; ++n)
+          for (int n = 0; n < NT; ++n)
             acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0); // keep the LDS refill (and its vmcnt wait) behind the MFMAs
-      GPX_STORE_TILE(nA, nB)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        nA[st_off + 32 * i * LDT] = ra[i].x;
+        nA[st_off + 32 * i * LDT + 1] = ra[i].y;
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        nB[st_off + 32 * i * LDT] = rb[i].x;
+        nB[st_off + 32 * i * LDT + 1] = rb[i].y;
+      }
       __syncthreads();
     }
-#undef GPX_LOAD_TILE
-#undef GPX_STORE_TILE
-#undef GPX_ST2
   }
 
   // epilogue: D[row = (lane >> 4) + 4 r][col = lane & 15] per 16x16 accumulator.  A wave
   // store covers 4 rows x 16 contiguous doubles (full 128-B lines).  The beta path batches the
-  // 16 C loads of one accumulator row-block ahead of their use (one latency, not sixteen).
+  // C loads of one accumulator row-block ahead of their use (one latency, not sixteen).
   const double alpha = g.alpha, beta = g.beta;
-  double* Cw = C + ((int64_t)by * BM + wr * 64 + fk) * g.ldc + (int64_t)bx * BN + wc * 64 + fr;
+  double* Cw = C + ((int64_t)by * BM + wr * 16 * MT + fk) * g.ldc + (int64_t)bx * BN + wc * 16 * NT + fr;
   if (beta != 0.0) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      double cv[4][4];
+    for (int m = 0; m < MT; ++m) {
+      double cv[4][NT];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) cv[r][n] = Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16];
+        for (int n = 0; n < NT; ++n) cv[r][n] = Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NT; ++n)
           Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = fma(beta, cv[r][n], alpha * acc[m][n][r]);
     }
   } else {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NT; ++n)
           Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = alpha * acc[m][n][r];
   }
+}
+
+template <int TAG, int MT, int NT>
+static int launch_variant(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits) {
+  static bool attr_set = false;
+  constexpr size_t lds = gemm_lds_bytes<MT, NT>();
+  if (!attr_set) {
+    GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<TAG, MT, NT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  // tiles_m / tiles_n are given in 128-tiles
+  dim3 grid(tiles_n * (4 / NT), tiles_m * (4 / MT), splits > 0 ? splits : 1);
+  gemm_nt_kernel<TAG, MT, NT><<<grid, 256, lds, ctx->s>>>(g);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
 }
 
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
                    int prof_cls, double work) {
   if (tiles_m <= 0 || tiles_n <= 0) return 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<0>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)GEMM_LDS_BYTES));
-    GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)GEMM_LDS_BYTES));
-    attr_set = true;
-  }
-  dim3 grid(tiles_n, tiles_m, splits > 0 ? splits : 1);
   ProfScope ps(ctx, prof_cls, work);
-  if (prof_cls == GPX_PROF_GEMM_TRAILING)
-    gemm_nt_kernel<1><<<grid, 256, GEMM_LDS_BYTES, ctx->s>>>(g);
-  else
-    gemm_nt_kernel<0><<<grid, 256, GEMM_LDS_BYTES, ctx->s>>>(g);
-  GPX_HIP(ctx, hipGetLastError());
-  return 0;
+  if (prof_cls == GPX_PROF_GEMM_TRAILING) return launch_variant<1, 4, 4>(ctx, g, tiles_m, tiles_n, splits);
+  // latency-bound launches (too few 128x128 tiles to fill 256 CUs x 2): smaller workgroup tiles
+  const int nsplit = splits > 0 ? splits : 1;
+  const double tiles = (double)tiles_m * tiles_n * nsplit * (g.lower ? 0.55 : 1.0);
+  static int small_ok = -1;
+  if (small_ok < 0) {
+    const char* e = getenv("GPX_GEMM_SMALL");
+    small_ok = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (small_ok && tiles < 400.0) {
+    if (g.C == g.A) { // in-place (panel TRSM): one workgroup must own the whole row width
+      if (tiles_n == 1) return launch_variant<0, 2, 4>(ctx, g, tiles_m, tiles_n, splits);
+    } else {
+      return launch_variant<0, 2, 2>(ctx, g, tiles_m, tiles_n, splits);
+    }
+  }
+  return launch_variant<0, 4, 4>(ctx, g, tiles_m, tiles_n, splits);
 }
 
 // ---- raw MFMA issue-rate microbenchmark ----------------------------------------------------
