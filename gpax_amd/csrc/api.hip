@@ -701,7 +701,7 @@ int gpx_gemm_nt(gpx_ctx* ctx, int M, int N, int K, double alpha, const double* A
   if (!ctx || ctx->device < 0) return -1;
   if (M < 1 || N < 1 || K < 1 || !A || !B || !C) return bad_arg(ctx, "gemm arguments");
   GPX_HIP(ctx, hipSetDevice(ctx->device));
-  const int Mp = round_up(M, TILE), Np = round_up(N, TILE), Kp = round_up(K, 16);
+  const int Mp = round_up(M, TILE), Np = round_up(N, TILE), Kp = round_up(K, 32);
   const int64_t lda = pick_ld(Kp), ldc = pick_ld(Np);
   GPX_TRY(ensure(ctx, ctx->tA, (size_t)Mp * lda * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->tB, (size_t)Np * lda * sizeof(double)));

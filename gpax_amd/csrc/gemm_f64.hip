@@ -28,12 +28,10 @@ namespace gpx {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 16;
-constexpr int LDT = BK + 1; // padded LDS row (doubles): odd => ds_read2_b64 fragment reads are conflict-free
 
-template <int MT, int NT>
+template <int MT, int NT, int BK, bool DBUF>
 constexpr size_t gemm_lds_bytes() {
-  return size_t(2) * (32 * MT + 32 * NT) * LDT * sizeof(double); // 2 buffers x (A tile + B tile)
+  return size_t(DBUF ? 2 : 1) * (32 * MT + 32 * NT) * (BK + 1) * sizeof(double); // buffers x (A tile + B tile)
 }
 
 // TAG only gives the Cholesky trailing update (TAG = 1) its own symbol, so that rocprofv3 kernel
@@ -43,10 +41,18 @@ constexpr size_t gemm_lds_bytes() {
 //   <2,4>  64x128  in-place panel TRSM (needs the full 128-column width in one workgroup)
 //   <2,2>  64x64   latency shape: small grids on the critical chain of the look-ahead — 4x more
 //                  workgroups, each with a 4x shorter K loop
-template <int TAG, int MT, int NT>
+// BK = k-step: 16 for the throughput shape; 32 for the latency shapes (their k-step time is one
+// global-load latency + barrier, not MFMA time, so fewer and fatter k-steps cut the launch latency).
+// LDS rows are padded to BK + 1 doubles (odd => ds_read2_b64 fragment reads are conflict-free).
+// DBUF = false: single LDS buffer (two barriers per k-step) — 17 KB for the 64x64 shape, which fits
+// in the LDS two resident trailing-update workgroups leave free, so a chain launch is placed at once.
+template <int TAG, int MT, int NT, int BK, bool DBUF>
 __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(GemmArgs g) {
-  constexpr int BM = 32 * MT, BN = 32 * NT;
+  constexpr int BM = 32 * MT, BN = 32 * NT, LDT = BK + 1;
   constexpr int TA = BM * LDT, TB = BN * LDT;
+  constexpr int TPR = BK / 2;    // threads per staged row (one double2 each)
+  constexpr int RPP = 256 / TPR; // rows staged per pass
+  constexpr int PA = BM / RPP, PB_ = BN / RPP;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // panel / small GEMMs sit on the critical path of the look-ahead
   const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -70,16 +76,16 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
   const int wr = wave >> 1, wc = wave & 1;
   const int fr = lane & 15, fk = lane >> 4;
 
-  // staging map: thread -> (row lr + 32 i, cols lc, lc + 1)
-  const int lr = tid >> 3, lc = (tid & 7) * 2;
+  // staging map: thread -> (row lr + RPP i, cols lc, lc + 1)
+  const int lr = tid / TPR, lc = (tid % TPR) * 2;
   const double* Ap = g.A + ((int64_t)by * BM + lr) * g.lda + kb + lc;
   const double* Bp = g.B + ((int64_t)bx * BN + lr) * g.ldb + kb + lc;
-  const int64_t a_step = 32 * g.lda, b_step = 32 * g.ldb;
+  const int64_t a_step = (int64_t)RPP * g.lda, b_step = (int64_t)RPP * g.ldb;
 
   double* sA0 = smem;
   double* sB0 = smem + TA;
-  double* sA1 = smem + TA + TB;
-  double* sB1 = smem + 2 * TA + TB;
+  double* sA1 = DBUF ? smem + TA + TB : sA0;
+  double* sB1 = DBUF ? smem + 2 * TA + TB : sB0;
 
   d4_t acc[MT][NT];
 #pragma unroll
@@ -92,20 +98,20 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
   const int st_off = lr * LDT + lc;
 
   if (nk > 0) {
-    double2 ra[MT], rb[NT];
+    double2 ra[PA], rb[PB_];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) ra[i] = *reinterpret_cast<const double2*>(Ap + i * a_step);
+    for (int i = 0; i < PA; ++i) ra[i] = *reinterpret_cast<const double2*>(Ap + i * a_step);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) rb[i] = *reinterpret_cast<const double2*>(Bp + i * b_step);
+    for (int i = 0; i < PB_; ++i) rb[i] = *reinterpret_cast<const double2*>(Bp + i * b_step);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      sA0[st_off + 32 * i * LDT] = ra[i].x;
-      sA0[st_off + 32 * i * LDT + 1] = ra[i].y;
+    for (int i = 0; i < PA; ++i) {
+      sA0[st_off + RPP * i * LDT] = ra[i].x;
+      sA0[st_off + RPP * i * LDT + 1] = ra[i].y;
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      sB0[st_off + 32 * i * LDT] = rb[i].x;
-      sB0[st_off + 32 * i * LDT + 1] = rb[i].y;
+    for (int i = 0; i < PB_; ++i) {
+      sB0[st_off + RPP * i * LDT] = rb[i].x;
+      sB0[st_off + RPP * i * LDT + 1] = rb[i].y;
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -116,9 +122,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
       // prefetch the next k-tile (the last iteration re-reads its own tile: in bounds, unused)
       const int koff = ((kt + 1 < nk) ? (kt + 1) : kt) * BK;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) ra[i] = *reinterpret_cast<const double2*>(Ap + i * a_step + koff);
+      for (int i = 0; i < PA; ++i) ra[i] = *reinterpret_cast<const double2*>(Ap + i * a_step + koff);
 #pragma unroll
-      for (int i = 0; i < NT; ++i) rb[i] = *reinterpret_cast<const double2*>(Bp + i * b_step + koff);
+      for (int i = 0; i < PB_; ++i) rb[i] = *reinterpret_cast<const double2*>(Bp + i * b_step + koff);
 #pragma unroll
       for (int kk = 0; kk < BK / 4; ++kk) {
         double af[MT], bf[NT];
@@ -133,15 +139,16 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
             acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0); // keep the LDS refill (and its vmcnt wait) behind the MFMAs
+      if (!DBUF) __syncthreads();          // single buffer: every wave is done reading before the refill
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        nA[st_off + 32 * i * LDT] = ra[i].x;
-        nA[st_off + 32 * i * LDT + 1] = ra[i].y;
+      for (int i = 0; i < PA; ++i) {
+        nA[st_off + RPP * i * LDT] = ra[i].x;
+        nA[st_off + RPP * i * LDT + 1] = ra[i].y;
       }
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        nB[st_off + 32 * i * LDT] = rb[i].x;
-        nB[st_off + 32 * i * LDT + 1] = rb[i].y;
+      for (int i = 0; i < PB_; ++i) {
+        nB[st_off + RPP * i * LDT] = rb[i].x;
+        nB[st_off + RPP * i * LDT + 1] = rb[i].y;
       }
       __syncthreads();
     }
@@ -177,18 +184,18 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
   }
 }
 
-template <int TAG, int MT, int NT>
+template <int TAG, int MT, int NT, int BK, bool DBUF>
 static int launch_variant(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits) {
   static bool attr_set = false;
-  constexpr size_t lds = gemm_lds_bytes<MT, NT>();
+  constexpr size_t lds = gemm_lds_bytes<MT, NT, BK, DBUF>();
   if (!attr_set) {
-    GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<TAG, MT, NT>),
+    GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<TAG, MT, NT, BK, DBUF>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   // tiles_m / tiles_n are given in 128-tiles
   dim3 grid(tiles_n * (4 / NT), tiles_m * (4 / MT), splits > 0 ? splits : 1);
-  gemm_nt_kernel<TAG, MT, NT><<<grid, 256, lds, ctx->s>>>(g);
+  gemm_nt_kernel<TAG, MT, NT, BK, DBUF><<<grid, 256, lds, ctx->s>>>(g);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -197,7 +204,7 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
                    int prof_cls, double work) {
   if (tiles_m <= 0 || tiles_n <= 0) return 0;
   ProfScope ps(ctx, prof_cls, work);
-  if (prof_cls == GPX_PROF_GEMM_TRAILING) return launch_variant<1, 4, 4>(ctx, g, tiles_m, tiles_n, splits);
+  if (prof_cls == GPX_PROF_GEMM_TRAILING) return launch_variant<1, 4, 4, 16, true>(ctx, g, tiles_m, tiles_n, splits);
   // latency-bound launches (too few 128x128 tiles to fill 256 CUs x 2): smaller workgroup tiles
   const int nsplit = splits > 0 ? splits : 1;
   const double tiles = (double)tiles_m * tiles_n * nsplit * (g.lower ? 0.55 : 1.0);
@@ -208,12 +215,12 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   }
   if (small_ok && tiles < 400.0) {
     if (g.C == g.A) { // in-place (panel TRSM): one workgroup must own the whole row width
-      if (tiles_n == 1) return launch_variant<0, 2, 4>(ctx, g, tiles_m, tiles_n, splits);
+      if (tiles_n == 1) return launch_variant<0, 2, 4, 16, true>(ctx, g, tiles_m, tiles_n, splits);
     } else {
-      return launch_variant<0, 2, 2>(ctx, g, tiles_m, tiles_n, splits);
+      return launch_variant<0, 2, 2, 16, false>(ctx, g, tiles_m, tiles_n, splits);
     }
   }
-  return launch_variant<0, 4, 4>(ctx, g, tiles_m, tiles_n, splits);
+  return launch_variant<0, 4, 4, 16, true>(ctx, g, tiles_m, tiles_n, splits);
 }
 
 // ---- raw MFMA issue-rate microbenchmark ----------------------------------------------------
