@@ -28,7 +28,7 @@ def main():
     # the dominant kernel has its own symbol: gpx::gemm_nt_kernel<1> (Cholesky trailing SYRK)
     try:
         rows = cur.execute("select counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection "
-                           "where kernel_name like '%gemm_nt_kernel<1>%' group by counter_name").fetchall()
+                           "where kernel_name like '%gemm_nt_kernel<1,%' group by counter_name").fetchall()
     except Exception:
         rows = []
     for cname, n, tot, avg, dur in rows:
