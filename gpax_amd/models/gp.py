@@ -333,8 +333,14 @@ class ExactGP:
         else:
             yres = self.y_train
         eps = rng_from_key(rng_key).standard_normal((S, n, M))
-        means, y_sampled, infos = self._engine().predict_sweep(self._kind, ells, scales, noises, yres, X_new,
-                                                               noiseless, jitter, eps)
+        # several samples in flight per GPU: independent libgpx contexts on the same device
+        engines = _lib.get_sweep_engines(self._device)
+        for e in engines[1:]:
+            e._train_owner = None
+        if len(engines) > 1:
+            engines[0]._train_owner = None
+        means, y_sampled, infos = _lib.concurrent_sweep(engines, self.X_train, self._kind, ells, scales, noises, yres,
+                                                        X_new, noiseless, jitter, eps)
         if mean_shift is not None:
             means = means + mean_shift
             y_sampled = y_sampled + mean_shift[:, None, :]

@@ -83,8 +83,8 @@ class Communicator:
 
 def predict_sharded(engine, kind: int, X, yres, Xnew, samples: Optional[Dict[str, np.ndarray]], eps,
                     noiseless: bool, jitter: float, comm: Communicator):
-    """The S-sample predictive sweep, sharded over comm.world ranks.  Inputs need only be valid
-    on rank 0.  Returns (means (S, M), y_sampled (S, n, M), infos (S,)) on rank 0, None elsewhere."""
+    """The S-sample predictive sweep, sharded over comm.world ranks (`engine`: one Engine or a list of
+    contexts on this rank's GPU, see _lib.get_sweep_engines).  Inputs need only be valid on rank 0.  Returns (means (S, M), y_sampled (S, n, M), infos (S,)) on rank 0, None elsewhere."""
     X = comm.bcast(X)
     yres = comm.bcast(yres)
     Xnew = comm.bcast(Xnew)
@@ -96,11 +96,13 @@ def predict_sharded(engine, kind: int, X, yres, Xnew, samples: Optional[Dict[str
     lo, hi = shard_range(S, comm.rank, comm.world)
     counts = [shard_range(S, r, comm.world)[1] - shard_range(S, r, comm.world)[0] for r in range(comm.world)]
     M, n = Xnew.shape[0], eps.shape[1]
-    engine.set_train(X)
     if hi > lo:
+        from ._lib import concurrent_sweep
+
+        engines = engine if isinstance(engine, (list, tuple)) else [engine]
         yr = yres if yres.ndim == 1 else yres[lo:hi]
-        means, draws, infos = engine.predict_sweep(kind, ells[lo:hi].reshape(hi - lo, -1), scales[lo:hi],
-                                                   noises[lo:hi], yr, Xnew, noiseless, jitter, eps[lo:hi])
+        means, draws, infos = concurrent_sweep(list(engines), X, kind, ells[lo:hi].reshape(hi - lo, -1), scales[lo:hi],
+                                               noises[lo:hi], yr, Xnew, noiseless, jitter, eps[lo:hi])
     else:
         means, draws, infos = np.empty((0, M)), np.empty((0, n, M)), np.empty((0,), dtype=np.int32)
     means = comm.gather_rows(means, counts)
