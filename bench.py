@@ -111,7 +111,7 @@ def main():
     # Several theta samples in flight per GPU: independent libgpx contexts on the same device fill the
     # latency-bound tail of one sample's pipeline with the GEMM-heavy head of another.
     import threading
-    n_fl = max(1, min(a.inflight, K))
+    n_fl = max(1, min(a.inflight, K // 2))  # at least two steps per context
     engines = [eng] + [_lib.Engine(local_rank) for _ in range(n_fl - 1)]
     # resident state: X, yres, Xnew, eps on the device before the timed region
     for e in engines:
