@@ -132,11 +132,13 @@ class ExactGP:
             off += s.size
         return theta
 
-    def _log_joint(self, sites, u, jitter: float, jacobian: bool, want_grad: bool = True):
+    def _log_joint(self, sites, u, jitter: float, jacobian: bool, want_grad: bool = True, eng=None):
         """log p(y | theta) + log p(theta) [+ log |dtheta/du|] at theta = T(u) and its gradient
-        w.r.t. u.  Returns (value, grad) — (-inf, zeros) when K(theta) is not positive definite."""
+        w.r.t. u.  Returns (value, grad) — (-inf, zeros) when K(theta) is not positive definite.
+        `eng`: a libgpx context that already holds X_train (parallel chains); default: the shared one."""
         theta = self._unpack(sites, u)
-        eng = self._engine()
+        if eng is None:
+            eng = self._engine()
         yres = self.y_train - self._mean(self.X_train, theta)
         lml, info = eng.factor(self._kind, theta["k_length"], theta["k_scale"], theta["noise"], jitter, yres)
         if info != 0 or not np.isfinite(lml):
@@ -206,23 +208,58 @@ class ExactGP:
         jitter = float(kwargs.get("jitter", 1e-6))
         rng = rng_from_key(rng_key)
         sites = self._sites()
+        # one independent generator per chain (children of the key): chains do not depend on how they are
+        # scheduled.  chain_method 'parallel' / 'vectorized' run the chains concurrently, each on its own
+        # libgpx context on this GPU (the reference pmaps / vmaps them, gp.py:173-174,214); 'sequential'
+        # runs them one after the other on the shared context.
+        chain_rngs = [rng] if num_chains == 1 else [np.random.default_rng(sd) for sd in rng.integers(0, 2 ** 63, num_chains)]
+        concurrent = chain_method != "sequential" and num_chains > 1
+        engines = _lib.get_sweep_engines(self._device, n=num_chains) if concurrent else [None]
+        if concurrent and len(engines) > 1:
+            for e in engines:
+                e.set_train(self.X_train)
+                e._train_owner = None
+        else:
+            concurrent = False
+        results = [None] * num_chains
+        errors = []
 
-        def potential(u):
-            v, g = self._log_joint(sites, u, jitter, jacobian=True)
-            return (-v, -g) if np.isfinite(v) else (np.inf, np.zeros_like(u))
+        def run_chain(c, eng):
+            try:
+                crng = chain_rngs[c]
 
-        chains, stats = [], []
-        for c in range(num_chains):
-            u0 = None
-            for _ in range(100):  # like NumPyro: redraw until the initial potential is finite
-                u0 = self._init_unconstrained(sites, rng)
-                if np.isfinite(potential(u0)[0]):
-                    break
-            prog = _Progress(progress_bar, f"chain {c + 1}/{num_chains}" if num_chains > 1 else "sample")
-            res = run_nuts(potential, u0, num_warmup, num_samples, rng, progress=prog)
-            prog.close()
-            chains.append(res["draws"])
-            stats.append({k: v for k, v in res.items() if k != "draws"})
+                def potential(u):
+                    v, g = self._log_joint(sites, u, jitter, jacobian=True, eng=eng)
+                    return (-v, -g) if np.isfinite(v) else (np.inf, np.zeros_like(u))
+
+                u0 = None
+                for _ in range(100):  # like NumPyro: redraw until the initial potential is finite
+                    u0 = self._init_unconstrained(sites, crng)
+                    if np.isfinite(potential(u0)[0]):
+                        break
+                prog = _Progress(progress_bar and (not concurrent or c == 0),
+                                 f"chain {c + 1}/{num_chains}" if num_chains > 1 else "sample")
+                results[c] = run_nuts(potential, u0, num_warmup, num_samples, crng, progress=prog)
+                prog.close()
+            except Exception as ex:
+                errors.append(ex)
+
+        if concurrent:
+            import threading
+            waves = [list(range(i, min(i + len(engines), num_chains))) for i in range(0, num_chains, len(engines))]
+            for wave in waves:
+                ts = [threading.Thread(target=run_chain, args=(c, engines[k])) for k, c in enumerate(wave)]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+        else:
+            for c in range(num_chains):
+                run_chain(c, None)
+        if errors:
+            raise errors[0]
+        chains = [r["draws"] for r in results]
+        stats = [{k: v for k, v in r.items() if k != "draws"} for r in results]
         draws = np.stack(chains)  # (chains, S, dim)
         samples = {}
         off = 0

@@ -117,3 +117,19 @@ def test_visparsegp_on_gpu(guide):
         assert m.loss[-1] < m.loss[0]
         rmse = np.sqrt(np.mean((mean - img.reshape(-1)) ** 2))
         assert rmse < 0.25
+
+
+def test_parallel_chains_on_gpu_match_sequential():
+    import time
+    X, y, _, _ = ref.synthetic_problem(256, 1, 4, seed=1)
+    out, dt = [], []
+    for method in ["sequential", "parallel"]:
+        m = ExactGP(1, "RBF")
+        t0 = time.perf_counter()
+        m.fit(get_keys()[0], X, y, num_warmup=30, num_samples=30, num_chains=3, chain_method=method,
+              progress_bar=False, print_summary=False)
+        dt.append(time.perf_counter() - t0)
+        out.append(m.get_samples(chain_dim=True))
+    for k in out[0]:
+        np.testing.assert_array_equal(out[0][k], out[1][k])  # own generator per chain, own context per chain
+    print(f"3 chains N=256: sequential {dt[0]:.2f} s, parallel {dt[1]:.2f} s")

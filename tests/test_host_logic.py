@@ -253,3 +253,16 @@ def test_visparsegp_fit_predict(guide):
     np.testing.assert_allclose(mb, mean, rtol=1e-10)
     if guide == "delta":
         assert np.nanmin(m2.loss[-5:]) < m2.loss[0]
+
+
+def test_parallel_chains_equal_sequential_chains():
+    # chains own independent generators, so the schedule does not change the draws
+    X, y = get_dummy_data()
+    outs = []
+    for method in ["sequential", "parallel"]:
+        m = ExactGP(1, "RBF")
+        m.fit(get_keys()[0], X, y, num_warmup=15, num_samples=15, num_chains=2, chain_method=method,
+              progress_bar=False, print_summary=False)
+        outs.append(m.get_samples(chain_dim=True)["k_length"])
+    assert outs[0].shape == (2, 15, 1)
+    np.testing.assert_array_equal(outs[0], outs[1])
