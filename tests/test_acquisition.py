@@ -1,0 +1,82 @@
+"""CPU: acquisition functions (SURVEY §8f "next" row 1) against scipy.stats closed forms and the reference's
+own test expectations (gpax/tests/test_acq.py: shapes, penalties, argument validation)."""
+import numpy as np
+import pytest
+from scipy.stats import norm
+
+from gpax_amd import _lib
+from gpax_amd.acquisition import EI, POI, UCB, UE, Thompson, compute_penalty, ei, poi, ucb, ue
+from gpax_amd.models import ExactGP, viGP
+from gpax_amd.utils import get_keys
+from oracle import cpu_ref as ref
+from tests.oracle_engine import OracleEngine
+
+
+@pytest.fixture(autouse=True)
+def oracle_engine():
+    _lib.set_engine(OracleEngine())
+    yield
+    _lib.set_engine(None)
+
+
+def test_base_functions_closed_forms():
+    rng = np.random.default_rng(0)
+    mean, var = rng.standard_normal(50), rng.uniform(0.1, 2.0, 50)
+    s = np.sqrt(var)
+    for maximize in [False, True]:
+        best = mean.max() if maximize else mean.min()
+        u = (mean - best) / s * (1 if maximize else -1)
+        np.testing.assert_allclose(ei((mean, var), maximize=maximize), s * (norm.pdf(u) + u * norm.cdf(u)), rtol=1e-12)
+        u2 = (mean - best - 0.01) / s * (1 if maximize else -1)
+        np.testing.assert_allclose(poi((mean, var), maximize=maximize), norm.cdf(u2), rtol=1e-12)
+    np.testing.assert_allclose(ucb((mean, var), beta=0.5, maximize=True), mean + np.sqrt(0.5 * var))
+    np.testing.assert_allclose(ucb((mean, var), beta=0.5, maximize=False), -(mean - np.sqrt(0.5 * var)))
+    np.testing.assert_allclose(ue((mean, var)), s)
+    np.testing.assert_allclose(ei((mean, var), best_f=0.3), ei((mean, var), best_f=0.3, maximize=False))
+
+
+def test_penalties():
+    X = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 2.0]])
+    recent = np.array([[1.0, 0.0]])
+    np.testing.assert_array_equal(compute_penalty(X, recent, "delta"), [0.0, np.inf, 0.0])
+    p = compute_penalty(X, recent, "inverse_distance", 2.0)
+    np.testing.assert_allclose(p, 2.0 / (np.linalg.norm(X - recent, axis=1) + 1))
+    recent2 = np.array([[0.0, 0.0], [2.0, 2.0]])  # [older, newer]: ages 3, 2
+    p2 = compute_penalty(X, recent2, "inverse_distance")
+    d = np.stack([np.linalg.norm(X - r, axis=1) for r in recent2], 1)
+    np.testing.assert_allclose(p2, (1 / (d + 1) / np.array([3, 2])).sum(1))
+    with pytest.raises(NotImplementedError):
+        compute_penalty(X, recent, "bogus")
+
+
+@pytest.mark.parametrize("acq", [EI, UCB, POI, UE])
+def test_wrappers_with_mcmc_and_vi_models(acq):
+    X, y, Xn, _ = ref.synthetic_problem(20, 1, 9, seed=2)
+    m = ExactGP(1, "RBF")
+    m.fit(get_keys()[0], X, y, num_warmup=15, num_samples=15, progress_bar=False, print_summary=False)
+    a = acq(get_keys()[1], m, Xn[:, 0], n=2)
+    assert a.shape == (9,) and np.isfinite(a).all()
+    v = viGP(1, "Matern")
+    v.fit(get_keys()[0], X, y, num_steps=20, progress_bar=False, print_summary=False)
+    a2 = acq(get_keys()[1], v, Xn)
+    assert a2.shape == (9,) and np.isfinite(a2).all()
+    mean, var = v.predict(get_keys()[1], Xn)
+    if acq is UE:
+        np.testing.assert_allclose(a2, np.sqrt(var))
+    with pytest.raises(ValueError):
+        acq(get_keys()[1], v, Xn, penalty="delta")
+    pen = acq(get_keys()[1], v, Xn, penalty="delta", recent_points=Xn[2:3])
+    assert np.isneginf(pen[2]) and np.all(np.isfinite(np.delete(pen, 2)))
+    pen2 = acq(get_keys()[1], v, Xn, penalty="inverse_distance", recent_points=Xn[2:4], penalty_factor=0.5)
+    assert np.all(pen2 < a2)
+
+
+def test_thompson_shapes():
+    X, y, Xn, _ = ref.synthetic_problem(20, 1, 9, seed=2)
+    m = ExactGP(1, "RBF")
+    m.fit(get_keys()[0], X, y, num_warmup=15, num_samples=15, progress_bar=False, print_summary=False)
+    t = Thompson(get_keys()[1], m, Xn)
+    assert np.asarray(t).reshape(-1).shape == (9,)
+    v = viGP(1, "RBF")
+    v.fit(get_keys()[0], X, y, num_steps=10, progress_bar=False, print_summary=False)
+    assert Thompson(get_keys()[1], v, Xn, noiseless=False).shape == (1, 9)
