@@ -13,7 +13,8 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-KERNEL_KINDS = {"RBF": 0, "Matern": 1}
+KERNEL_KINDS = {"RBF": 0, "Matern": 1, "Periodic": 2}
+KIND_PERIODIC = 2
 MAX_DIM = 16
 
 PROF_GEMM_TRAILING, PROF_GEMM_OTHER, PROF_POTF2, PROF_GRAM = 0, 1, 2, 3
@@ -121,6 +122,24 @@ def broadcast_lengthscale(k_length, d: int) -> np.ndarray:
     return np.ascontiguousarray(ell)
 
 
+def pack_ell(kind: int, k_length, d: int, period=None) -> np.ndarray:
+    """The `ell` argument of the C-ABI: d lengthscales, followed by the period for the periodic
+    kernel (include/gpx.h GPX_KERNEL_PERIODIC).  An already packed (d + 1,) array passes through."""
+    if kind != KIND_PERIODIC:
+        return broadcast_lengthscale(k_length, d)
+    arr = np.asarray(k_length, dtype=np.float64).reshape(-1)
+    if period is None:
+        if arr.size != d + 1:
+            raise ValueError("the periodic kernel needs `period` (or a packed k_length of d + 1 values)")
+        return np.ascontiguousarray(arr)
+    per = float(np.asarray(period, dtype=np.float64).reshape(-1)[0])
+    return np.ascontiguousarray(np.concatenate([broadcast_lengthscale(arr, d), [per]]))
+
+
+def n_ell(kind: int, d: int) -> int:
+    return d + (1 if kind == KIND_PERIODIC else 0)
+
+
 class Engine:
     """One libgpx context = one GPU.  Thin, stateful mirror of the C-ABI."""
 
@@ -172,7 +191,7 @@ class Engine:
         Z = _f64(Z)
         n, d = X.shape
         m = Z.shape[0]
-        ell = broadcast_lengthscale(ell, d)
+        ell = pack_ell(kind, ell, d)
         out = np.empty((n, m), dtype=np.float64)
         self._check(self._lib.gpx_gram(self._ctx, kind, _ptr(X), n, _ptr(Z), m, d, _ptr(ell), float(scale),
                                        float(diag_add), int(bool(add_diag)), _ptr(out)), "gpx_gram")
@@ -185,7 +204,8 @@ class Engine:
         self._check(self._lib.gpx_set_train(self._ctx, _ptr(X), self.N, self.d), "gpx_set_train")
 
     def factor(self, kind: int, ell, scale: float, noise: float, jitter: float, yres) -> Tuple[float, int]:
-        ell = broadcast_lengthscale(ell, self.d)
+        ell = pack_ell(kind, ell, self.d)
+        self._last_kind = kind
         yres = _f64(yres, (self.N,))
         lml, info = C.c_double(), C.c_int()
         self._check(self._lib.gpx_factor(self._ctx, kind, _ptr(ell), float(scale), float(noise), float(jitter),
@@ -193,7 +213,7 @@ class Engine:
         return lml.value, info.value
 
     def lml_grad(self):
-        g_ell = np.empty(self.d)
+        g_ell = np.empty(n_ell(getattr(self, '_last_kind', 0), self.d))
         g_scale, g_noise = C.c_double(), C.c_double()
         alpha = np.empty(self.N)
         self._check(self._lib.gpx_lml_grad(self._ctx, _ptr(g_ell), C.byref(g_scale), C.byref(g_noise),
@@ -223,7 +243,7 @@ class Engine:
                       eps: Optional[np.ndarray]):
         ells = _f64(ells)
         S = ells.shape[0]
-        ells = _f64(ells, (S, self.d))
+        ells = _f64(ells, (S, n_ell(kind, self.d)))
         scales = _f64(scales, (S,))
         noises = _f64(noises, (S,))
         yres = _f64(yres)
@@ -303,7 +323,7 @@ class Engine:
     def sweep_resident(self, kind: int, ells, scales, noises, noiseless: bool, jitter: float, n_draws: int) -> float:
         ells = _f64(ells)
         S = ells.shape[0]
-        ells = _f64(ells, (S, self.d))
+        ells = _f64(ells, (S, n_ell(kind, self.d)))
         scales = _f64(scales, (S,))
         noises = _f64(noises, (S,))
         ms = C.c_double()

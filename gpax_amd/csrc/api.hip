@@ -21,17 +21,19 @@ int ensure(gpx_ctx* ctx, DevBuf& b, size_t bytes) {
 }
 
 int set_theta(gpx_ctx* ctx, int kind, int d, const double* ell, double scale) {
-  if (kind != GPX_KERNEL_RBF && kind != GPX_KERNEL_MATERN52) return bad_arg(ctx, "kernel kind");
+  if (kind != GPX_KERNEL_RBF && kind != GPX_KERNEL_MATERN52 && kind != GPX_KERNEL_PERIODIC)
+    return bad_arg(ctx, "kernel kind");
   if (d < 1 || d > GPX_MAX_DIM) return bad_arg(ctx, "input dimension must be 1..16");
   ctx->theta.kind = kind;
   ctx->theta.d = d;
   for (int c = 0; c < GPX_MAX_DIM; ++c) ctx->theta.inv_ell[c] = (c < d) ? 1.0 / ell[c] : 0.0;
   ctx->theta.scale = scale;
+  ctx->theta.pi_over_p = (kind == GPX_KERNEL_PERIODIC) ? 3.14159265358979323846 / ell[d] : 0.0;
   return 0;
 }
 
 double kdiag_value(const KernelParams& kp) {
-  if (kp.kind == GPX_KERNEL_RBF) return kp.scale;
+  if (kp.kind != GPX_KERNEL_MATERN52) return kp.scale;
   const double r = std::sqrt(MATERN_EPS);
   const double s5r = SQRT5 * r;
   return kp.scale * (1.0 + s5r) * std::exp(-s5r);
@@ -94,11 +96,11 @@ int dev_grad(gpx_ctx* ctx) {
     GPX_TRY(launch_gemm_nt(ctx, g, nt, nt, 0, GPX_PROF_GEMM_OTHER, n * n * n / 3.0));
   }
   const int nt64 = (N + 63) / 64;
-  GPX_TRY(ensure(ctx, ctx->part, (size_t)nt64 * (nt64 + 1) / 2 * (GPX_MAX_DIM + 2) * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->part, (size_t)nt64 * (nt64 + 1) / 2 * (GPX_MAX_DIM + 3) * sizeof(double)));
   int nblocks = 0;
   GPX_TRY(launch_grad_contract(ctx, ctx->theta, ctx->X.d(), N, K, ctx->ldk, ctx->alpha.d(),
                                ctx->part.d(), &nblocks));
-  GPX_TRY(launch_grad_reduce(ctx, ctx->part.d(), nblocks, ctx->d + 2, ctx->scal.d() + SC_GRAD));
+  GPX_TRY(launch_grad_reduce(ctx, ctx->part.d(), nblocks, n_ell(ctx->theta) + 2, ctx->scal.d() + SC_GRAD));
   ctx->factored = false; // K now holds K^-1
   return 0;
 }
@@ -397,8 +399,9 @@ int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* gra
   if (!ctx->factored) return bad_arg(ctx, "gpx_lml_grad must follow gpx_factor");
   GPX_HIP(ctx, hipSetDevice(ctx->device));
   GPX_TRY(dev_grad(ctx));
-  double h[GPX_MAX_DIM + 2];
-  GPX_HIP(ctx, hipMemcpyAsync(h, ctx->scal.d() + SC_GRAD, (ctx->d + 2) * sizeof(double),
+  double h[GPX_MAX_DIM + 3];
+  const int ne = n_ell(ctx->theta);
+  GPX_HIP(ctx, hipMemcpyAsync(h, ctx->scal.d() + SC_GRAD, (ne + 2) * sizeof(double),
                               hipMemcpyDeviceToHost, ctx->stream));
   if (alpha) {
     GPX_HIP(ctx, hipMemcpyAsync(alpha, ctx->alpha.d(), (size_t)ctx->N * sizeof(double),
@@ -406,9 +409,9 @@ int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* gra
   }
   GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (grad_ell)
-    for (int c = 0; c < ctx->d; ++c) grad_ell[c] = h[c];
-  if (grad_scale) *grad_scale = h[ctx->d];
-  if (grad_noise) *grad_noise = h[ctx->d + 1];
+    for (int c = 0; c < ne; ++c) grad_ell[c] = h[c];
+  if (grad_scale) *grad_scale = h[ne];
+  if (grad_noise) *grad_noise = h[ne + 1];
   return 0;
 }
 
@@ -526,7 +529,7 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
     SWEEP_HIP(hipMemsetAsync(ctx->eps.d(), 0, (size_t)n_pad * ctx->ldc * sizeof(double), ctx->stream));
   }
   for (int s = 0; s < S; ++s) {
-    SWEEP_TRY(set_theta(ctx, kind, d, ells + (int64_t)s * d, scales[s]));
+    SWEEP_TRY(set_theta(ctx, kind, d, ells + (int64_t)s * (d + (kind == GPX_KERNEL_PERIODIC ? 1 : 0)), scales[s]));
     ctx->noise = noises[s];
     ctx->noise_p = noiseless ? 0.0 : noises[s];
     if (strided)
@@ -675,7 +678,7 @@ int gpx_sweep_resident(gpx_ctx* ctx, int kind, int S, const double* ells, const 
   GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   GPX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   for (int s = 0; s < S; ++s) {
-    GPX_TRY(set_theta(ctx, kind, ctx->d, ells + (int64_t)s * ctx->d, scales[s]));
+    GPX_TRY(set_theta(ctx, kind, ctx->d, ells + (int64_t)s * (ctx->d + (kind == GPX_KERNEL_PERIODIC ? 1 : 0)), scales[s]));
     ctx->noise = noises[s];
     ctx->noise_p = noiseless ? 0.0 : noises[s];
     GPX_TRY(dev_factor(ctx, true));

@@ -60,7 +60,9 @@ struct KernelParams {
   int d;
   double inv_ell[GPX_MAX_DIM];
   double scale;
+  double pi_over_p; // pi / period (periodic kernel only)
 };
+inline int n_ell(const KernelParams& kp) { return kp.d + (kp.kind == GPX_KERNEL_PERIODIC ? 1 : 0); }
 
 struct ProfAcc {
   int64_t launches = 0;

@@ -21,6 +21,8 @@ template <int KIND>
 __device__ __forceinline__ double kernel_value(double r2, double scale) {
   if (KIND == GPX_KERNEL_RBF) {
     return scale * exp(-0.5 * r2);
+  } else if (KIND == GPX_KERNEL_PERIODIC) { // r2 carries sum_k (sin(pi (x_k - z_k) / p) / l_k)^2
+    return scale * exp(-2.0 * r2);
   } else {
     const double r = sqrt(r2 + MATERN_EPS);
     const double s5r = SQRT5 * r;
@@ -43,15 +45,16 @@ __global__ __launch_bounds__(256) void gram_kernel(KernelParams kp, const double
   for (int idx = tid; idx < GT_ROWS * d; idx += 256) {
     const int r = idx / d, c = idx - r * d;
     const int i = i0 + r;
-    sx[idx] = (i < n) ? X[(int64_t)i * d + c] * kp.inv_ell[c] : 0.0;
+    sx[idx] = (i < n) ? X[(int64_t)i * d + c] * (KIND == GPX_KERNEL_PERIODIC ? 1.0 : kp.inv_ell[c]) : 0.0;
   }
   const int j = j0 + 2 * tid;
   double z0[(D > 0) ? D : 1], z1[(D > 0) ? D : 1];
   if (D > 0) {
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-      z0[c] = (j < m) ? Z[(int64_t)j * D + c] * kp.inv_ell[c] : 0.0;
-      z1[c] = (j + 1 < m) ? Z[(int64_t)(j + 1) * D + c] * kp.inv_ell[c] : 0.0;
+      const double zs = (KIND == GPX_KERNEL_PERIODIC) ? 1.0 : kp.inv_ell[c];
+      z0[c] = (j < m) ? Z[(int64_t)j * D + c] * zs : 0.0;
+      z1[c] = (j + 1 < m) ? Z[(int64_t)(j + 1) * D + c] * zs : 0.0;
     }
   }
   __syncthreads();
@@ -64,16 +67,25 @@ __global__ __launch_bounds__(256) void gram_kernel(KernelParams kp, const double
 #pragma unroll
       for (int c = 0; c < D; ++c) {
         const double x = sx[r * D + c];
-        const double a = x - z0[c], b = x - z1[c];
+        double a = x - z0[c], b = x - z1[c];
+        if (KIND == GPX_KERNEL_PERIODIC) {
+          a = sin(a * kp.pi_over_p) * kp.inv_ell[c];
+          b = sin(b * kp.pi_over_p) * kp.inv_ell[c];
+        }
         r20 = fma(a, a, r20);
         r21 = fma(b, b, r21);
       }
     } else {
       for (int c = 0; c < d; ++c) {
         const double x = sx[r * d + c];
-        const double za = (j < m) ? Z[(int64_t)j * d + c] * kp.inv_ell[c] : 0.0;
-        const double zb = (j + 1 < m) ? Z[(int64_t)(j + 1) * d + c] * kp.inv_ell[c] : 0.0;
-        const double a = x - za, b = x - zb;
+        const double zs = (KIND == GPX_KERNEL_PERIODIC) ? 1.0 : kp.inv_ell[c];
+        const double za = (j < m) ? Z[(int64_t)j * d + c] * zs : 0.0;
+        const double zb = (j + 1 < m) ? Z[(int64_t)(j + 1) * d + c] * zs : 0.0;
+        double a = x - za, b = x - zb;
+        if (KIND == GPX_KERNEL_PERIODIC) {
+          a = sin(a * kp.pi_over_p) * kp.inv_ell[c];
+          b = sin(b * kp.pi_over_p) * kp.inv_ell[c];
+        }
         r20 = fma(a, a, r20);
         r21 = fma(b, b, r21);
       }
@@ -136,6 +148,9 @@ int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, i
   if (kp.kind == GPX_KERNEL_RBF)
     gram_dispatch<GPX_KERNEL_RBF>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
                                   add_diag, lower_only, dOut, ld);
+  else if (kp.kind == GPX_KERNEL_PERIODIC)
+    gram_dispatch<GPX_KERNEL_PERIODIC>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
+                                       add_diag, lower_only, dOut, ld);
   else
     gram_dispatch<GPX_KERNEL_MATERN52>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
                                        add_diag, lower_only, dOut, ld);

@@ -281,6 +281,7 @@ int launch_rowdot(gpx_ctx* ctx, const double* dV, int64_t ldv, int rows, int col
 
 __device__ __forceinline__ double kval_rt(int kind, double r2, double scale) {
   if (kind == GPX_KERNEL_RBF) return scale * exp(-0.5 * r2);
+  if (kind == GPX_KERNEL_PERIODIC) return scale * exp(-2.0 * r2);
   const double r = sqrt(r2 + MATERN_EPS);
   const double s5r = SQRT5 * r;
   return scale * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(KernelParams kp,
     if (a < M && b < M) {
       double r2 = 0.0;
       for (int c = 0; c < d; ++c) {
-        const double u = (Xn[(int64_t)a * d + c] - Xn[(int64_t)b * d + c]) * kp.inv_ell[c];
+        double u = Xn[(int64_t)a * d + c] - Xn[(int64_t)b * d + c];
+        u = (kp.kind == GPX_KERNEL_PERIODIC) ? sin(u * kp.pi_over_p) * kp.inv_ell[c] : u * kp.inv_ell[c];
         r2 = fma(u, u, r2);
       }
       v = kval_rt(kp.kind, r2, kp.scale);
@@ -340,7 +342,7 @@ int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXne
 //   RBF: dk/dr2 = -k/2;  Matern52: dk/dr2 = -(5/6) s e^{-sqrt5 r} (1 + sqrt5 r2 / r).
 // Output per block: [g_ell(0..d), g_scale, g_noise]; reduced in fixed order afterwards.
 constexpr int GC_TILE = 64;
-constexpr int GC_MAXV = GPX_MAX_DIM + 2;
+constexpr int GC_MAXV = GPX_MAX_DIM + 3;
 
 __global__ __launch_bounds__(256) void grad_contract_kernel(KernelParams kp,
                                                             const double* __restrict__ X, int N,
@@ -355,9 +357,10 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernelParams kp,
   while ((int64_t)ti * (ti + 1) / 2 > bid) --ti;
   const int tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
   const int d = kp.d;
+  const int ne = d + (kp.kind == GPX_KERNEL_PERIODIC ? 1 : 0); // [ell(0..d), (period), scale, noise]
   __shared__ double red[16];
   double acc[GC_MAXV];
-  for (int c = 0; c < d + 2; ++c) acc[c] = 0.0;
+  for (int c = 0; c < ne + 2; ++c) acc[c] = 0.0;
   const int j = tj * GC_TILE + (threadIdx.x & 63);
   const int ibase = ti * GC_TILE + (threadIdx.x >> 6);
   if (j < N) {
@@ -367,30 +370,46 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernelParams kp,
       if (i >= N || j > i) continue;
       const double G = alpha[i] * aj - Kinv[(int64_t)i * ld + j];
       const double wgt = (i == j) ? 0.5 : 1.0;
-      double r2 = 0.0;
-      double u2[GPX_MAX_DIM];
-      for (int c = 0; c < d; ++c) {
-        const double u = (X[(int64_t)i * d + c] - X[(int64_t)j * d + c]) * kp.inv_ell[c];
-        u2[c] = u * u;
-        r2 += u2[c];
-      }
-      double kv, dk;
-      if (kp.kind == GPX_KERNEL_RBF) {
-        kv = kp.scale * exp(-0.5 * r2);
-        dk = -0.5 * kv;
-      } else {
-        const double r = sqrt(r2 + MATERN_EPS);
-        const double e = exp(-SQRT5 * r);
-        kv = kp.scale * (1.0 + SQRT5 * r + (5.0 / 3.0) * r2) * e;
-        dk = -(5.0 / 6.0) * kp.scale * e * (1.0 + SQRT5 * r2 / r);
-      }
       const double wg = wgt * G;
-      for (int c = 0; c < d; ++c) acc[c] += wg * dk * (-2.0 * u2[c] * kp.inv_ell[c]);
-      acc[d] += wg * kv / kp.scale;
-      if (i == j) acc[d + 1] += wg;
+      if (kp.kind == GPX_KERNEL_PERIODIC) {
+        // k = s exp(-2 sum (S_m / l_m)^2), S_m = sin(pi delta_m / p)
+        double q = 0.0, dp = 0.0, s2[GPX_MAX_DIM];
+        for (int c = 0; c < d; ++c) {
+          const double delta = X[(int64_t)i * d + c] - X[(int64_t)j * d + c];
+          const double sn = sin(delta * kp.pi_over_p), cs = cos(delta * kp.pi_over_p);
+          s2[c] = sn * sn * kp.inv_ell[c] * kp.inv_ell[c];
+          q += s2[c];
+          dp += sn * cs * delta * kp.inv_ell[c] * kp.inv_ell[c];
+        }
+        const double kv = kp.scale * exp(-2.0 * q);
+        for (int c = 0; c < d; ++c) acc[c] += wg * kv * 4.0 * s2[c] * kp.inv_ell[c];            // d/d l_m
+        acc[d] += wg * kv * 4.0 * dp * kp.pi_over_p * kp.pi_over_p / 3.14159265358979323846;    // d/d p
+        acc[ne] += wg * kv / kp.scale;
+      } else {
+        double r2 = 0.0;
+        double u2[GPX_MAX_DIM];
+        for (int c = 0; c < d; ++c) {
+          const double u = (X[(int64_t)i * d + c] - X[(int64_t)j * d + c]) * kp.inv_ell[c];
+          u2[c] = u * u;
+          r2 += u2[c];
+        }
+        double kv, dk;
+        if (kp.kind == GPX_KERNEL_RBF) {
+          kv = kp.scale * exp(-0.5 * r2);
+          dk = -0.5 * kv;
+        } else {
+          const double r = sqrt(r2 + MATERN_EPS);
+          const double e = exp(-SQRT5 * r);
+          kv = kp.scale * (1.0 + SQRT5 * r + (5.0 / 3.0) * r2) * e;
+          dk = -(5.0 / 6.0) * kp.scale * e * (1.0 + SQRT5 * r2 / r);
+        }
+        for (int c = 0; c < d; ++c) acc[c] += wg * dk * (-2.0 * u2[c] * kp.inv_ell[c]);
+        acc[ne] += wg * kv / kp.scale;
+      }
+      if (i == j) acc[ne + 1] += wg;
     }
   }
-  for (int c = 0; c < d + 2; ++c) {
+  for (int c = 0; c < ne + 2; ++c) {
     const double s = block_sum(acc[c], red);
     if (threadIdx.x == 0) part[(int64_t)bid * GC_MAXV + c] = s;
   }

@@ -36,10 +36,11 @@ def _scalar(v, name):
 def _gram(kind: int, X, Z, params, noise, jitter):
     X, Z = _as2d(X), _as2d(Z)
     scale = _scalar(params["k_scale"], "k_scale")
+    ell = _lib.pack_ell(kind, params["k_length"], X.shape[1], params.get("period"))
     # the reference adds (noise + jitter) * eye iff X.shape == Z.shape (kernels.py:63,89)
     add_diag = X.shape == Z.shape
     diag_add = add_jitter(_scalar(noise, "noise"), jitter) if add_diag else 0.0
-    return _lib.get_engine().gram(kind, X, Z, params["k_length"], scale, diag_add, add_diag)
+    return _lib.get_engine().gram(kind, X, Z, ell, scale, diag_add, add_diag)
 
 
 def RBFKernel(X, Z, params: Dict[str, np.ndarray], noise=0, jitter: float = 1e-6, **kwargs) -> np.ndarray:
@@ -52,13 +53,19 @@ def MaternKernel(X, Z, params: Dict[str, np.ndarray], noise=0, jitter: float = 1
     return _gram(_lib.KERNEL_KINDS["Matern"], X, Z, params, noise, jitter)
 
 
+def PeriodicKernel(X, Z, params: Dict[str, np.ndarray], noise=0, jitter: float = 1e-6, **kwargs) -> np.ndarray:
+    """Periodic kernel (gpax/kernels/kernels.py:94-117) on the GPU; params: k_length, k_scale, period."""
+    return _gram(_lib.KERNEL_KINDS["Periodic"], X, Z, params, noise, jitter)
+
+
+PeriodicKernel.gpx_name = "Periodic"
 RBFKernel.gpx_name = "RBF"
 MaternKernel.gpx_name = "Matern"
 
 
 def get_kernel(kernel: Union[str, kernel_fn_type] = 'RBF', **kwargs):
-    """gpax/kernels/kernels.py:227-241.  'Periodic' and 'NNGP' have no MI355X path."""
-    kernel_book = {'RBF': RBFKernel, 'Matern': MaternKernel}
+    """gpax/kernels/kernels.py:227-241.  'NNGP' has no MI355X path."""
+    kernel_book = {'RBF': RBFKernel, 'Matern': MaternKernel, 'Periodic': PeriodicKernel}
     if isinstance(kernel, str):
         try:
             kernel = kernel_book[kernel]

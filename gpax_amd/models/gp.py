@@ -103,8 +103,10 @@ class ExactGP:
         length_dist = self.lengthscale_prior_dist if self.lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
         noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
         sites = [_Site("k_length", (self.kernel_dim,), length_dist),  # plate "ard", gp.py:238-239
-                 _Site("k_scale", (), dist.LogNormal(0.0, 1.0)),     # gp.py:241
-                 _Site("noise", (), noise_dist)]                     # gp.py:222-227
+                 _Site("k_scale", (), dist.LogNormal(0.0, 1.0))]     # gp.py:241
+        if self.kernel_name == "Periodic":
+            sites.append(_Site("period", (), dist.LogNormal(0.0, 1.0)))  # gp.py:243-244
+        sites.append(_Site("noise", (), noise_dist))                     # gp.py:222-227
         for name, d in self._mean_prior_dict().items():
             sites.append(_Site(name, (), d))
         return sites
@@ -116,6 +118,10 @@ class ExactGP:
             eng._train_owner = self
             eng._train_version = self.X_train
         return eng
+
+    def _ell(self, params) -> np.ndarray:
+        """d lengthscales (+ the period for the periodic kernel), as the C-ABI takes them."""
+        return _lib.pack_ell(self._kind, params["k_length"], self.kernel_dim, params.get("period"))
 
     def _mean(self, X, params) -> np.ndarray:
         if self.mean_fn is None:
@@ -140,14 +146,17 @@ class ExactGP:
         if eng is None:
             eng = self._engine()
         yres = self.y_train - self._mean(self.X_train, theta)
-        lml, info = eng.factor(self._kind, theta["k_length"], theta["k_scale"], theta["noise"], jitter, yres)
+        lml, info = eng.factor(self._kind, self._ell(theta), theta["k_scale"], theta["noise"], jitter, yres)
         if info != 0 or not np.isfinite(lml):
             return -np.inf, np.zeros_like(u)
         val = lml
         grad = np.zeros_like(u)
         if want_grad:
             g_ell, g_scale, g_noise, alpha = eng.lml_grad()
-            glik = {"k_length": g_ell, "k_scale": np.array([g_scale]), "noise": np.array([g_noise])}
+            d_ = self.kernel_dim
+            glik = {"k_length": g_ell[:d_], "k_scale": np.array([g_scale]), "noise": np.array([g_noise])}
+            if self.kernel_name == "Periodic":
+                glik["period"] = g_ell[d_:d_ + 1]
         off = 0
         for s in sites:
             ui = u[off:off + s.size]
@@ -299,7 +308,7 @@ class ExactGP:
         noise_p = noise * (1 - int(bool(noiseless)))
         y_residual = self.y_train - self._mean(self.X_train, params)
         eng = self._engine()
-        lml, info = eng.factor(self._kind, params["k_length"], self._scalar(params["k_scale"]), noise, jitter,
+        lml, info = eng.factor(self._kind, self._ell(params), self._scalar(params["k_scale"]), noise, jitter,
                                y_residual)
         mean, cov, _ = eng.posterior(X_new, noise_p, jitter, want_cov=True)
         if info != 0:
@@ -360,6 +369,9 @@ class ExactGP:
         d, M = self.kernel_dim, X_new.shape[0]
         ells = np.asarray(samples["k_length"], dtype=np.float64).reshape(S, -1)
         ells = np.ascontiguousarray(np.broadcast_to(ells, (S, d)))
+        if self.kernel_name == "Periodic":
+            ells = np.ascontiguousarray(np.concatenate(
+                [ells, np.asarray(samples["period"], dtype=np.float64).reshape(S, 1)], axis=1))
         scales = np.asarray(samples["k_scale"], dtype=np.float64).reshape(S)
         noises = np.asarray(samples["noise"], dtype=np.float64).reshape(S)
         mean_shift = None
@@ -394,7 +406,7 @@ class ExactGP:
         out = np.empty((num_samples, X.shape[0]))
         for i in range(num_samples):
             theta = {s.name: (s.dist.sample(rng, s.shape) if s.shape else float(s.dist.sample(rng))) for s in self._sites()}
-            K = eng.gram(self._kind, X, X, theta["k_length"], theta["k_scale"], theta["noise"] + 1e-6, True)
+            K = eng.gram(self._kind, X, X, self._ell(theta), theta["k_scale"], theta["noise"] + 1e-6, True)
             L, info = eng.potrf(K)
             out[i] = self._mean(X, theta) + L @ rng.standard_normal(X.shape[0]) if info == 0 else np.nan
         return out

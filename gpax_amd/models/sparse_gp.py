@@ -30,6 +30,8 @@ class viSparseGP(viGP):
                  lengthscale_prior_dist: Optional[dist.Distribution] = None, guide: str = 'delta') -> None:
         super().__init__(input_dim, kernel, mean_fn, kernel_prior, mean_fn_prior, noise_prior, noise_prior_dist,
                          lengthscale_prior_dist, guide)
+        if self.kernel_name == "Periodic":
+            raise NotImplementedError("viSparseGP on the MI355X path supports 'RBF' and 'Matern'")
         self.Xu = None
 
     # -- objective: bound + log prior (+ log |J|), gradient w.r.t. (u, Xu) -----------------------------

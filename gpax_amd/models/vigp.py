@@ -102,7 +102,7 @@ class viGP(ExactGP):
     def _factor_at(self, params, jitter):
         noise = self._scalar(params["noise"])
         y_residual = self.y_train - self._mean(self.X_train, params)
-        return self._engine().factor(self._kind, params["k_length"], self._scalar(params["k_scale"]), noise, jitter,
+        return self._engine().factor(self._kind, self._ell(params), self._scalar(params["k_scale"]), noise, jitter,
                                      y_residual)
 
     def _posterior_mean_var(self, X_new, params, noiseless, jitter):

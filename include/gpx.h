@@ -34,6 +34,8 @@ typedef struct gpx_ctx gpx_ctx;
 /* kernel family selector — gpax/kernels/kernels.py:227-241 (get_kernel registry) */
 #define GPX_KERNEL_RBF 0      /* gpax/kernels/kernels.py:44-65 */
 #define GPX_KERNEL_MATERN52 1 /* gpax/kernels/kernels.py:68-91 */
+#define GPX_KERNEL_PERIODIC 2 /* gpax/kernels/kernels.py:94-117; `ell` then carries d + 1 values:
+                                 the d lengthscales followed by the period (and gradients likewise) */
 
 #define GPX_MAX_DIM 16 /* max input dimension d handled by the fused kernels */
 

@@ -79,9 +79,21 @@ def MaternKernel(X, Z, params, noise=0, jitter=1e-6, **kwargs):
     return k
 
 
+def PeriodicKernel(X, Z, params, noise=0, jitter=1e-6, **kwargs):
+    """gpax/kernels/kernels.py:94-117"""
+    X = np.asarray(X, dtype=np.float64)
+    Z = np.asarray(Z, dtype=np.float64)
+    d = X[:, None] - Z[None]
+    scaled_sin = np.sin(math.pi * d / params["period"]) / params["k_length"]
+    k = params["k_scale"] * np.exp(-2 * (scaled_sin ** 2).sum(-1))
+    if X.shape == Z.shape:
+        k = k + add_jitter(noise, jitter) * np.eye(X.shape[0])
+    return k
+
+
 def get_kernel(kernel="RBF"):
     """gpax/kernels/kernels.py:227-241 (in-scope names only)"""
-    kernel_book = {"RBF": RBFKernel, "Matern": MaternKernel}
+    kernel_book = {"RBF": RBFKernel, "Matern": MaternKernel, "Periodic": PeriodicKernel}
     if isinstance(kernel, str):
         return kernel_book[kernel]
     return kernel

@@ -8,7 +8,17 @@ import scipy.linalg as sla
 from gpax_amd._lib import broadcast_lengthscale
 from oracle import cpu_ref as ref
 
-_NAMES = {0: "RBF", 1: "Matern"}
+_NAMES = {0: "RBF", 1: "Matern", 2: "Periodic"}
+
+
+def _params(kind, ell, d, scale, noise=None):
+    ell = np.asarray(ell, dtype=np.float64).reshape(-1)
+    p = {"k_length": broadcast_lengthscale(ell[:d] if kind == 2 else ell, d), "k_scale": float(scale)}
+    if kind == 2:
+        p["period"] = float(ell[d])
+    if noise is not None:
+        p["noise"] = float(noise)
+    return p
 
 
 class OracleEngine:
@@ -24,7 +34,7 @@ class OracleEngine:
 
     def gram(self, kind, X, Z, ell, scale, diag_add, add_diag):
         X, Z = np.asarray(X, dtype=np.float64), np.asarray(Z, dtype=np.float64)
-        p = {"k_length": broadcast_lengthscale(ell, X.shape[1]), "k_scale": scale}
+        p = _params(kind, ell, X.shape[1], scale)
         K = ref.get_kernel(_NAMES[kind])(X, Z, p, noise=0.0, jitter=0.0)
         if add_diag:
             K = K + diag_add * np.eye(X.shape[0])
@@ -37,8 +47,8 @@ class OracleEngine:
             return np.full_like(A, np.nan), 1
 
     def factor(self, kind, ell, scale, noise, jitter, yres):
-        self._theta = dict(kind=kind, p={"k_length": broadcast_lengthscale(ell, self.d), "k_scale": float(scale),
-                                         "noise": float(noise)}, jitter=float(jitter))
+        self._theta = dict(kind=kind, p=_params(kind, ell, self.d, scale, noise), jitter=float(jitter), ell=ell,
+                           scale=float(scale), noise=float(noise))
         self._yres = np.asarray(yres, dtype=np.float64)
         K = self.gram(kind, self.X, self.X, ell, scale, noise + jitter, True)
         try:
@@ -53,8 +63,28 @@ class OracleEngine:
 
     def lml_grad(self):
         t = self._theta
-        return ref.exactgp_log_likelihood_grad(self.X, self._yres, t["p"], kernel=_NAMES[t["kind"]],
-                                               jitter=t["jitter"], yres=self._yres)
+        if t["kind"] != 2:
+            return ref.exactgp_log_likelihood_grad(self.X, self._yres, t["p"], kernel=_NAMES[t["kind"]],
+                                                   jitter=t["jitter"], yres=self._yres)
+        # periodic: central differences of the oracle lml (tests only)
+        ell = np.asarray(t["ell"], dtype=np.float64).reshape(-1)
+
+        def f(e, s, n):
+            return ref.exactgp_log_likelihood(self.X, self._yres, _params(2, e, self.d, s, n), kernel="Periodic",
+                                              jitter=t["jitter"])
+
+        g = np.empty(ell.size)
+        for m in range(ell.size):
+            h = 1e-6 * ell[m]
+            a, b = ell.copy(), ell.copy()
+            a[m] += h
+            b[m] -= h
+            g[m] = (f(a, t["scale"], t["noise"]) - f(b, t["scale"], t["noise"])) / (2 * h)
+        hs, hn = 1e-6 * t["scale"], 1e-6 * t["noise"]
+        gs = (f(ell, t["scale"] + hs, t["noise"]) - f(ell, t["scale"] - hs, t["noise"])) / (2 * hs)
+        gn = (f(ell, t["scale"], t["noise"] + hn) - f(ell, t["scale"], t["noise"] - hn)) / (2 * hn)
+        K = ref.PeriodicKernel(self.X, self.X, t["p"], t["noise"], jitter=t["jitter"])
+        return g, gs, gn, np.linalg.solve(K, self._yres)
 
     def posterior(self, Xnew, noise_p, jitter, want_cov=True, want_var=False):
         t = self._theta

@@ -69,7 +69,7 @@ def test_two_chains_and_custom_priors():
 
 def test_unsupported_inputs_raise_clearly():
     with pytest.raises(NotImplementedError):
-        ExactGP(1, "Periodic")
+        ExactGP(1, "NNGP")
     with pytest.raises(NotImplementedError):
         ExactGP(1, lambda a, b, c: None)
     with pytest.raises(NotImplementedError):
@@ -266,3 +266,26 @@ def test_parallel_chains_equal_sequential_chains():
         outs.append(m.get_samples(chain_dim=True)["k_length"])
     assert outs[0].shape == (2, 15, 1)
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_periodic_kernel_model_surface():
+    # gpax/tests/test_gp.py:41-49 parametrises 'Periodic' as well: fit + predict run, 'period' is a sample site
+    from gpax_amd.kernels import PeriodicKernel
+    rng = np.random.default_rng(0)
+    X = np.linspace(0, 6, 24)
+    y = np.sin(2 * np.pi * X / 2.0) + 0.05 * rng.standard_normal(24)
+    K = PeriodicKernel(X[:, None], X[:, None], {"k_length": 1.0, "k_scale": 1.0, "period": 2.0}, noise=0.1)
+    Kr = ref.PeriodicKernel(X[:, None], X[:, None], {"k_length": 1.0, "k_scale": 1.0, "period": 2.0}, noise=0.1)
+    np.testing.assert_allclose(K, Kr, rtol=1e-12)
+    m = ExactGP(1, "Periodic")
+    m.fit(get_keys()[0], X, y, num_warmup=20, num_samples=20, progress_bar=False, print_summary=False)
+    s = m.get_samples()
+    assert set(s) == {"k_length", "k_scale", "period", "noise"} and s["period"].shape == (20,)
+    ym, ys = m.predict(get_keys()[1], np.linspace(0, 6, 7), n=1)
+    assert ym.shape == (7,) and ys.shape == (20, 1, 7)
+    v = viGP(1, "Periodic")
+    v.fit(get_keys()[0], X, y, num_steps=15, progress_bar=False, print_summary=False)
+    mean, var = v.predict(get_keys()[1], np.linspace(0, 6, 7))
+    assert mean.shape == (7,) and np.all(var > 0)
+    with pytest.raises(NotImplementedError):
+        viSparseGP(1, "Periodic")
