@@ -71,6 +71,7 @@ def load_library() -> C.CDLL:
         "gpx_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64), _dp, _dp]),
         "gpx_time_stage": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
         "gpx_sweep_resident": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp]),
+        "gpx_sweep_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
         "gpx_mfma_f64_peak": (C.c_int, [vp, _dp]),
         "gpx_gemm_nt": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_double, _dp]),
         "gpx_potrf": (C.c_int, [vp, C.c_int, _dp, _dp, _ip]),
@@ -87,7 +88,7 @@ EXPORTED_SYMBOLS = (
     "gpx_init gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train "
     "gpx_factor gpx_lml_grad gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
-    "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_sweep_resident gpx_mfma_f64_peak gpx_gemm_nt "
+    "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf"
 ).split()
 
@@ -332,6 +333,12 @@ class Engine:
                     "gpx_sweep_resident")
         return ms.value
 
+    def sweep_stats(self):
+        """(batches launched, samples processed, batch size B of the last sweep) of this context."""
+        nb, ns, last = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        self._check(self._lib.gpx_sweep_stats(self._ctx, C.byref(nb), C.byref(ns), C.byref(last)), "gpx_sweep_stats")
+        return int(nb.value), int(ns.value), int(last.value)
+
     def mfma_f64_peak(self) -> float:
         return self.mfma_f64_probe()["tflops"]
 
@@ -392,6 +399,11 @@ def sweep_inflight() -> int:
     return max(1, int(os.environ.get("GPX_INFLIGHT", "3")))
 
 
+# Below this N one context's batched sweep (B samples per launch) saturates the chip; above it the
+# batches are small (B <= ~30) and a few contexts in flight still overlap each other's serial tails.
+_BATCHED_SINGLE_CTX_BELOW_N = 3000
+
+
 def get_sweep_engines(device: Optional[int] = None, n: Optional[int] = None) -> list:
     """The default engine plus (n - 1) more contexts on the same GPU, for concurrent sweeps.  An
     injected (non-libgpx) engine is returned alone."""
@@ -415,6 +427,8 @@ def concurrent_sweep(engines: list, X, kind: int, ells, scales, noises, yres, Xn
     ells = np.asarray(ells, dtype=np.float64)
     S = ells.shape[0]
     n = max(1, min(len(engines), S))
+    if np.shape(X)[0] < _BATCHED_SINGLE_CTX_BELOW_N:
+        n = 1  # the batched sweep already fills the GPU from one context (measured: extra contexts do not help)
     if n == 1:
         engines[0].set_train(X)
         return engines[0].predict_sweep(kind, ells, scales, noises, yres, Xnew, noiseless, jitter, eps)

@@ -39,30 +39,71 @@ double kdiag_value(const KernelParams& kp) {
   return kp.scale * (1.0 + s5r) * std::exp(-s5r);
 }
 
+// ---- batch layout ------------------------------------------------------------------------------
+// Split-K slabs of the posterior-covariance SYRK (lower tiles only): enough slabs to give the
+// launch ~512 workgroups, each slab a multiple of 128 k-columns.
+struct CovSplit {
+  int splits, kchunk;
+};
+CovSplit cov_split(const gpx_ctx* ctx) {
+  const int nt = (ctx->N + TILE - 1) / TILE;
+  const int mt = ctx->Mp / TILE;
+  const int ktot = nt * TILE;
+  const int lower_tiles = mt * (mt + 1) / 2;
+  int splits = (512 + lower_tiles - 1) / lower_tiles;
+  const int max_splits = ktot / 256 > 0 ? ktot / 256 : 1;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int kchunk = round_up((ktot + splits - 1) / splits, TILE);
+  splits = (ktot + kchunk - 1) / kchunk;
+  return CovSplit{splits, kchunk};
+}
+
+// Plan over the context's own buffers: B samples per launch, sample b at base + b * stride.
+// B = 1 with th = nullptr is the eager single-theta path of gpx_factor / gpx_posterior.
+BatchPlan make_plan(gpx_ctx* ctx, int B, int n_pad, bool fused) {
+  BatchPlan p;
+  p.B = B;
+  p.yres = ctx->yres.d();
+  p.k_bs = (int64_t)(ctx->Np + (fused ? ctx->Mp : 0)) * ctx->ldk;
+  p.linv_bs = (int64_t)(ctx->Np / TILE) * TILE * TILE;
+  p.mean_bs = ctx->Mp;
+  p.cov_bs = (int64_t)ctx->Mp * ctx->ldc;
+  p.covlinv_bs = (int64_t)(ctx->Mp / TILE) * TILE * TILE;
+  p.splitk_bs = (ctx->Mp > 0) ? (int64_t)cov_split(ctx).splits * p.cov_bs : 0;
+  p.eps_bs = (int64_t)n_pad * ctx->ldc;
+  p.info_train = sc_int(ctx) + SI_TRAIN;
+  p.info_cov = sc_int(ctx) + SI_COV;
+  return p;
+}
+
 // Gram (lower tiles) + augmentation + blocked Cholesky + lml reductions; all async.
 // fused: the k_pX rows of the resident X_new ride below the square matrix (rows Np ..), so the
 // factorisation also leaves Vt = k_pX L^-T there (see potrf_lower).
-int dev_factor(gpx_ctx* ctx, bool fused) {
-  const int N = ctx->N, Np = ctx->Np;
+int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
+  const int N = ctx->N, Np = ctx->Np, B = bp.B;
   const int extra = fused ? ctx->Mp / TILE : 0;
-  if (fused) GPX_TRY(ensure(ctx, ctx->K, (size_t)(Np + ctx->Mp) * ctx->ldk * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->K, (size_t)((B - 1) * bp.k_bs + (int64_t)(Np + (fused ? ctx->Mp : 0)) * ctx->ldk) *
+                                  sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->Linv, (size_t)B * bp.linv_bs * sizeof(double)));
   double* K = ctx->K.d();
   GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->X.d(), N, N, ctx->X.d(), N, Np,
-                             ctx->noise + ctx->jitter, 1, 1, K, ctx->ldk));
-  GPX_TRY(launch_augment(ctx, K, ctx->ldk, N, Np, ctx->yres.d()));
+                             ctx->noise + ctx->jitter, 1, 1, K, ctx->ldk, B, bp.k_bs, bp.th, 1));
+  GPX_TRY(launch_augment(ctx, K, ctx->ldk, N, Np, bp.yres, B, bp.k_bs, bp.y_bs));
   if (fused) {
     // k_pX = kernel(X_new, X_train, params, jitter=0.0): no diagonal term (gp.py:268)
     GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->Xnew.d(), ctx->M, ctx->Mp, ctx->X.d(), N, Np, 0.0,
-                               0, 0, K + (int64_t)Np * ctx->ldk, ctx->ldk));
+                               0, 0, K + (int64_t)Np * ctx->ldk, ctx->ldk, B, bp.k_bs, bp.th, 0));
   }
-  GPX_HIP(ctx, hipMemsetAsync(sc_int(ctx) + SI_TRAIN, 0, sizeof(int), ctx->stream));
-  GPX_TRY(potrf_lower(ctx, K, ctx->ldk, Np, extra, ctx->Linv.d(), sc_int(ctx) + SI_TRAIN));
-  GPX_TRY(launch_lml_terms(ctx, K, ctx->ldk, N, ctx->scal.d() + SC_QUAD));
-  ctx->factored = true;
+  GPX_HIP(ctx, hipMemsetAsync(bp.info_train, 0, (size_t)B * sizeof(int), ctx->stream));
+  GPX_TRY(potrf_lower(ctx, K, ctx->ldk, Np, extra, ctx->Linv.d(), bp.info_train, B, bp.k_bs, bp.linv_bs));
+  if (want_lml) GPX_TRY(launch_lml_terms(ctx, K, ctx->ldk, N, ctx->scal.d() + SC_QUAD));
+  ctx->factored = (B == 1);
   ctx->fused_vt = fused;
   ctx->have_post = false;
   return 0;
 }
+int dev_factor(gpx_ctx* ctx, bool fused) { return dev_factor(ctx, fused, make_plan(ctx, 1, 0, fused), true); }
 
 // L^-T (upper) into W, K^-1 = L^-T L^-1 (lower) over K, alpha = L^-T w, gradient contraction.
 int dev_grad(gpx_ctx* ctx) {
@@ -120,41 +161,42 @@ int set_xnew(gpx_ctx* ctx, const double* Xnew, int M) {
 }
 
 // k_pX -> Vt = k_pX L^-T, mean = Vt w, var, and (optionally) cov = k_pp - Vt Vt^T.
-int dev_posterior(gpx_ctx* ctx, bool want_cov) {
-  const int N = ctx->N, M = ctx->M, Mp = ctx->Mp;
+int dev_posterior(gpx_ctx* ctx, bool want_cov, const BatchPlan& bp) {
+  const int N = ctx->N, M = ctx->M, Mp = ctx->Mp, B = bp.B;
   const int nt = (N + TILE - 1) / TILE;
   const int mt = Mp / TILE;
   const double* K = ctx->K.d();
   KernelParams kp = ctx->theta;
   double* Vt;
-  int64_t ldv;
+  int64_t ldv, v_bs;
   if (ctx->fused_vt) { // already solved during the factorisation
     Vt = ctx->K.d() + (int64_t)ctx->Np * ctx->ldk;
     ldv = ctx->ldk;
+    v_bs = bp.k_bs;
   } else {
+    if (B != 1) return bad_arg(ctx, "batched posterior needs the fused factorisation");
     GPX_TRY(ensure(ctx, ctx->Vt, (size_t)ctx->Mp * ctx->ldv * sizeof(double)));
     Vt = ctx->Vt.d();
     ldv = ctx->ldv;
+    v_bs = 0;
     // k_pX = kernel(X_new, X_train, params, jitter=0.0): no diagonal term (gp.py:268)
-    GPX_TRY(launch_gram_padded(ctx, kp, ctx->Xnew.d(), M, Mp, ctx->X.d(), N, nt * TILE, 0.0, 0, 0, Vt, ldv));
+    GPX_TRY(launch_gram_padded(ctx, kp, ctx->Xnew.d(), M, Mp, ctx->X.d(), N, nt * TILE, 0.0, 0, 0, Vt, ldv, 1, 0,
+                               bp.th, 0));
     GPX_TRY(trsm_right_lt(ctx, Vt, ldv, mt, K, ctx->ldk, ctx->Linv.d(), nt, 0));
   }
+  GPX_TRY(ensure(ctx, ctx->mean, (size_t)B * bp.mean_bs * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->var, (size_t)B * bp.mean_bs * sizeof(double)));
   const double kd = kdiag_value(kp) + ctx->noise_p + ctx->jitter;
-  GPX_TRY(launch_rowdot(ctx, Vt, ldv, M, N, K + (int64_t)N * ctx->ldk, kd, ctx->mean.d(), ctx->var.d(), 0));
+  GPX_TRY(launch_rowdot(ctx, Vt, ldv, M, N, K + (int64_t)N * ctx->ldk, kd, ctx->mean.d(), ctx->var.d(), 0, B, v_bs,
+                        bp.k_bs, bp.mean_bs, bp.th));
   ctx->cov_factored = false;
   if (want_cov) {
-    GPX_TRY(ensure(ctx, ctx->Cov, (size_t)Mp * ctx->ldc * sizeof(double)));
+    const CovSplit cs = cov_split(ctx);
     const int ktot = nt * TILE;
-    const int lower_tiles = mt * (mt + 1) / 2;
-    int splits = (512 + lower_tiles - 1) / lower_tiles;
-    const int max_splits = ktot / 256 > 0 ? ktot / 256 : 1;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int kchunk = round_up((ktot + splits - 1) / splits, TILE);
-    splits = (ktot + kchunk - 1) / kchunk;
     const int64_t ldp = ctx->ldc;
     const int64_t stride = (int64_t)Mp * ldp;
-    GPX_TRY(ensure(ctx, ctx->SplitK, (size_t)splits * stride * sizeof(double)));
+    GPX_TRY(ensure(ctx, ctx->Cov, (size_t)B * bp.cov_bs * sizeof(double)));
+    GPX_TRY(ensure(ctx, ctx->SplitK, (size_t)B * cs.splits * stride * sizeof(double)));
     GemmArgs g{};
     g.A = Vt;
     g.lda = ldv;
@@ -166,25 +208,34 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov) {
     g.alpha = 1.0;
     g.beta = 0.0;
     g.lower = 1;
-    g.kchunk = kchunk;
+    g.kchunk = cs.kchunk;
     g.c_split_stride = stride;
+    g.batch = B;
+    g.a_bs = v_bs;
+    g.b_bs = v_bs;
+    g.c_bs = bp.splitk_bs;
     const double m = (double)Mp;
-    GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, splits, GPX_PROF_GEMM_OTHER, m * (m + 1.0) * ktot));
-    GPX_TRY(launch_cov_finalize(ctx, kp, ctx->Xnew.d(), M, Mp, ctx->SplitK.d(), splits, stride, ldp,
-                                ctx->noise_p + ctx->jitter, ctx->Cov.d(), ctx->ldc));
+    GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, cs.splits, GPX_PROF_GEMM_OTHER, m * (m + 1.0) * ktot));
+    GPX_TRY(launch_cov_finalize(ctx, kp, ctx->Xnew.d(), M, Mp, ctx->SplitK.d(), cs.splits, stride, ldp,
+                                ctx->noise_p + ctx->jitter, ctx->Cov.d(), ctx->ldc, B, bp.splitk_bs, bp.cov_bs,
+                                bp.th));
   }
-  ctx->have_post = want_cov;
+  ctx->have_post = want_cov && B == 1;
   return 0;
+}
+int dev_posterior(gpx_ctx* ctx, bool want_cov) {
+  return dev_posterior(ctx, want_cov, make_plan(ctx, 1, 0, ctx->fused_vt));
 }
 
 // chol(cov) (once per posterior) and draws = mean + eps Lc^T; eps already on device, padded.
-int dev_draw(gpx_ctx* ctx, int n_pad, int n) {
-  const int Mp = ctx->Mp, mt = Mp / TILE;
+int dev_draw(gpx_ctx* ctx, int n_pad, int n, const BatchPlan& bp) {
+  const int Mp = ctx->Mp, mt = Mp / TILE, B = bp.B;
   if (!ctx->cov_factored) {
-    GPX_TRY(ensure(ctx, ctx->CovLinv, (size_t)mt * TILE * TILE * sizeof(double)));
-    GPX_HIP(ctx, hipMemsetAsync(sc_int(ctx) + SI_COV, 0, sizeof(int), ctx->stream));
-    GPX_TRY(potrf_lower(ctx, ctx->Cov.d(), ctx->ldc, Mp, 0, ctx->CovLinv.d(), sc_int(ctx) + SI_COV));
-    ctx->cov_factored = true;
+    GPX_TRY(ensure(ctx, ctx->CovLinv, (size_t)B * bp.covlinv_bs * sizeof(double)));
+    GPX_HIP(ctx, hipMemsetAsync(bp.info_cov, 0, (size_t)B * sizeof(int), ctx->stream));
+    GPX_TRY(potrf_lower(ctx, ctx->Cov.d(), ctx->ldc, Mp, 0, ctx->CovLinv.d(), bp.info_cov, B, bp.cov_bs,
+                        bp.covlinv_bs));
+    ctx->cov_factored = (B == 1);
   }
   GemmArgs g{};
   g.A = ctx->eps.d();
@@ -197,11 +248,16 @@ int dev_draw(gpx_ctx* ctx, int n_pad, int n) {
   g.alpha = 1.0;
   g.beta = 0.0;
   g.kupper = 1;
+  g.batch = B;
+  g.a_bs = bp.eps_bs;
+  g.b_bs = bp.cov_bs;
+  g.c_bs = bp.eps_bs;
   GPX_TRY(launch_gemm_nt(ctx, g, n_pad / TILE, mt, 0, GPX_PROF_GEMM_OTHER,
                          2.0 * n_pad * (double)Mp * Mp / 2.0));
-  GPX_TRY(launch_add_mean(ctx, ctx->draws.d(), ctx->ldc, n, ctx->M, ctx->mean.d()));
+  GPX_TRY(launch_add_mean(ctx, ctx->draws.d(), ctx->ldc, n, ctx->M, ctx->mean.d(), B, bp.eps_bs, bp.mean_bs));
   return 0;
 }
+int dev_draw(gpx_ctx* ctx, int n_pad, int n) { return dev_draw(ctx, n_pad, n, make_plan(ctx, 1, n_pad, ctx->fused_vt)); }
 
 int upload_eps(gpx_ctx* ctx, const double* eps, int n, int* n_pad_out) {
   const int n_pad = round_up(n, TILE);
@@ -214,6 +270,167 @@ int upload_eps(gpx_ctx* ctx, const double* eps, int n, int* n_pad_out) {
                                   (size_t)ctx->M * sizeof(double), (size_t)ctx->M * sizeof(double), n,
                                   hipMemcpyHostToDevice, ctx->stream));
   }
+  return 0;
+}
+
+// ---- batched predictive sweep ---------------------------------------------------------------
+// The vmap of ExactGP.predict (gpax/models/gp.py:393-395) as a grid dimension: B theta samples
+// advance through the same launch sequence together (grid.z / one potf2 workgroup each), so a
+// launch carries B times the work and the serial chain of small kernels is paid once per batch.
+// Each sample's arithmetic is the single-sample arithmetic (same kernels, same tile shapes, same
+// accumulation order): results do not depend on B.
+
+// eps (S, n, M) contiguous -> per-sample padded slabs dst[b][n_pad][ldc]
+__global__ __launch_bounds__(256) void eps_gather_kernel(double* __restrict__ dst, int64_t ldc,
+                                                         int64_t eps_bs, const double* __restrict__ src,
+                                                         int n, int M) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y, b = blockIdx.z;
+  if (a < M) dst[(int64_t)b * eps_bs + (int64_t)r * ldc + a] = src[((int64_t)b * n + r) * M + a];
+}
+
+// per-batch results -> the sweep's contiguous outputs: means (b, M), samples (b, n, M), infos (b, 2)
+__global__ __launch_bounds__(256) void sweep_store_kernel(const double* __restrict__ mean, int64_t mean_bs,
+                                                          const double* __restrict__ draws, int64_t ldc,
+                                                          int64_t eps_bs, int n, int M,
+                                                          const int* __restrict__ info_train,
+                                                          const int* __restrict__ info_cov,
+                                                          double* __restrict__ means, double* __restrict__ samples,
+                                                          int* __restrict__ infos) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y, b = blockIdx.z;
+  if (a < M) {
+    if (r == 0)
+      means[(int64_t)b * M + a] = mean[(int64_t)b * mean_bs + a];
+    else
+      samples[((int64_t)b * n + (r - 1)) * M + a] = draws[(int64_t)b * eps_bs + (int64_t)(r - 1) * ldc + a];
+  }
+  if (a == 0 && r == 0 && infos != nullptr) {
+    infos[2 * b] = info_train[b];
+    infos[2 * b + 1] = (n > 0) ? info_cov[b] : 0;
+  }
+}
+
+struct SweepIO {
+  int kind = 0, S = 0, n = 0, noiseless = 0;
+  double jitter = 0.0;
+  const double *ells = nullptr, *scales = nullptr, *noises = nullptr; // host tables
+  const double* dYres = nullptr; // device (S, N) or nullptr: ctx->yres shared by all samples
+  const double* dEps = nullptr;  // device (S, n, M) or nullptr: whatever is resident in ctx->eps
+  double* dMeans = nullptr;      // device outputs (nullptr: results stay in the batch buffers)
+  double* dSamples = nullptr;
+  int* dInfos = nullptr;
+};
+
+// Samples per launch: enough that the small-N pipeline fills the chip, bounded by memory.
+int pick_batch(gpx_ctx* ctx, int S, int n_pad, bool want_cov) {
+  int forced = 0;
+  if (const char* e = getenv("GPX_SWEEP_BATCH")) forced = atoi(e);
+  // auto: ~2 * (16384 / Np)^2 — 1 at N = 16384 (the trailing SYRK alone fills the chip), 7 at 8192,
+  // 30 at 4096, 256 (cap) from N ~ 1400 down; measured in tools/small_n_sweep.py / multi_ctx.py
+  const double r = 16384.0 / (double)ctx->Np;
+  int B = forced > 0 ? forced : (int)(2.0 * r * r);
+  if (B > 256) B = 256;
+  const BatchPlan p = make_plan(ctx, 1, n_pad, true);
+  double per = (double)p.k_bs + p.linv_bs + 2.0 * p.mean_bs;
+  if (want_cov) per += (double)p.cov_bs + p.splitk_bs + p.covlinv_bs + 2.0 * p.eps_bs;
+  per *= sizeof(double);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    double budget = (double)free_b / 3.0;
+    const double cap = 24.0 * 1024 * 1024 * 1024;
+    if (budget > cap) budget = cap;
+    // buffers this context already holds are reused, not added
+    budget += (double)ctx->K.cap;
+    const int fit = (int)(budget / per);
+    if (B > fit) B = fit;
+  }
+  if (B > S) B = S;
+  if (B < 1) B = 1;
+  return B;
+}
+
+int fill_theta_table(gpx_ctx* ctx, const SweepIO& io) {
+  const int d = ctx->d;
+  const int stride = d + (io.kind == GPX_KERNEL_PERIODIC ? 1 : 0);
+  ctx->h_thtab.resize((size_t)io.S);
+  const KernelParams saved = ctx->theta;
+  for (int s = 0; s < io.S; ++s) {
+    int rc = set_theta(ctx, io.kind, d, io.ells + (int64_t)s * stride, io.scales[s]);
+    if (rc < 0) {
+      ctx->theta = saved;
+      return rc;
+    }
+    ThetaDev& t = ctx->h_thtab[(size_t)s];
+    t.kp = ctx->theta;
+    const double noise_p = io.noiseless ? 0.0 : io.noises[s];
+    t.diag_train = io.noises[s] + io.jitter;
+    t.diag_pred = noise_p + io.jitter;
+    t.kdiag_pred = kdiag_value(t.kp) + noise_p + io.jitter;
+  }
+  // ctx->theta keeps the structural fields (kind, d) the launchers dispatch on
+  GPX_TRY(ensure(ctx, ctx->thtab, (size_t)io.S * sizeof(ThetaDev)));
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->thtab.p, ctx->h_thtab.data(), (size_t)io.S * sizeof(ThetaDev),
+                              hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+// Enqueue the whole sweep on the context's streams (asynchronous; the caller synchronises).
+int sweep_core(gpx_ctx* ctx, const SweepIO& io) {
+  const int N = ctx->N, M = ctx->M, n = io.n, S = io.S;
+  const int n_pad = round_up(n > 0 ? n : 1, TILE);
+  ctx->jitter = io.jitter;
+  GPX_TRY(fill_theta_table(ctx, io));
+  const int B = pick_batch(ctx, S, n_pad, n > 0);
+  BatchPlan bp = make_plan(ctx, B, n_pad, true);
+  GPX_TRY(ensure(ctx, ctx->binfo, (size_t)2 * B * sizeof(int)));
+  bp.info_train = ctx->binfo.i();
+  bp.info_cov = ctx->binfo.i() + B;
+  if (n > 0) {
+    const size_t eb = (size_t)B * bp.eps_bs * sizeof(double);
+    const bool grew = ctx->eps.cap < eb;
+    GPX_TRY(ensure(ctx, ctx->eps, eb));
+    GPX_TRY(ensure(ctx, ctx->draws, eb));
+    // padding rows / columns of eps must be zero; resident eps (no dEps) is kept unless reallocated
+    if (io.dEps != nullptr || grew) GPX_HIP(ctx, hipMemsetAsync(ctx->eps.p, 0, eb, ctx->stream));
+  }
+  const ThetaDev* table = static_cast<const ThetaDev*>(ctx->thtab.p);
+  for (int s0 = 0; s0 < S; s0 += B) {
+    const int b = (S - s0 < B) ? S - s0 : B;
+    bp.B = b;
+    bp.th = table + s0;
+    if (io.dYres != nullptr) {
+      bp.yres = io.dYres + (int64_t)s0 * N;
+      bp.y_bs = N;
+    } else {
+      bp.yres = ctx->yres.d();
+      bp.y_bs = 0;
+    }
+    if (n > 0 && io.dEps != nullptr) {
+      dim3 grid((M + 255) / 256, n, b);
+      eps_gather_kernel<<<grid, 256, 0, ctx->stream>>>(ctx->eps.d(), ctx->ldc, bp.eps_bs,
+                                                        io.dEps + (int64_t)s0 * n * M, n, M);
+      GPX_HIP(ctx, hipGetLastError());
+    }
+    GPX_TRY(dev_factor(ctx, true, bp, false));
+    GPX_TRY(dev_posterior(ctx, n > 0, bp));
+    if (n > 0) GPX_TRY(dev_draw(ctx, n_pad, n, bp));
+    if (io.dMeans != nullptr) {
+      dim3 grid((M + 255) / 256, n + 1, b);
+      sweep_store_kernel<<<grid, 256, 0, ctx->stream>>>(
+          ctx->mean.d(), bp.mean_bs, ctx->draws.d(), ctx->ldc, bp.eps_bs, n, M, bp.info_train, bp.info_cov,
+          io.dMeans + (int64_t)s0 * M, io.dSamples ? io.dSamples + (int64_t)s0 * n * M : nullptr,
+          io.dInfos ? io.dInfos + 2 * s0 : nullptr);
+      GPX_HIP(ctx, hipGetLastError());
+    }
+    ctx->sweep_batches += 1;
+    ctx->sweep_samples += b;
+  }
+  ctx->last_batch = B;
+  // the context no longer holds a single factored theta
+  ctx->factored = false;
+  ctx->have_post = false;
+  ctx->cov_factored = false;
   return 0;
 }
 
@@ -280,7 +497,7 @@ void gpx_destroy(gpx_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->X,    &ctx->K,   &ctx->W,       &ctx->Linv,   &ctx->yres, &ctx->scal,
                       &ctx->part, &ctx->alpha, &ctx->Xnew,  &ctx->Vt,     &ctx->Cov,  &ctx->CovLinv,
                       &ctx->SplitK, &ctx->mean, &ctx->var,  &ctx->eps,    &ctx->draws, &ctx->tA,
-                      &ctx->tB,   &ctx->tC};
+                      &ctx->tB,   &ctx->tC,  &ctx->thtab,   &ctx->binfo};
     for (DevBuf* b : bufs) b->release();
     sgp_release(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -476,14 +693,13 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   if (!ells || !scales || !noises || !yres || !Xnew || !means) return bad_arg(ctx, "null pointer");
   if (n > 0 && (!eps || !samples)) return bad_arg(ctx, "eps/samples required when n > 0");
   GPX_HIP(ctx, hipSetDevice(ctx->device));
-  const int N = ctx->N, d = ctx->d;
+  const int N = ctx->N;
   GPX_TRY(set_xnew(ctx, Xnew, M));
-  ctx->jitter = jitter;
-  const int n_pad = round_up(n > 0 ? n : 1, TILE);
   // device staging for all inputs/outputs of the sweep: nothing crosses PCIe inside the loop
   DevBuf dEps, dYres, dMeans, dSamples, dInfos;
   int rc = 0;
   auto cleanup = [&]() {
+    (void)hipStreamSynchronize(ctx->stream); // nothing may still read the staging buffers
     dEps.release();
     dYres.release();
     dMeans.release();
@@ -524,35 +740,22 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
     SWEEP_TRY(ensure(ctx, dSamples, (size_t)S * n * M * sizeof(double)));
     SWEEP_HIP(hipMemcpyAsync(dEps.d(), eps, (size_t)S * n * M * sizeof(double), hipMemcpyHostToDevice,
                              ctx->stream));
-    SWEEP_TRY(ensure(ctx, ctx->eps, (size_t)n_pad * ctx->ldc * sizeof(double)));
-    SWEEP_TRY(ensure(ctx, ctx->draws, (size_t)n_pad * ctx->ldc * sizeof(double)));
-    SWEEP_HIP(hipMemsetAsync(ctx->eps.d(), 0, (size_t)n_pad * ctx->ldc * sizeof(double), ctx->stream));
   }
-  for (int s = 0; s < S; ++s) {
-    SWEEP_TRY(set_theta(ctx, kind, d, ells + (int64_t)s * (d + (kind == GPX_KERNEL_PERIODIC ? 1 : 0)), scales[s]));
-    ctx->noise = noises[s];
-    ctx->noise_p = noiseless ? 0.0 : noises[s];
-    if (strided)
-      SWEEP_HIP(hipMemcpyAsync(ctx->yres.d(), dYres.d() + (int64_t)s * N, (size_t)N * sizeof(double),
-                               hipMemcpyDeviceToDevice, ctx->stream));
-    SWEEP_TRY(dev_factor(ctx, true));
-    SWEEP_TRY(dev_posterior(ctx, n > 0));
-    SWEEP_HIP(hipMemcpyAsync(dMeans.d() + (int64_t)s * M, ctx->mean.d(), (size_t)M * sizeof(double),
-                             hipMemcpyDeviceToDevice, ctx->stream));
-    SWEEP_HIP(hipMemcpyAsync(dInfos.i() + 2 * s, sc_int(ctx) + SI_TRAIN, sizeof(int),
-                             hipMemcpyDeviceToDevice, ctx->stream));
-    if (n > 0) {
-      SWEEP_HIP(hipMemcpy2DAsync(ctx->eps.d(), ctx->ldc * sizeof(double),
-                                 dEps.d() + (int64_t)s * n * M, (size_t)M * sizeof(double),
-                                 (size_t)M * sizeof(double), n, hipMemcpyDeviceToDevice, ctx->stream));
-      SWEEP_TRY(dev_draw(ctx, n_pad, n));
-      SWEEP_HIP(hipMemcpy2DAsync(dSamples.d() + (int64_t)s * n * M, (size_t)M * sizeof(double),
-                                 ctx->draws.d(), ctx->ldc * sizeof(double), (size_t)M * sizeof(double),
-                                 n, hipMemcpyDeviceToDevice, ctx->stream));
-      SWEEP_HIP(hipMemcpyAsync(dInfos.i() + 2 * s + 1, sc_int(ctx) + SI_COV, sizeof(int),
-                               hipMemcpyDeviceToDevice, ctx->stream));
-    }
-  }
+  SweepIO io;
+  io.kind = kind;
+  io.S = S;
+  io.n = n;
+  io.noiseless = noiseless;
+  io.jitter = jitter;
+  io.ells = ells;
+  io.scales = scales;
+  io.noises = noises;
+  io.dYres = strided ? dYres.d() : nullptr;
+  io.dEps = n > 0 ? dEps.d() : nullptr;
+  io.dMeans = dMeans.d();
+  io.dSamples = n > 0 ? dSamples.d() : nullptr;
+  io.dInfos = dInfos.i();
+  SWEEP_TRY(sweep_core(ctx, io));
   std::vector<int> hinfos(2 * (size_t)S);
   SWEEP_HIP(hipMemcpyAsync(means, dMeans.d(), (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost,
                            ctx->stream));
@@ -576,6 +779,14 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
     if (code != 0 && n > 0)
       for (int64_t t = 0; t < (int64_t)n * M; ++t) samples[(int64_t)s * n * M + t] = NAN;
   }
+  return 0;
+}
+
+int gpx_sweep_stats(gpx_ctx* ctx, int64_t* batches, int64_t* samples, int* last_batch) {
+  if (!ctx) return -1;
+  if (batches) *batches = ctx->sweep_batches;
+  if (samples) *samples = ctx->sweep_samples;
+  if (last_batch) *last_batch = ctx->last_batch;
   return 0;
 }
 
@@ -669,22 +880,18 @@ int gpx_sweep_resident(gpx_ctx* ctx, int kind, int S, const double* ells, const 
   if (ctx->N < 1 || ctx->M < 1) return bad_arg(ctx, "gpx_factor and gpx_posterior must be called first");
   if (S < 1 || !ells || !scales || !noises || n_draws < 0) return bad_arg(ctx, "sweep arguments");
   GPX_HIP(ctx, hipSetDevice(ctx->device));
-  const int n_pad = round_up(n_draws > 0 ? n_draws : 1, TILE);
-  if (n_draws > 0) {
-    GPX_TRY(ensure(ctx, ctx->eps, (size_t)n_pad * ctx->ldc * sizeof(double)));
-    GPX_TRY(ensure(ctx, ctx->draws, (size_t)n_pad * ctx->ldc * sizeof(double)));
-  }
-  ctx->jitter = jitter;
+  SweepIO io;
+  io.kind = kind;
+  io.S = S;
+  io.n = n_draws;
+  io.noiseless = noiseless;
+  io.jitter = jitter;
+  io.ells = ells;
+  io.scales = scales;
+  io.noises = noises;
   GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   GPX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  for (int s = 0; s < S; ++s) {
-    GPX_TRY(set_theta(ctx, kind, ctx->d, ells + (int64_t)s * (ctx->d + (kind == GPX_KERNEL_PERIODIC ? 1 : 0)), scales[s]));
-    ctx->noise = noises[s];
-    ctx->noise_p = noiseless ? 0.0 : noises[s];
-    GPX_TRY(dev_factor(ctx, true));
-    GPX_TRY(dev_posterior(ctx, n_draws > 0));
-    if (n_draws > 0) GPX_TRY(dev_draw(ctx, n_pad, n_draws));
-  }
+  GPX_TRY(sweep_core(ctx, io));
   GPX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   GPX_HIP(ctx, hipEventSynchronize(ctx->ev1));
   float ms = 0.f;

@@ -64,6 +64,30 @@ struct KernelParams {
 };
 inline int n_ell(const KernelParams& kp) { return kp.d + (kp.kind == GPX_KERNEL_PERIODIC ? 1 : 0); }
 
+// Hyper-parameters of one posterior sample as the batched launches read them from a device
+// table (entry b of a launch's batch): the kernel parameters plus the three diagonal terms.
+struct ThetaDev {
+  KernelParams kp;
+  double diag_train; // noise + jitter            (K's diagonal, gp.py:160 / kernels.py:63-65)
+  double diag_pred;  // noise_p + jitter          (k_pp's diagonal, gp.py:267)
+  double kdiag_pred; // k(x, x) + noise_p + jitter (diag of k_pp, for the variance-only path)
+};
+
+// Batch layout of the device-resident pipeline: B independent samples per launch (the vmap of
+// gpax/models/gp.py:393-395 as a grid dimension).  Element b lives at base + b * stride.
+struct BatchPlan {
+  int B = 1;
+  const ThetaDev* th = nullptr; // device table (B entries) or nullptr: by-value ctx->theta
+  const double* yres = nullptr; // y residuals, element stride y_bs (0 = shared by the batch)
+  int64_t y_bs = 0;
+  int64_t k_bs = 0, linv_bs = 0;                     // K / Linv
+  int64_t mean_bs = 0;                               // mean, var
+  int64_t cov_bs = 0, covlinv_bs = 0, splitk_bs = 0; // Cov, CovLinv, SplitK
+  int64_t eps_bs = 0;                                // eps, draws
+  int* info_train = nullptr;                         // B ints each
+  int* info_cov = nullptr;
+};
+
 struct ProfAcc {
   int64_t launches = 0;
   double work = 0.0;
@@ -115,6 +139,13 @@ struct gpx_ctx {
   double noise_p = 0;
   bool have_post = false;
   bool cov_factored = false;
+
+  // ---- batched sweep state (gpx_predict_sweep / gpx_sweep_resident) -----------------------
+  gpx::DevBuf thtab;   // S x ThetaDev
+  gpx::DevBuf binfo;   // 2 x B ints (train / cov pivots of the batch in flight)
+  std::vector<gpx::ThetaDev> h_thtab;           // host image of thtab (outlives the async upload)
+  int64_t sweep_batches = 0, sweep_samples = 0; // statistics: batches launched, samples processed
+  int last_batch = 0;                           // samples per launch chosen by the last sweep
 
   void* sgp = nullptr; // sparse-GP state (sparse.hip)
 
@@ -180,10 +211,14 @@ struct ProfScope {
 // gram.hip
 int launch_gram(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, const double* dZ,
                 int m, double diag_add, int add_diag, int lower_only, double* dOut, int64_t ld);
+// th != nullptr: batched launch, entry b uses th[b].kp and (diag_sel 1: diag_train, 2: diag_pred,
+// 0: none) instead of the by-value kp / diag_add, and writes dOut + b * out_bs.
 int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, int n_pad,
                        const double* dZ, int m, int m_pad, double diag_add, int add_diag,
-                       int lower_only, double* dOut, int64_t ld);
-int launch_augment(gpx_ctx* ctx, double* dK, int64_t ld, int N, int Np, const double* dy);
+                       int lower_only, double* dOut, int64_t ld, int batch = 1, int64_t out_bs = 0,
+                       const ThetaDev* th = nullptr, int diag_sel = 0);
+int launch_augment(gpx_ctx* ctx, double* dK, int64_t ld, int N, int Np, const double* dy,
+                   int batch = 1, int64_t k_bs = 0, int64_t y_bs = 0);
 int launch_pad_identity(gpx_ctx* ctx, double* dA, int64_t ld, int n, int np);
 
 // gemm_f64.hip
@@ -202,6 +237,9 @@ struct GemmArgs {
   int kupper;  // k range ends at (tj_off + bx + 1) * 128 (B lower triangular, e.g. chol factor)
   int kchunk;  // split-K chunk (multiple of 16), 0 = no split
   int64_t c_split_stride;
+  int nsplit;  // grid.z = nsplit * batch (filled in by launch_gemm_nt)
+  int batch;   // independent problems per launch (0 or 1 = one); element b at base + b * *_bs
+  int64_t a_bs, b_bs, c_bs;
 };
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
                    int prof_cls, double work);
@@ -209,26 +247,29 @@ int mfma_peak(gpx_ctx* ctx, double* tflops);
 
 // potf2.hip
 int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo,
-                     int info_base);
+                     int info_base, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0);
 
 // linalg.hip
 int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,
-                int* dInfo);
+                int* dInfo, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0);
 int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_p, const double* dL,
                   int64_t ldl, const double* dLinv, int nblk, int upper_rows);
 int launch_set_identity(gpx_ctx* ctx, double* dA, int64_t ld, int np);
 int launch_lml_terms(gpx_ctx* ctx, const double* dL, int64_t ld, int N, double* dOut2);
 int launch_rowdot(gpx_ctx* ctx, const double* dV, int64_t ldv, int rows, int cols,
                   const double* dw, double kdiag, double* dmean, double* dvar,
-                  int col_start_by_row);
+                  int col_start_by_row, int batch = 1, int64_t v_bs = 0, int64_t w_bs = 0,
+                  int64_t out_bs = 0, const ThetaDev* th = nullptr);
 int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXnew, int M, int Mp,
                         const double* dPart, int splits, int64_t split_stride, int64_t ldp,
-                        double diag_add, double* dCov, int64_t ldc);
+                        double diag_add, double* dCov, int64_t ldc, int batch = 1,
+                        int64_t part_bs = 0, int64_t cov_bs = 0, const ThetaDev* th = nullptr);
 int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int N,
                          const double* dKinv, int64_t ld, const double* dalpha, double* dpart,
                          int* nblocks_out);
 int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals, double* dout);
 void sgp_release(gpx_ctx* ctx);
-int launch_add_mean(gpx_ctx* ctx, double* ddraws, int64_t ld, int n, int M, const double* dmean);
+int launch_add_mean(gpx_ctx* ctx, double* ddraws, int64_t ld, int n, int M, const double* dmean,
+                    int batch = 1, int64_t d_bs = 0, int64_t mean_bs = 0);
 
 } // namespace gpx

@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
   constexpr int PA = BM / RPP, PB_ = BN / RPP;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // panel / small GEMMs sit on the critical path of the look-ahead
-  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  // grid.z = batch entry * nsplit + split-K slab
+  const int bb = (g.batch > 1) ? blockIdx.z / g.nsplit : 0;
+  const int bz = blockIdx.z - bb * g.nsplit;
   // element coordinates of this tile in the caller's global tile frame (offsets given in 128-tiles)
   const int row0 = g.ti_off * 128 + by * BM, col0 = g.tj_off * 128 + bx * BN;
   if (g.lower && col0 > row0 + BM - 1) return; // entirely above the diagonal
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
   int kb = 0, ke = g.K;
   if (g.ktri) kb = row0 & ~(BK - 1);            // A rows are zero left of the diagonal (upper-triangular operand)
   if (g.kupper) ke = min(ke, col0 + BN);        // B rows are zero right of the diagonal (lower-triangular factor)
-  double* C = g.C;  // may alias A (in-place panel TRSM): no restrict here
+  double* C = g.C + (int64_t)bb * g.c_bs;  // may alias A (in-place panel TRSM): no restrict here
   if (g.kchunk > 0) {
     kb = max(kb, bz * g.kchunk);
     ke = min(ke, (bz + 1) * g.kchunk);
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
 
   // staging map: thread -> (row lr + RPP i, cols lc, lc + 1)
   const int lr = tid / TPR, lc = (tid % TPR) * 2;
-  const double* Ap = g.A + ((int64_t)by * BM + lr) * g.lda + kb + lc;
-  const double* Bp = g.B + ((int64_t)bx * BN + lr) * g.ldb + kb + lc;
+  const double* Ap = g.A + (int64_t)bb * g.a_bs + ((int64_t)by * BM + lr) * g.lda + kb + lc;
+  const double* Bp = g.B + (int64_t)bb * g.b_bs + ((int64_t)bx * BN + lr) * g.ldb + kb + lc;
   const int64_t a_step = (int64_t)RPP * g.lda, b_step = (int64_t)RPP * g.ldb;
 
   double* sA0 = smem;
@@ -185,7 +188,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
 }
 
 template <int TAG, int MT, int NT, int BK, bool DBUF>
-static int launch_variant(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits) {
+static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int tiles_n, int splits) {
+  GemmArgs g = g0;
+  g.nsplit = splits > 0 ? splits : 1;
+  if (g.batch < 1) g.batch = 1;
   static bool attr_set = false;
   constexpr size_t lds = gemm_lds_bytes<MT, NT, BK, DBUF>();
   if (!attr_set) {
@@ -194,7 +200,7 @@ static int launch_variant(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
     attr_set = true;
   }
   // tiles_m / tiles_n are given in 128-tiles
-  dim3 grid(tiles_n * (4 / NT), tiles_m * (4 / MT), splits > 0 ? splits : 1);
+  dim3 grid(tiles_n * (4 / NT), tiles_m * (4 / MT), g.nsplit * g.batch);
   gemm_nt_kernel<TAG, MT, NT, BK, DBUF><<<grid, 256, lds, ctx->s>>>(g);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
@@ -203,7 +209,7 @@ static int launch_variant(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
                    int prof_cls, double work) {
   if (tiles_m <= 0 || tiles_n <= 0) return 0;
-  ProfScope ps(ctx, prof_cls, work);
+  ProfScope ps(ctx, prof_cls, work * (g.batch > 1 ? g.batch : 1));
   if (prof_cls == GPX_PROF_GEMM_TRAILING) return launch_variant<1, 4, 4, 16, true>(ctx, g, tiles_m, tiles_n, splits);
   // latency-bound launches (too few 128x128 tiles to fill 256 CUs x 2): smaller workgroup tiles
   const int nsplit = splits > 0 ? splits : 1;

@@ -31,28 +31,39 @@ __device__ __forceinline__ double kernel_value(double r2, double scale) {
 }
 
 template <int KIND, int D>
-__global__ __launch_bounds__(256) void gram_kernel(KernelParams kp, const double* __restrict__ X,
+__global__ __launch_bounds__(256) void gram_kernel(KernelParams kpv, const double* __restrict__ X,
                                                    int n, int n_pad,
                                                    const double* __restrict__ Z, int m, int m_pad,
                                                    double diag_add, int add_diag, int lower_only,
-                                                   double* __restrict__ out, int64_t ld) {
+                                                   double* __restrict__ out, int64_t ld,
+                                                   int64_t out_bs, const ThetaDev* __restrict__ th,
+                                                   int diag_sel) {
   const int j0 = blockIdx.x * GT_COLS;
   const int i0 = blockIdx.y * GT_ROWS;
   if (lower_only && j0 > i0 + GT_ROWS - 1) return;
+  // batched launch: sample blockIdx.z reads its hyper-parameters from the device table
+  const ThetaDev* t = (th != nullptr) ? th + blockIdx.z : nullptr;
+  const double k_scale = t ? t->kp.scale : kpv.scale;
+  const double pi_over_p = t ? t->kp.pi_over_p : kpv.pi_over_p;
+  auto inv_ell = [&](int c) -> double { return t ? t->kp.inv_ell[c] : kpv.inv_ell[c]; };
+  if (t != nullptr) {
+    diag_add = (diag_sel == 1) ? t->diag_train : (diag_sel == 2 ? t->diag_pred : 0.0);
+    out += (int64_t)blockIdx.z * out_bs;
+  }
   __shared__ double sx[GT_ROWS * GPX_MAX_DIM];
   const int tid = threadIdx.x;
-  const int d = (D > 0) ? D : kp.d;
+  const int d = (D > 0) ? D : kpv.d; // structural: the same for every entry of a batch
   for (int idx = tid; idx < GT_ROWS * d; idx += 256) {
     const int r = idx / d, c = idx - r * d;
     const int i = i0 + r;
-    sx[idx] = (i < n) ? X[(int64_t)i * d + c] * (KIND == GPX_KERNEL_PERIODIC ? 1.0 : kp.inv_ell[c]) : 0.0;
+    sx[idx] = (i < n) ? X[(int64_t)i * d + c] * (KIND == GPX_KERNEL_PERIODIC ? 1.0 : inv_ell(c)) : 0.0;
   }
   const int j = j0 + 2 * tid;
   double z0[(D > 0) ? D : 1], z1[(D > 0) ? D : 1];
   if (D > 0) {
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-      const double zs = (KIND == GPX_KERNEL_PERIODIC) ? 1.0 : kp.inv_ell[c];
+      const double zs = (KIND == GPX_KERNEL_PERIODIC) ? 1.0 : inv_ell(c);
       z0[c] = (j < m) ? Z[(int64_t)j * D + c] * zs : 0.0;
       z1[c] = (j + 1 < m) ? Z[(int64_t)(j + 1) * D + c] * zs : 0.0;
     }
@@ -69,8 +80,8 @@ __global__ __launch_bounds__(256) void gram_kernel(KernelParams kp, const double
         const double x = sx[r * D + c];
         double a = x - z0[c], b = x - z1[c];
         if (KIND == GPX_KERNEL_PERIODIC) {
-          a = sin(a * kp.pi_over_p) * kp.inv_ell[c];
-          b = sin(b * kp.pi_over_p) * kp.inv_ell[c];
+          a = sin(a * pi_over_p) * inv_ell(c);
+          b = sin(b * pi_over_p) * inv_ell(c);
         }
         r20 = fma(a, a, r20);
         r21 = fma(b, b, r21);
@@ -78,20 +89,20 @@ __global__ __launch_bounds__(256) void gram_kernel(KernelParams kp, const double
     } else {
       for (int c = 0; c < d; ++c) {
         const double x = sx[r * d + c];
-        const double zs = (KIND == GPX_KERNEL_PERIODIC) ? 1.0 : kp.inv_ell[c];
+        const double zs = (KIND == GPX_KERNEL_PERIODIC) ? 1.0 : inv_ell(c);
         const double za = (j < m) ? Z[(int64_t)j * d + c] * zs : 0.0;
         const double zb = (j + 1 < m) ? Z[(int64_t)(j + 1) * d + c] * zs : 0.0;
         double a = x - za, b = x - zb;
         if (KIND == GPX_KERNEL_PERIODIC) {
-          a = sin(a * kp.pi_over_p) * kp.inv_ell[c];
-          b = sin(b * kp.pi_over_p) * kp.inv_ell[c];
+          a = sin(a * pi_over_p) * inv_ell(c);
+          b = sin(b * pi_over_p) * inv_ell(c);
         }
         r20 = fma(a, a, r20);
         r21 = fma(b, b, r21);
       }
     }
-    double v0 = kernel_value<KIND>(r20, kp.scale);
-    double v1 = kernel_value<KIND>(r21, kp.scale);
+    double v0 = kernel_value<KIND>(r20, k_scale);
+    double v1 = kernel_value<KIND>(r21, k_scale);
     if (add_diag) {
       if (i == j) v0 += diag_add;
       if (i == j + 1) v1 += diag_add;
@@ -111,27 +122,28 @@ __global__ __launch_bounds__(256) void gram_kernel(KernelParams kp, const double
 template <int KIND>
 static void gram_dispatch(const KernelParams& kp, dim3 grid, hipStream_t s, const double* X, int n,
                           int n_pad, const double* Z, int m, int m_pad, double diag_add,
-                          int add_diag, int lower_only, double* out, int64_t ld) {
+                          int add_diag, int lower_only, double* out, int64_t ld, int64_t out_bs,
+                          const ThetaDev* th, int diag_sel) {
   switch (kp.d) {
     case 1:
       gram_kernel<KIND, 1><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld);
+                                                 lower_only, out, ld, out_bs, th, diag_sel);
       break;
     case 2:
       gram_kernel<KIND, 2><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld);
+                                                 lower_only, out, ld, out_bs, th, diag_sel);
       break;
     case 3:
       gram_kernel<KIND, 3><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld);
+                                                 lower_only, out, ld, out_bs, th, diag_sel);
       break;
     case 4:
       gram_kernel<KIND, 4><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld);
+                                                 lower_only, out, ld, out_bs, th, diag_sel);
       break;
     default:
       gram_kernel<KIND, 0><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld);
+                                                 lower_only, out, ld, out_bs, th, diag_sel);
   }
 }
 
@@ -139,21 +151,23 @@ static void gram_dispatch(const KernelParams& kp, dim3 grid, hipStream_t s, cons
 // n_pad / m_pad are passed through dOut's caller as the padded extents via ld-sized rows.
 int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, int n_pad,
                        const double* dZ, int m, int m_pad, double diag_add, int add_diag,
-                       int lower_only, double* dOut, int64_t ld) {
+                       int lower_only, double* dOut, int64_t ld, int batch, int64_t out_bs,
+                       const ThetaDev* th, int diag_sel) {
   if (n_pad <= 0 || m_pad <= 0) return 0;
-  dim3 grid((m_pad + GT_COLS - 1) / GT_COLS, (n_pad + GT_ROWS - 1) / GT_ROWS);
+  if (batch > 1 && th == nullptr) return bad_arg(ctx, "batched Gram needs a device theta table");
+  dim3 grid((m_pad + GT_COLS - 1) / GT_COLS, (n_pad + GT_ROWS - 1) / GT_ROWS, batch > 1 ? batch : 1);
   // algorithmic bytes: 8*n*m written (+ inputs); SURVEY 8(d): a symmetric build may claim the
   // full 8 n m.
-  ProfScope ps(ctx, GPX_PROF_GRAM, 8.0 * (double)n * (double)m);
+  ProfScope ps(ctx, GPX_PROF_GRAM, 8.0 * (double)n * (double)m * (batch > 1 ? batch : 1));
   if (kp.kind == GPX_KERNEL_RBF)
     gram_dispatch<GPX_KERNEL_RBF>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
-                                  add_diag, lower_only, dOut, ld);
+                                  add_diag, lower_only, dOut, ld, out_bs, th, diag_sel);
   else if (kp.kind == GPX_KERNEL_PERIODIC)
     gram_dispatch<GPX_KERNEL_PERIODIC>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
-                                       add_diag, lower_only, dOut, ld);
+                                       add_diag, lower_only, dOut, ld, out_bs, th, diag_sel);
   else
     gram_dispatch<GPX_KERNEL_MATERN52>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
-                                       add_diag, lower_only, dOut, ld);
+                                       add_diag, lower_only, dOut, ld, out_bs, th, diag_sel);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -169,7 +183,10 @@ int launch_gram(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, c
 // Factoring the augmented matrix leaves w = L^-1 y in row N of the factor, so the forward
 // solve of the lml (NumPyro MVN log_prob's solve_triangular) costs no extra launch.
 __global__ __launch_bounds__(256) void augment_kernel(double* __restrict__ K, int64_t ld, int N,
-                                                      int Np, const double* __restrict__ y) {
+                                                      int Np, const double* __restrict__ y,
+                                                      int64_t k_bs, int64_t y_bs) {
+  K += (int64_t)blockIdx.z * k_bs;
+  y += (int64_t)blockIdx.z * y_bs;
   const int i = N + blockIdx.y;
   for (int j = blockIdx.x * 256 + threadIdx.x; j < Np; j += gridDim.x * 256) {
     double v;
@@ -181,9 +198,10 @@ __global__ __launch_bounds__(256) void augment_kernel(double* __restrict__ K, in
   }
 }
 
-int launch_augment(gpx_ctx* ctx, double* dK, int64_t ld, int N, int Np, const double* dy) {
-  dim3 grid(min(64, (Np + 255) / 256), Np - N);
-  augment_kernel<<<grid, 256, 0, ctx->s>>>(dK, ld, N, Np, dy);
+int launch_augment(gpx_ctx* ctx, double* dK, int64_t ld, int N, int Np, const double* dy, int batch,
+                   int64_t k_bs, int64_t y_bs) {
+  dim3 grid(min(64, (Np + 255) / 256), Np - N, batch > 1 ? batch : 1);
+  augment_kernel<<<grid, 256, 0, ctx->s>>>(dK, ld, N, Np, dy, k_bs, y_bs);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }

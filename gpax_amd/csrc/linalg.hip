@@ -42,17 +42,29 @@ static inline GemmArgs gemm_args(const double* A, int64_t lda, const double* B, 
 // P(k+1) only needs U1(k), so it runs concurrently with U2(k) — the latency-bound panel work
 // hides behind the big SYRK, and U2(k) follows U2(k-1) with no gap.  Every C tile still receives
 // its updates in a fixed order (U2(k-1) before U1(k) by event), so results are bit-reproducible.
+struct BatchStrides {
+  int batch;
+  int64_t a_bs, linv_bs;
+};
+static inline void set_batch(GemmArgs& g, int batch, int64_t a_bs, int64_t b_bs, int64_t c_bs) {
+  g.batch = batch;
+  g.a_bs = a_bs;
+  g.b_bs = b_bs;
+  g.c_bs = c_bs;
+}
+
 static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob, int oe,
-                       double* dLinv, int* dInfo) {
+                       double* dLinv, int* dInfo, const BatchStrides& bs) {
   for (int kb = ob; kb < oe; ++kb) {
     double* Akk = dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE;
     double* Li = dLinv + (int64_t)kb * TILE * TILE;
-    GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE));
+    GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs));
     const int below = nblk - kb - 1 + extra;
     if (below <= 0) continue;
     double* Apan = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)kb * TILE;
     { // panel TRSM, in place: A[kb+1.., kb] <- A[kb+1.., kb] * Linv^T
       GemmArgs g = gemm_args(Apan, lda, Li, TILE, Apan, lda, TILE, 1.0, 0.0);
+      set_batch(g, bs.batch, bs.a_bs, bs.linv_bs, bs.a_bs);
       GPX_TRY(launch_gemm_nt(ctx, g, below, 1, 0, GPX_PROF_GEMM_OTHER,
                              2.0 * below * TILE * (double)TILE * TILE));
     }
@@ -60,6 +72,7 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
     if (inner_cols > 0) { // update the rest of the outer block's columns (lower tiles)
       double* Cin = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)(kb + 1) * TILE;
       GemmArgs g = gemm_args(Apan, lda, Apan, lda, Cin, lda, TILE, -1.0, 1.0);
+      set_batch(g, bs.batch, bs.a_bs, bs.a_bs, bs.a_bs);
       g.lower = 1;
       g.ti_off = kb + 1;
       g.tj_off = kb + 1;
@@ -72,7 +85,7 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
 
 // C[rows r0.., cols c0..c1) -= Pan[rows, ob..oe) * Pan[cols, ob..oe)^T, lower tiles only.
 static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob,
-                           int oe, int r0, int c0, int c1, int prof_cls) {
+                           int oe, int r0, int c0, int c1, int prof_cls, const BatchStrides& bs) {
   const int rows = nblk + extra - r0, cols = c1 - c0;
   if (rows <= 0 || cols <= 0) return 0;
   const int K = (oe - ob) * TILE;
@@ -80,6 +93,7 @@ static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int 
   const double* PanC = dA + (int64_t)c0 * TILE * lda + (int64_t)ob * TILE;
   double* Ctr = dA + (int64_t)r0 * TILE * lda + (int64_t)c0 * TILE;
   GemmArgs g = gemm_args(PanR, lda, PanC, lda, Ctr, lda, K, -1.0, 1.0);
+  set_batch(g, bs.batch, bs.a_bs, bs.a_bs, bs.a_bs);
   g.lower = 1;
   g.ti_off = r0;
   g.tj_off = c0;
@@ -95,7 +109,8 @@ static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int 
 }
 
 int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,
-                int* dInfo) {
+                int* dInfo, int batch, int64_t a_bs, int64_t linv_bs) {
+  const BatchStrides bs{batch > 1 ? batch : 1, a_bs, linv_bs};
   const int nblk = np / TILE;
   const int nouter = (nblk + OUTER_TILES - 1) / OUTER_TILES;
   while ((int)ctx->evP.size() < nouter + 1) {
@@ -116,7 +131,7 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     const int oe2 = (oe + OUTER_TILES < nblk) ? oe + OUTER_TILES : nblk;
     // P(k) on the panel stream (it follows U1(k-1) there, in stream order)
     ctx->s = span;
-    rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo);
+    rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs);
     if (rc < 0) break;
     GPX_HIP(ctx, hipEventRecord(ctx->evP[k], span));
     GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
@@ -126,10 +141,10 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
       // disjoint C tiles, so the big SYRKs run back to back with no U1 gap between them.
       if (k > 0) GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
       // (profiled / prioritised with the panel GEMMs: it is latency-critical and overlaps U2)
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, oe2, GPX_PROF_GEMM_OTHER);
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, oe2, GPX_PROF_GEMM_OTHER, bs);
       if (rc < 0) break;
       ctx->s = smain;
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe2, oe2, nblk, GPX_PROF_GEMM_TRAILING);
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe2, oe2, nblk, GPX_PROF_GEMM_TRAILING, bs);
       GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain));
     }
   }
@@ -249,10 +264,16 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ 
                                                      const double* __restrict__ w, double kdiag,
                                                      double* __restrict__ mean,
                                                      double* __restrict__ var,
-                                                     int col_start_by_row) {
+                                                     int col_start_by_row, int64_t v_bs,
+                                                     int64_t w_bs, int64_t out_bs,
+                                                     const ThetaDev* __restrict__ th) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wave;
   if (r >= rows) return;
+  const int bb = blockIdx.y; // batch entry
+  V += (int64_t)bb * v_bs;
+  w += (int64_t)bb * w_bs;
+  if (th != nullptr) kdiag = th[bb].kdiag_pred;
   const double* v = V + (int64_t)r * ldv;
   double m = 0.0, q = 0.0;
   int k0 = col_start_by_row ? (r & ~63) : 0;
@@ -264,17 +285,19 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ 
   m = wave_sum(m);
   q = wave_sum(q);
   if (lane == 0) {
-    if (mean) mean[r] = m;
-    if (var) var[r] = kdiag - q;
+    if (mean) mean[(int64_t)bb * out_bs + r] = m;
+    if (var) var[(int64_t)bb * out_bs + r] = kdiag - q;
   }
 }
 
 int launch_rowdot(gpx_ctx* ctx, const double* dV, int64_t ldv, int rows, int cols,
                   const double* dw, double kdiag, double* dmean, double* dvar,
-                  int col_start_by_row) {
+                  int col_start_by_row, int batch, int64_t v_bs, int64_t w_bs, int64_t out_bs,
+                  const ThetaDev* th) {
   if (rows <= 0) return 0;
-  rowdot_kernel<<<(rows + 3) / 4, 256, 0, ctx->s>>>(dV, ldv, rows, cols, dw, kdiag, dmean,
-                                                         dvar, col_start_by_row);
+  dim3 grid((rows + 3) / 4, batch > 1 ? batch : 1);
+  rowdot_kernel<<<grid, 256, 0, ctx->s>>>(dV, ldv, rows, cols, dw, kdiag, dmean, dvar,
+                                          col_start_by_row, v_bs, w_bs, out_bs, th);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -290,16 +313,25 @@ __device__ __forceinline__ double kval_rt(int kind, double r2, double scale) {
 // cov[a][b] = k_pp(a, b) - sum_z P_z[max(a,b)][min(a,b)]   (a, b < M); identity padding.
 // k_pp = kernel(X_new, X_new, theta, noise_p, jitter)  (gpax/models/gp.py:267) evaluated on
 // the fly; the split-K slabs only hold lower tiles.
-__global__ __launch_bounds__(256) void cov_finalize_kernel(KernelParams kp,
+__global__ __launch_bounds__(256) void cov_finalize_kernel(KernelParams kpv,
                                                            const double* __restrict__ Xn, int M,
                                                            int Mp, const double* __restrict__ P,
                                                            int splits, int64_t split_stride,
                                                            int64_t ldp, double diag_add,
-                                                           double* __restrict__ Cov, int64_t ldc) {
+                                                           double* __restrict__ Cov, int64_t ldc,
+                                                           int64_t part_bs, int64_t cov_bs,
+                                                           const ThetaDev* __restrict__ th) {
   const int b = blockIdx.x * 64 + (threadIdx.x & 63);
   const int a0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
   if (b >= Mp) return;
-  const int d = kp.d;
+  const ThetaDev* t = (th != nullptr) ? th + blockIdx.z : nullptr; // batch entry blockIdx.z
+  const int d = kpv.d, kind = kpv.kind;                            // structural, same for the batch
+  const double k_scale = t ? t->kp.scale : kpv.scale;
+  const double pi_over_p = t ? t->kp.pi_over_p : kpv.pi_over_p;
+  auto inv_ell = [&](int c) -> double { return t ? t->kp.inv_ell[c] : kpv.inv_ell[c]; };
+  if (t != nullptr) diag_add = t->diag_pred;
+  P += (int64_t)blockIdx.z * part_bs;
+  Cov += (int64_t)blockIdx.z * cov_bs;
   for (int t = 0; t < 4; ++t) {
     const int a = a0 + t;
     if (a >= Mp) return;
@@ -308,10 +340,10 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(KernelParams kp,
       double r2 = 0.0;
       for (int c = 0; c < d; ++c) {
         double u = Xn[(int64_t)a * d + c] - Xn[(int64_t)b * d + c];
-        u = (kp.kind == GPX_KERNEL_PERIODIC) ? sin(u * kp.pi_over_p) * kp.inv_ell[c] : u * kp.inv_ell[c];
+        u = (kind == GPX_KERNEL_PERIODIC) ? sin(u * pi_over_p) * inv_ell(c) : u * inv_ell(c);
         r2 = fma(u, u, r2);
       }
-      v = kval_rt(kp.kind, r2, kp.scale);
+      v = kval_rt(kind, r2, k_scale);
       if (a == b) v += diag_add;
       const int hi = a > b ? a : b, lo = a > b ? b : a;
       double acc = 0.0;
@@ -326,10 +358,11 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(KernelParams kp,
 
 int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXnew, int M, int Mp,
                         const double* dPart, int splits, int64_t split_stride, int64_t ldp,
-                        double diag_add, double* dCov, int64_t ldc) {
-  dim3 grid((Mp + 63) / 64, (Mp + 15) / 16);
+                        double diag_add, double* dCov, int64_t ldc, int batch, int64_t part_bs,
+                        int64_t cov_bs, const ThetaDev* th) {
+  dim3 grid((Mp + 63) / 64, (Mp + 15) / 16, batch > 1 ? batch : 1);
   cov_finalize_kernel<<<grid, 256, 0, ctx->s>>>(kp, dXnew, M, Mp, dPart, splits, split_stride,
-                                                     ldp, diag_add, dCov, ldc);
+                                                ldp, diag_add, dCov, ldc, part_bs, cov_bs, th);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -446,16 +479,20 @@ int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals
 
 // draws[s][a] += mean[a]
 __global__ __launch_bounds__(256) void add_mean_kernel(double* __restrict__ D, int64_t ld, int n,
-                                                       int M, const double* __restrict__ mean) {
+                                                       int M, const double* __restrict__ mean,
+                                                       int64_t d_bs, int64_t mean_bs) {
   const int a = blockIdx.x * 256 + threadIdx.x;
   const int s = blockIdx.y;
+  D += (int64_t)blockIdx.z * d_bs;
+  mean += (int64_t)blockIdx.z * mean_bs;
   if (a < M && s < n) D[(int64_t)s * ld + a] += mean[a];
 }
 
-int launch_add_mean(gpx_ctx* ctx, double* ddraws, int64_t ld, int n, int M, const double* dmean) {
+int launch_add_mean(gpx_ctx* ctx, double* ddraws, int64_t ld, int n, int M, const double* dmean,
+                    int batch, int64_t d_bs, int64_t mean_bs) {
   if (n <= 0) return 0;
-  dim3 grid((M + 255) / 256, n);
-  add_mean_kernel<<<grid, 256, 0, ctx->s>>>(ddraws, ld, n, M, dmean);
+  dim3 grid((M + 255) / 256, n, batch > 1 ? batch : 1);
+  add_mean_kernel<<<grid, 256, 0, ctx->s>>>(ddraws, ld, n, M, dmean, d_bs, mean_bs);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -78,7 +78,11 @@ __device__ __forceinline__ void potf2_block(double (&S)[8][8], double* colbuf, d
 }
 
 __global__ __launch_bounds__(256, 1) void potf2_inv_kernel(double* A, int64_t lda, double* Linv,
-                                                           int* info, int info_base) {
+                                                           int* info, int info_base, int64_t a_bs,
+                                                           int64_t linv_bs) {
+  A += (int64_t)blockIdx.x * a_bs; // one workgroup per batch entry
+  Linv += (int64_t)blockIdx.x * linv_bs;
+  if (info != nullptr) info += blockIdx.x;
   // latency-critical serial kernel of the factorisation: win issue arbitration against the
   // trailing-update waves it shares a CU with under look-ahead
   __builtin_amdgcn_s_setprio(3);
@@ -273,7 +277,10 @@ __device__ __forceinline__ void diag16(double* D, double* Dinv, double* col /* 2
 }
 
 __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t lda, double* Linv, int* info,
-                                                            int info_base) {
+                                                            int info_base, int64_t a_bs, int64_t linv_bs) {
+  A += (int64_t)blockIdx.x * a_bs; // one workgroup per batch entry
+  Linv += (int64_t)blockIdx.x * linv_bs;
+  if (info != nullptr) info += blockIdx.x;
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* Pbuf = lds;            // 8 tiles: column-p panel (raw -> L)
@@ -373,7 +380,9 @@ __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t l
 } // namespace gpx
 
 namespace gpx {
-int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo, int info_base) {
+int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo, int info_base,
+                     int batch, int64_t a_bs, int64_t linv_bs) {
+  const int nb = batch > 1 ? batch : 1;
   static int use_tile = -1;
   if (use_tile < 0) {
     const char* e = getenv("GPX_POTF2");
@@ -382,11 +391,11 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS_BYTES));
   }
   // algorithmic flops: factor n^3/3 + triangular inverse n^3/3
-  ProfScope ps(ctx, GPX_PROF_POTF2, 2.0 * PB * (double)PB * PB / 3.0);
+  ProfScope ps(ctx, GPX_PROF_POTF2, nb * 2.0 * PB * (double)PB * PB / 3.0);
   if (use_tile)
-    potf2_tile_kernel<<<1, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base);
+    potf2_tile_kernel<<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
   else
-    potf2_inv_kernel<<<1, 256, POTF2_LDS_BYTES, ctx->s>>>(dA, lda, dLinv, dInfo, info_base);
+    potf2_inv_kernel<<<nb, 256, POTF2_LDS_BYTES, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }

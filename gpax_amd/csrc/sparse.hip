@@ -21,9 +21,6 @@
 
 namespace gpx {
 
-int launch_gram_padded(gpx_ctx*, const KernelParams&, const double*, int, int, const double*, int, int, double, int,
-                       int, double*, int64_t);
-
 // ---- small kernels ---------------------------------------------------------------------------
 
 // out (cols x rows, ldo) = in^T (rows x cols, ldi); 32x32 tiles through LDS.

@@ -102,8 +102,11 @@ int gpx_posterior(gpx_ctx* ctx, const double* Xnew, int M, double noise_p, doubl
 int gpx_mvn_draw(gpx_ctx* ctx, const double* eps, int n, double* out, int* info);
 
 /* ---- predictive sweep: ExactGP.predict, gpax/models/gp.py:351-399 -------------------------
- * The jax.vmap over S posterior samples, run as a device-resident loop (one theta at a
- * time; nothing S*N*N is ever materialised).  For sample s:
+ * The jax.vmap over S posterior samples, run as a device-resident loop over batches of B
+ * samples: the batch is a grid dimension of every launch (B is picked from N and free HBM,
+ * B = 1 at N = 16384, 256 at N <= 1024; GPX_SWEEP_BATCH forces it), so at most B*N*N is
+ * materialised and small-N sweeps are not launch-bound.  Results do not depend on B.
+ * For sample s:
  *   theta_s = (ells[s*d .. s*d+d), scales[s], noises[s]);
  *   yres_s  = yres + s*yres_stride (yres_stride = 0 when no mean function);
  *   mean_s, cov_s as gpx_posterior with noise_p = noiseless ? 0 : noises[s];
@@ -132,6 +135,10 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
 int gpx_sgp_posterior(gpx_ctx* ctx, int kind, const double* ell, double scale, double noise, double jitter,
                       const double* Xu, int Mi, const double* yres, const double* Xnew, int Ms, double noise_p,
                       double* mean, double* cov, double* var, int* info);
+
+/* Sweep statistics since gpx_init: batches launched, samples processed, and the batch size B
+ * chosen by the most recent sweep. */
+int gpx_sweep_stats(gpx_ctx* ctx, int64_t* batches, int64_t* samples, int* last_batch);
 
 /* ---- measurement hooks (bench.py / profiles) ----------------------------------------------
  * When enabled, HIP events bracket every launch of the profiled kernel classes on the

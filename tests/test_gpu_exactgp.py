@@ -141,3 +141,40 @@ def test_full_size_roundtrip_properties(engine):
     K_rows[np.arange(len(sub)), sub] += params["noise"] + 1e-6
     assert relerr(K_rows @ alpha, y[sub]) < 1e-8
     assert np.all(var > 0) and np.allclose(var, np.diag(cov), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind,name", KINDS)
+@pytest.mark.parametrize("strided", [False, True])
+def test_batched_sweep_is_independent_of_batch_size(engine, kind, name, strided, monkeypatch):
+    # the vmap over samples runs as a grid dimension (B samples per launch): every sample's arithmetic is the
+    # single-sample arithmetic, so results must be BIT-identical for any B, including ragged last batches
+    N, d, M, S, n = 300, 2, 70, 11, 2
+    X, y, Xnew, params = ref.synthetic_problem(N, d, M, seed=21)
+    th = ref.synthetic_theta_samples(S, d, seed=22)
+    rng = np.random.default_rng(23)
+    eps = rng.standard_normal((S, n, M))
+    yres = y[None, :] + 0.01 * rng.standard_normal((S, N)) if strided else y
+    th["noise"][4] = -5.0  # a non-PD sample in the middle of a batch must only poison itself
+    engine.set_train(X)
+    outs = {}
+    for B in ("1", "4", "11", "0"):
+        monkeypatch.setenv("GPX_SWEEP_BATCH", B)
+        before = engine.sweep_stats()
+        outs[B] = engine.predict_sweep(kind, th["k_length"], th["k_scale"], th["noise"], yres, Xnew, False, 1e-6, eps)
+        nb, ns, last = engine.sweep_stats()
+        assert ns - before[1] == S
+        assert last == (int(B) if B != "0" else S)  # auto: 2 (16384/Np)^2 >> S at this size
+        assert nb - before[0] == -(-S // last)
+    for B in ("4", "11", "0"):
+        for a, b in zip(outs["1"], outs[B]):
+            np.testing.assert_array_equal(a, b)
+    means, draws, infos = outs["0"]
+    assert infos[4] != 0 and np.all(np.isnan(means[4])) and np.all(np.isnan(draws[4]))
+    ok = [s for s in range(S) if s != 4]
+    assert np.all(infos[ok] == 0)
+    for s in ok[:4]:
+        p = {"k_length": th["k_length"][s], "k_scale": th["k_scale"][s], "noise": th["noise"][s]}
+        ys = yres[s] if strided else y
+        m_ref, c_ref = ref.get_mvn_posterior(X, ys, Xnew, p, False, kernel=name, jitter=1e-6, route="inv")
+        assert relerr(means[s], m_ref) < 1e-8
+        assert relerr(draws[s], ref.mvn_sample(m_ref, c_ref, eps[s])) < 1e-6
