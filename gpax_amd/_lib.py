@@ -58,6 +58,8 @@ def load_library() -> C.CDLL:
         "gpx_set_train": (C.c_int, [vp, _dp, C.c_int, C.c_int]),
         "gpx_factor": (C.c_int, [vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _ip]),
         "gpx_lml_grad": (C.c_int, [vp, _dp, _dp, _dp, _dp]),
+        "gpx_fit_batch": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, C.c_int64, _dp, _ip, _dp,
+                                    _dp]),
         "gpx_posterior": (C.c_int, [vp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]),
         "gpx_mvn_draw": (C.c_int, [vp, _dp, C.c_int, _dp, _ip]),
         "gpx_predict_sweep": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _dp,
@@ -86,7 +88,7 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = (
     "gpx_init gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train "
-    "gpx_factor gpx_lml_grad gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
+    "gpx_factor gpx_lml_grad gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
     "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf"
@@ -220,6 +222,32 @@ class Engine:
         self._check(self._lib.gpx_lml_grad(self._ctx, _ptr(g_ell), C.byref(g_scale), C.byref(g_noise),
                                            _ptr(alpha)), "gpx_lml_grad")
         return g_ell, g_scale.value, g_noise.value, alpha
+
+    def fit_batch(self, kind: int, ells, scales, noises, jitter: float, yres, want_grad: bool = True):
+        """gpx_factor + gpx_lml_grad for B hyper-parameter vectors in one launch sequence.
+        ells (B, n_ell); yres (N,) shared or (B, N).  Returns lml (B,), info (B,), grad (B, n_ell + 2) or None
+        ([d/d ell.., d/d scale, d/d noise]), alpha (B, N) or None."""
+        ells = _f64(ells)
+        B = ells.shape[0]
+        ne = n_ell(kind, self.d)
+        ells = _f64(ells, (B, ne))
+        scales, noises = _f64(scales, (B,)), _f64(noises, (B,))
+        yres = _f64(yres)
+        stride = 0
+        if yres.ndim == 2:
+            yres = _f64(yres, (B, self.N))
+            stride = self.N
+        else:
+            yres = _f64(yres, (self.N,))
+        lml = np.empty(B)
+        info = np.zeros(B, dtype=np.int32)
+        grad = np.empty((B, ne + 2)) if want_grad else None
+        alpha = np.empty((B, self.N)) if want_grad else None
+        self._last_kind = kind
+        self._check(self._lib.gpx_fit_batch(self._ctx, kind, B, _ptr(ells), _ptr(scales), _ptr(noises), float(jitter),
+                                            _ptr(yres), stride, _ptr(lml), info.ctypes.data_as(_ip), _ptr(grad),
+                                            _ptr(alpha)), "gpx_fit_batch")
+        return lml, info, grad, alpha
 
     def posterior(self, Xnew, noise_p: float, jitter: float, want_cov: bool = True, want_var: bool = False):
         Xnew = _f64(Xnew)

@@ -74,6 +74,8 @@ BatchPlan make_plan(gpx_ctx* ctx, int B, int n_pad, bool fused) {
   p.eps_bs = (int64_t)n_pad * ctx->ldc;
   p.info_train = sc_int(ctx) + SI_TRAIN;
   p.info_cov = sc_int(ctx) + SI_COV;
+  p.scal = ctx->scal.d();
+  p.scal_bs = 0;
   return p;
 }
 
@@ -97,7 +99,7 @@ int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
   }
   GPX_HIP(ctx, hipMemsetAsync(bp.info_train, 0, (size_t)B * sizeof(int), ctx->stream));
   GPX_TRY(potrf_lower(ctx, K, ctx->ldk, Np, extra, ctx->Linv.d(), bp.info_train, B, bp.k_bs, bp.linv_bs));
-  if (want_lml) GPX_TRY(launch_lml_terms(ctx, K, ctx->ldk, N, ctx->scal.d() + SC_QUAD));
+  if (want_lml) GPX_TRY(launch_lml_terms(ctx, K, ctx->ldk, N, bp.scal + SC_QUAD, B, bp.k_bs, bp.scal_bs));
   ctx->factored = (B == 1);
   ctx->fused_vt = fused;
   ctx->have_post = false;
@@ -106,20 +108,22 @@ int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
 int dev_factor(gpx_ctx* ctx, bool fused) { return dev_factor(ctx, fused, make_plan(ctx, 1, 0, fused), true); }
 
 // L^-T (upper) into W, K^-1 = L^-T L^-1 (lower) over K, alpha = L^-T w, gradient contraction.
-int dev_grad(gpx_ctx* ctx) {
-  const int N = ctx->N;
+// Per sample b the results land in bp.scal + b * bp.scal_bs: [quad, sumlog, grad...].
+int dev_grad(gpx_ctx* ctx, const BatchPlan& bp) {
+  const int N = ctx->N, B = bp.B;
   const int nt = (N + TILE - 1) / TILE; // tiles that carry real rows (excludes a pure aug tile)
   const int n128 = nt * TILE;
-  GPX_TRY(ensure(ctx, ctx->W, (size_t)ctx->Np * ctx->ldk * sizeof(double)));
-  GPX_TRY(ensure(ctx, ctx->alpha, (size_t)ctx->Np * sizeof(double)));
+  const int64_t w_bs = (int64_t)ctx->Np * ctx->ldk, alpha_bs = ctx->Np;
+  GPX_TRY(ensure(ctx, ctx->W, (size_t)B * w_bs * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->alpha, (size_t)B * alpha_bs * sizeof(double)));
   double* W = ctx->W.d();
   double* K = ctx->K.d();
-  GPX_TRY(launch_set_identity(ctx, W, ctx->ldk, n128));
-  GPX_TRY(trsm_right_lt(ctx, W, ctx->ldk, nt, K, ctx->ldk, ctx->Linv.d(), nt, 1));
+  GPX_TRY(launch_set_identity(ctx, W, ctx->ldk, n128, B, w_bs));
+  GPX_TRY(trsm_right_lt(ctx, W, ctx->ldk, nt, K, ctx->ldk, ctx->Linv.d(), nt, 1, B, w_bs, bp.k_bs, bp.linv_bs));
   // alpha_i = sum_{k>=i} W[i][k] w[k], w = row N of the augmented factor (read before K is
   // overwritten by K^-1)
   GPX_TRY(launch_rowdot(ctx, W, ctx->ldk, N, N, K + (int64_t)N * ctx->ldk, 0.0, ctx->alpha.d(),
-                        nullptr, 1));
+                        nullptr, 1, B, w_bs, bp.k_bs, alpha_bs, nullptr));
   {
     GemmArgs g{};
     g.A = W;
@@ -133,18 +137,23 @@ int dev_grad(gpx_ctx* ctx) {
     g.beta = 0.0;
     g.lower = 1;
     g.ktri = 1;
+    g.batch = B;
+    g.a_bs = w_bs;
+    g.b_bs = w_bs;
+    g.c_bs = bp.k_bs;
     const double n = (double)n128;
     GPX_TRY(launch_gemm_nt(ctx, g, nt, nt, 0, GPX_PROF_GEMM_OTHER, n * n * n / 3.0));
   }
   const int nt64 = (N + 63) / 64;
-  GPX_TRY(ensure(ctx, ctx->part, (size_t)nt64 * (nt64 + 1) / 2 * (GPX_MAX_DIM + 3) * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->part, (size_t)B * nt64 * (nt64 + 1) / 2 * (GPX_MAX_DIM + 3) * sizeof(double)));
   int nblocks = 0;
   GPX_TRY(launch_grad_contract(ctx, ctx->theta, ctx->X.d(), N, K, ctx->ldk, ctx->alpha.d(),
-                               ctx->part.d(), &nblocks));
-  GPX_TRY(launch_grad_reduce(ctx, ctx->part.d(), nblocks, n_ell(ctx->theta) + 2, ctx->scal.d() + SC_GRAD));
+                               ctx->part.d(), &nblocks, B, bp.k_bs, alpha_bs, bp.th));
+  GPX_TRY(launch_grad_reduce(ctx, ctx->part.d(), nblocks, n_ell(ctx->theta) + 2, bp.scal + SC_GRAD, B, bp.scal_bs));
   ctx->factored = false; // K now holds K^-1
   return 0;
 }
+int dev_grad(gpx_ctx* ctx) { return dev_grad(ctx, make_plan(ctx, 1, 0, false)); }
 
 int set_xnew(gpx_ctx* ctx, const double* Xnew, int M) {
   if (M < 1) return bad_arg(ctx, "M must be >= 1");
@@ -497,7 +506,7 @@ void gpx_destroy(gpx_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->X,    &ctx->K,   &ctx->W,       &ctx->Linv,   &ctx->yres, &ctx->scal,
                       &ctx->part, &ctx->alpha, &ctx->Xnew,  &ctx->Vt,     &ctx->Cov,  &ctx->CovLinv,
                       &ctx->SplitK, &ctx->mean, &ctx->var,  &ctx->eps,    &ctx->draws, &ctx->tA,
-                      &ctx->tB,   &ctx->tC,  &ctx->thtab,   &ctx->binfo};
+                      &ctx->tB,   &ctx->tC,  &ctx->thtab,   &ctx->binfo, &ctx->bscal, &ctx->byres};
     for (DevBuf* b : bufs) b->release();
     sgp_release(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -629,6 +638,75 @@ int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* gra
     for (int c = 0; c < ne; ++c) grad_ell[c] = h[c];
   if (grad_scale) *grad_scale = h[ne];
   if (grad_noise) *grad_noise = h[ne + 1];
+  return 0;
+}
+
+int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const double* scales,
+                  const double* noises, double jitter, const double* yres, int64_t yres_stride,
+                  double* lml, int* info, double* grad, double* alpha) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (ctx->N < 1) return bad_arg(ctx, "gpx_set_train must be called first");
+  if (B < 0) return bad_arg(ctx, "negative batch");
+  if (B == 0) return 0;
+  if (!ells || !scales || !noises || !yres || !lml) return bad_arg(ctx, "null pointer");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  const int N = ctx->N;
+  constexpr int SB = 32; // doubles per sample in bscal
+  SweepIO io;
+  io.kind = kind;
+  io.S = B;
+  io.jitter = jitter;
+  io.ells = ells;
+  io.scales = scales;
+  io.noises = noises;
+  ctx->jitter = jitter;
+  GPX_TRY(fill_theta_table(ctx, io));
+  BatchPlan bp = make_plan(ctx, B, 0, false);
+  bp.th = static_cast<const ThetaDev*>(ctx->thtab.p);
+  GPX_TRY(ensure(ctx, ctx->binfo, (size_t)2 * B * sizeof(int)));
+  GPX_TRY(ensure(ctx, ctx->bscal, (size_t)B * SB * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->byres, (size_t)B * N * sizeof(double)));
+  bp.info_train = ctx->binfo.i();
+  bp.info_cov = ctx->binfo.i() + B;
+  bp.scal = ctx->bscal.d();
+  bp.scal_bs = SB;
+  if (yres_stride != 0) {
+    GPX_HIP(ctx, hipMemcpy2DAsync(ctx->byres.d(), (size_t)N * sizeof(double), yres,
+                                  (size_t)yres_stride * sizeof(double), (size_t)N * sizeof(double), B,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    bp.yres = ctx->byres.d();
+    bp.y_bs = N;
+  } else {
+    GPX_HIP(ctx, hipMemcpyAsync(ctx->yres.d(), yres, (size_t)N * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->stream));
+    bp.yres = ctx->yres.d();
+    bp.y_bs = 0;
+  }
+  GPX_TRY(dev_factor(ctx, false, bp, true));
+  const int ne = n_ell(ctx->theta);
+  if (grad) GPX_TRY(dev_grad(ctx, bp));
+  ctx->h_bscal.resize((size_t)B * SB);
+  ctx->h_binfo.resize((size_t)B);
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->h_bscal.data(), ctx->bscal.d(), (size_t)B * SB * sizeof(double),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->h_binfo.data(), bp.info_train, (size_t)B * sizeof(int),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  if (grad && alpha)
+    GPX_HIP(ctx, hipMemcpy2DAsync(alpha, (size_t)N * sizeof(double), ctx->alpha.d(),
+                                  (size_t)ctx->Np * sizeof(double), (size_t)N * sizeof(double), B,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->factored = false;
+  ctx->have_post = false;
+  for (int b = 0; b < B; ++b) {
+    int hinfo = ctx->h_binfo[(size_t)b];
+    if (hinfo > N) hinfo = 0; // a failure at the augmentation pivot itself is not a failure of K
+    if (info) info[b] = hinfo;
+    const double* h = ctx->h_bscal.data() + (size_t)b * SB;
+    lml[b] = (hinfo != 0) ? NAN : (-0.5 * h[SC_QUAD] - h[SC_SUMLOG] - 0.5 * N * LOG_2PI);
+    if (grad)
+      for (int c = 0; c < ne + 2; ++c) grad[(int64_t)b * (ne + 2) + c] = (hinfo != 0) ? NAN : h[SC_GRAD + c];
+  }
   return 0;
 }
 

@@ -86,6 +86,8 @@ struct BatchPlan {
   int64_t eps_bs = 0;                                // eps, draws
   int* info_train = nullptr;                         // B ints each
   int* info_cov = nullptr;
+  double* scal = nullptr; // per sample [quad, sumlog, grad(ell.., scale, noise)], stride scal_bs
+  int64_t scal_bs = 0;
 };
 
 struct ProfAcc {
@@ -143,6 +145,10 @@ struct gpx_ctx {
   // ---- batched sweep state (gpx_predict_sweep / gpx_sweep_resident) -----------------------
   gpx::DevBuf thtab;   // S x ThetaDev
   gpx::DevBuf binfo;   // 2 x B ints (train / cov pivots of the batch in flight)
+  gpx::DevBuf bscal;   // B x 32 doubles: lml pieces + gradient of every entry of a fit batch
+  gpx::DevBuf byres;   // B x N residuals of a fit batch
+  std::vector<double> h_bscal;
+  std::vector<int> h_binfo;
   std::vector<gpx::ThetaDev> h_thtab;           // host image of thtab (outlives the async upload)
   int64_t sweep_batches = 0, sweep_samples = 0; // statistics: batches launched, samples processed
   int last_batch = 0;                           // samples per launch chosen by the last sweep
@@ -253,9 +259,11 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
 int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,
                 int* dInfo, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0);
 int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_p, const double* dL,
-                  int64_t ldl, const double* dLinv, int nblk, int upper_rows);
-int launch_set_identity(gpx_ctx* ctx, double* dA, int64_t ld, int np);
-int launch_lml_terms(gpx_ctx* ctx, const double* dL, int64_t ld, int N, double* dOut2);
+                  int64_t ldl, const double* dLinv, int nblk, int upper_rows, int batch = 1,
+                  int64_t b_bs = 0, int64_t l_bs = 0, int64_t linv_bs = 0);
+int launch_set_identity(gpx_ctx* ctx, double* dA, int64_t ld, int np, int batch = 1, int64_t a_bs = 0);
+int launch_lml_terms(gpx_ctx* ctx, const double* dL, int64_t ld, int N, double* dOut2, int batch = 1,
+                     int64_t l_bs = 0, int64_t out_bs = 0);
 int launch_rowdot(gpx_ctx* ctx, const double* dV, int64_t ldv, int rows, int cols,
                   const double* dw, double kdiag, double* dmean, double* dvar,
                   int col_start_by_row, int batch = 1, int64_t v_bs = 0, int64_t w_bs = 0,
@@ -266,8 +274,10 @@ int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXne
                         int64_t part_bs = 0, int64_t cov_bs = 0, const ThetaDev* th = nullptr);
 int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int N,
                          const double* dKinv, int64_t ld, const double* dalpha, double* dpart,
-                         int* nblocks_out);
-int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals, double* dout);
+                         int* nblocks_out, int batch = 1, int64_t k_bs = 0, int64_t alpha_bs = 0,
+                         const ThetaDev* th = nullptr);
+int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals, double* dout,
+                       int batch = 1, int64_t out_bs = 0);
 void sgp_release(gpx_ctx* ctx);
 int launch_add_mean(gpx_ctx* ctx, double* ddraws, int64_t ld, int n, int M, const double* dmean,
                     int batch = 1, int64_t d_bs = 0, int64_t mean_bs = 0);

@@ -157,7 +157,9 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
 // as in potrf_lower.  upper_rows != 0: B is upper triangular (the L^-T build of the gradient),
 // so column block i only involves row tiles 0..i.
 int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const double* dL,
-                  int64_t ldl, const double* dLinv, int nblk, int upper_rows) {
+                  int64_t ldl, const double* dLinv, int nblk, int upper_rows, int batch,
+                  int64_t b_bs, int64_t l_bs, int64_t linv_bs) {
+  if (batch < 1) batch = 1;
   for (int ob = 0; ob < nblk; ob += OUTER_TILES) {
     const int oe = (ob + OUTER_TILES < nblk) ? ob + OUTER_TILES : nblk;
     for (int i = ob; i < oe; ++i) {
@@ -166,6 +168,7 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
       {
         GemmArgs g = gemm_args(Bi, ldb, dLinv + (int64_t)i * TILE * TILE, TILE, Bi, ldb, TILE, 1.0,
                                0.0);
+        set_batch(g, batch, b_bs, linv_bs, b_bs);
         GPX_TRY(launch_gemm_nt(ctx, g, rt, 1, 0, GPX_PROF_GEMM_OTHER,
                                2.0 * rt * TILE * (double)TILE * TILE));
       }
@@ -174,6 +177,7 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
         const double* Lsub = dL + (int64_t)(i + 1) * TILE * ldl + (int64_t)i * TILE;
         GemmArgs g = gemm_args(Bi, ldb, Lsub, ldl, dB + (int64_t)(i + 1) * TILE, ldb, TILE, -1.0,
                                1.0);
+        set_batch(g, batch, b_bs, l_bs, b_bs);
         GPX_TRY(launch_gemm_nt(ctx, g, rt, inner_cols, 0, GPX_PROF_GEMM_OTHER,
                                2.0 * rt * inner_cols * (double)TILE * TILE * TILE));
       }
@@ -185,6 +189,7 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
       const double* Lsub = dL + (int64_t)oe * TILE * ldl + (int64_t)ob * TILE;
       GemmArgs g = gemm_args(dB + (int64_t)ob * TILE, ldb, Lsub, ldl, dB + (int64_t)oe * TILE, ldb,
                              K, -1.0, 1.0);
+      set_batch(g, batch, b_bs, l_bs, b_bs);
       GPX_TRY(launch_gemm_nt(ctx, g, rt, rest, 0, GPX_PROF_GEMM_OTHER,
                              2.0 * rt * rest * (double)TILE * TILE * K));
     }
@@ -195,17 +200,17 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
 // ---- small kernels ---------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ A, int64_t ld,
-                                                           int np) {
+                                                           int np, int64_t a_bs) {
   const int i = blockIdx.y;
-  double* row = A + (int64_t)i * ld;
+  double* row = A + (int64_t)blockIdx.z * a_bs + (int64_t)i * ld;
   for (int j = (blockIdx.x * 256 + threadIdx.x) * 2; j < np; j += gridDim.x * 512) {
     *reinterpret_cast<double2*>(row + j) = make_double2(j == i ? 1.0 : 0.0, j + 1 == i ? 1.0 : 0.0);
   }
 }
 
-int launch_set_identity(gpx_ctx* ctx, double* dA, int64_t ld, int np) {
-  dim3 grid(min(32, (np / 2 + 255) / 256), np);
-  set_identity_kernel<<<grid, 256, 0, ctx->s>>>(dA, ld, np);
+int launch_set_identity(gpx_ctx* ctx, double* dA, int64_t ld, int np, int batch, int64_t a_bs) {
+  dim3 grid(min(32, (np / 2 + 255) / 256), np, batch > 1 ? batch : 1);
+  set_identity_kernel<<<grid, 256, 0, ctx->s>>>(dA, ld, np, a_bs);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -234,8 +239,11 @@ __device__ __forceinline__ double block_sum(double v, double* red /* >= 16 doubl
 // out[0] = sum_{k<N} L[N][k]^2 (= |L^-1 y|^2: row N of the augmented factor),
 // out[1] = sum_{i<N} log L[i][i].
 __global__ __launch_bounds__(1024) void lml_terms_kernel(const double* __restrict__ L, int64_t ld,
-                                                         int N, double* __restrict__ out) {
+                                                         int N, double* __restrict__ out,
+                                                         int64_t l_bs, int64_t out_bs) {
   __shared__ double red[16];
+  L += (int64_t)blockIdx.x * l_bs; // one workgroup per batch entry
+  out += (int64_t)blockIdx.x * out_bs;
   double q = 0.0, s = 0.0;
   const double* w = L + (int64_t)N * ld;
   for (int k = threadIdx.x; k < N; k += 1024) {
@@ -251,8 +259,9 @@ __global__ __launch_bounds__(1024) void lml_terms_kernel(const double* __restric
   }
 }
 
-int launch_lml_terms(gpx_ctx* ctx, const double* dL, int64_t ld, int N, double* dOut2) {
-  lml_terms_kernel<<<1, 1024, 0, ctx->s>>>(dL, ld, N, dOut2);
+int launch_lml_terms(gpx_ctx* ctx, const double* dL, int64_t ld, int N, double* dOut2, int batch,
+                     int64_t l_bs, int64_t out_bs) {
+  lml_terms_kernel<<<batch > 1 ? batch : 1, 1024, 0, ctx->s>>>(dL, ld, N, dOut2, l_bs, out_bs);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -377,81 +386,131 @@ int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXne
 constexpr int GC_TILE = 64;
 constexpr int GC_MAXV = GPX_MAX_DIM + 3;
 
-__global__ __launch_bounds__(256) void grad_contract_kernel(KernelParams kp,
+// KIND / D are compile-time (D = 0: generic d <= 16) so the per-dimension accumulators stay in
+// registers; batch entry blockIdx.y reads its hyper-parameters from the device table `th`.
+template <int KIND, int D>
+__global__ __launch_bounds__(256) void grad_contract_kernel(KernelParams kpv,
                                                             const double* __restrict__ X, int N,
                                                             const double* __restrict__ Kinv,
                                                             int64_t ld,
                                                             const double* __restrict__ alpha,
-                                                            double* __restrict__ part) {
+                                                            double* __restrict__ part,
+                                                            int64_t k_bs, int64_t alpha_bs,
+                                                            int64_t part_bs,
+                                                            const ThetaDev* __restrict__ th) {
+  constexpr int DM = (D > 0) ? D : GPX_MAX_DIM;
+  const ThetaDev* t = (th != nullptr) ? th + blockIdx.y : nullptr;
+  const double k_scale = t ? t->kp.scale : kpv.scale;
+  const double pi_over_p = t ? t->kp.pi_over_p : kpv.pi_over_p;
+  const int d = (D > 0) ? D : kpv.d;
+  double inv_ell[DM];
+#pragma unroll
+  for (int c = 0; c < DM; ++c) inv_ell[c] = (c < d) ? (t ? t->kp.inv_ell[c] : kpv.inv_ell[c]) : 0.0;
+  Kinv += (int64_t)blockIdx.y * k_bs;
+  alpha += (int64_t)blockIdx.y * alpha_bs;
+  part += (int64_t)blockIdx.y * part_bs;
   // linear block id -> lower-triangle tile (ti >= tj)
   const int bid = blockIdx.x;
   int ti = (int)((sqrt(8.0 * bid + 1.0) - 1.0) * 0.5);
   while ((int64_t)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
   while ((int64_t)ti * (ti + 1) / 2 > bid) --ti;
   const int tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
-  const int d = kp.d;
-  const int ne = d + (kp.kind == GPX_KERNEL_PERIODIC ? 1 : 0); // [ell(0..d), (period), scale, noise]
+  constexpr bool PER = (KIND == GPX_KERNEL_PERIODIC);
+  const int ne = d + (PER ? 1 : 0); // [ell(0..d), (period), scale, noise]
   __shared__ double red[16];
-  double acc[GC_MAXV];
-  for (int c = 0; c < ne + 2; ++c) acc[c] = 0.0;
+  double acc_ell[DM], acc_p = 0.0, acc_s = 0.0, acc_n = 0.0;
+#pragma unroll
+  for (int c = 0; c < DM; ++c) acc_ell[c] = 0.0;
   const int j = tj * GC_TILE + (threadIdx.x & 63);
   const int ibase = ti * GC_TILE + (threadIdx.x >> 6);
   if (j < N) {
     const double aj = alpha[j];
-    for (int t = 0; t < GC_TILE / 4; ++t) {
-      const int i = ibase + 4 * t;
+    double xj[DM];
+#pragma unroll
+    for (int c = 0; c < DM; ++c) xj[c] = (c < d) ? X[(int64_t)j * d + c] : 0.0;
+    for (int tt = 0; tt < GC_TILE / 4; ++tt) {
+      const int i = ibase + 4 * tt;
       if (i >= N || j > i) continue;
       const double G = alpha[i] * aj - Kinv[(int64_t)i * ld + j];
       const double wgt = (i == j) ? 0.5 : 1.0;
       const double wg = wgt * G;
-      if (kp.kind == GPX_KERNEL_PERIODIC) {
+      if (PER) {
         // k = s exp(-2 sum (S_m / l_m)^2), S_m = sin(pi delta_m / p)
-        double q = 0.0, dp = 0.0, s2[GPX_MAX_DIM];
-        for (int c = 0; c < d; ++c) {
-          const double delta = X[(int64_t)i * d + c] - X[(int64_t)j * d + c];
-          const double sn = sin(delta * kp.pi_over_p), cs = cos(delta * kp.pi_over_p);
-          s2[c] = sn * sn * kp.inv_ell[c] * kp.inv_ell[c];
-          q += s2[c];
-          dp += sn * cs * delta * kp.inv_ell[c] * kp.inv_ell[c];
+        double q = 0.0, dp = 0.0, s2[DM];
+#pragma unroll
+        for (int c = 0; c < DM; ++c) {
+          s2[c] = 0.0;
+          if (c < d) {
+            const double delta = X[(int64_t)i * d + c] - xj[c];
+            const double sn = sin(delta * pi_over_p), cs = cos(delta * pi_over_p);
+            s2[c] = sn * sn * inv_ell[c] * inv_ell[c];
+            q += s2[c];
+            dp += sn * cs * delta * inv_ell[c] * inv_ell[c];
+          }
         }
-        const double kv = kp.scale * exp(-2.0 * q);
-        for (int c = 0; c < d; ++c) acc[c] += wg * kv * 4.0 * s2[c] * kp.inv_ell[c];            // d/d l_m
-        acc[d] += wg * kv * 4.0 * dp * kp.pi_over_p * kp.pi_over_p / 3.14159265358979323846;    // d/d p
-        acc[ne] += wg * kv / kp.scale;
+        const double kv = k_scale * exp(-2.0 * q);
+#pragma unroll
+        for (int c = 0; c < DM; ++c) acc_ell[c] += wg * kv * 4.0 * s2[c] * inv_ell[c];          // d/d l_m
+        acc_p += wg * kv * 4.0 * dp * pi_over_p * pi_over_p / 3.14159265358979323846;          // d/d p
+        acc_s += wg * kv / k_scale;
       } else {
         double r2 = 0.0;
-        double u2[GPX_MAX_DIM];
-        for (int c = 0; c < d; ++c) {
-          const double u = (X[(int64_t)i * d + c] - X[(int64_t)j * d + c]) * kp.inv_ell[c];
-          u2[c] = u * u;
-          r2 += u2[c];
+        double u2[DM];
+#pragma unroll
+        for (int c = 0; c < DM; ++c) {
+          u2[c] = 0.0;
+          if (c < d) {
+            const double u = (X[(int64_t)i * d + c] - xj[c]) * inv_ell[c];
+            u2[c] = u * u;
+            r2 += u2[c];
+          }
         }
         double kv, dk;
-        if (kp.kind == GPX_KERNEL_RBF) {
-          kv = kp.scale * exp(-0.5 * r2);
+        if (KIND == GPX_KERNEL_RBF) {
+          kv = k_scale * exp(-0.5 * r2);
           dk = -0.5 * kv;
         } else {
           const double r = sqrt(r2 + MATERN_EPS);
           const double e = exp(-SQRT5 * r);
-          kv = kp.scale * (1.0 + SQRT5 * r + (5.0 / 3.0) * r2) * e;
-          dk = -(5.0 / 6.0) * kp.scale * e * (1.0 + SQRT5 * r2 / r);
+          kv = k_scale * (1.0 + SQRT5 * r + (5.0 / 3.0) * r2) * e;
+          dk = -(5.0 / 6.0) * k_scale * e * (1.0 + SQRT5 * r2 / r);
         }
-        for (int c = 0; c < d; ++c) acc[c] += wg * dk * (-2.0 * u2[c] * kp.inv_ell[c]);
-        acc[ne] += wg * kv / kp.scale;
+#pragma unroll
+        for (int c = 0; c < DM; ++c) acc_ell[c] += wg * dk * (-2.0 * u2[c] * inv_ell[c]);
+        acc_s += wg * kv / k_scale;
       }
-      if (i == j) acc[ne + 1] += wg;
+      if (i == j) acc_n += wg;
     }
   }
-  for (int c = 0; c < ne + 2; ++c) {
-    const double s = block_sum(acc[c], red);
-    if (threadIdx.x == 0) part[(int64_t)bid * GC_MAXV + c] = s;
+  double* out = part + (int64_t)bid * GC_MAXV;
+#pragma unroll
+  for (int c = 0; c < DM; ++c) {
+    if (c < d) { // uniform condition
+      const double sum = block_sum(acc_ell[c], red);
+      if (threadIdx.x == 0) out[c] = sum;
+    }
+  }
+  if (PER) {
+    const double sum = block_sum(acc_p, red);
+    if (threadIdx.x == 0) out[d] = sum;
+  }
+  {
+    const double ss = block_sum(acc_s, red);
+    const double sn = block_sum(acc_n, red);
+    if (threadIdx.x == 0) {
+      out[ne] = ss;
+      out[ne + 1] = sn;
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ part,
                                                           int nblocks, int nvals,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, int64_t part_bs,
+                                                          int64_t out_bs) {
   __shared__ double red[16];
+  part += (int64_t)blockIdx.x * part_bs; // one workgroup per batch entry
+  out += (int64_t)blockIdx.x * out_bs;
   for (int c = 0; c < nvals; ++c) {
     double s = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(int64_t)b * GC_MAXV + c];
@@ -462,17 +521,41 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
 
 int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int N,
                          const double* dKinv, int64_t ld, const double* dalpha, double* dpart,
-                         int* nblocks_out) {
+                         int* nblocks_out, int batch, int64_t k_bs, int64_t alpha_bs,
+                         const ThetaDev* th) {
   const int nt = (N + GC_TILE - 1) / GC_TILE;
   const int nblocks = nt * (nt + 1) / 2;
   *nblocks_out = nblocks;
-  grad_contract_kernel<<<nblocks, 256, 0, ctx->s>>>(kp, dX, N, dKinv, ld, dalpha, dpart);
+  dim3 grid(nblocks, batch > 1 ? batch : 1);
+  const int64_t part_bs = (int64_t)nblocks * GC_MAXV;
+#define GPX_GC_LAUNCH(KIND, DD)                                                                         \
+  grad_contract_kernel<KIND, DD><<<grid, 256, 0, ctx->s>>>(kp, dX, N, dKinv, ld, dalpha, dpart, k_bs, \
+                                                           alpha_bs, part_bs, th)
+#define GPX_GC_KIND(KIND)            \
+  switch (kp.d) {                    \
+    case 1: GPX_GC_LAUNCH(KIND, 1); break; \
+    case 2: GPX_GC_LAUNCH(KIND, 2); break; \
+    case 3: GPX_GC_LAUNCH(KIND, 3); break; \
+    case 4: GPX_GC_LAUNCH(KIND, 4); break; \
+    default: GPX_GC_LAUNCH(KIND, 0);  \
+  }
+  if (kp.kind == GPX_KERNEL_RBF) {
+    GPX_GC_KIND(GPX_KERNEL_RBF)
+  } else if (kp.kind == GPX_KERNEL_PERIODIC) {
+    GPX_GC_KIND(GPX_KERNEL_PERIODIC)
+  } else {
+    GPX_GC_KIND(GPX_KERNEL_MATERN52)
+  }
+#undef GPX_GC_KIND
+#undef GPX_GC_LAUNCH
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
 
-int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals, double* dout) {
-  grad_reduce_kernel<<<1, 256, 0, ctx->s>>>(dpart, nblocks, nvals, dout);
+int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals, double* dout,
+                       int batch, int64_t out_bs) {
+  grad_reduce_kernel<<<batch > 1 ? batch : 1, 256, 0, ctx->s>>>(dpart, nblocks, nvals, dout,
+                                                                 (int64_t)nblocks * GC_MAXV, out_bs);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -36,6 +36,54 @@ class _Site:
         self.size = int(np.prod(shape)) if shape else 1
 
 
+class _Lockstep:
+    """Rendezvous of concurrently running chains: each chain thread submits the point where it needs
+    log p and its gradient and blocks; when every live chain has submitted, the last one to arrive
+    evaluates all requests as one batch and wakes the others.  Chains are independent, so results do
+    not depend on the grouping."""
+
+    def __init__(self, n: int, batch_fn):
+        import threading
+        self._cv = threading.Condition()
+        self._live = n
+        self._pending = {}
+        self._results = {}
+        self._batch_fn = batch_fn
+        self._error = None
+
+    def _run_batch(self):  # called with the lock held and every live chain waiting
+        ids = sorted(self._pending)
+        try:
+            outs = self._batch_fn([self._pending[i] for i in ids])
+            for i, o in zip(ids, outs):
+                self._results[i] = o
+        except Exception as ex:  # wake everybody up; each waiter re-raises
+            self._error = ex
+            for i in ids:
+                self._results[i] = None
+        self._pending.clear()
+        self._cv.notify_all()
+
+    def evaluate(self, cid: int, u):
+        with self._cv:
+            self._pending[cid] = u
+            if len(self._pending) >= self._live:
+                self._run_batch()
+            else:
+                while cid not in self._results:
+                    self._cv.wait()
+            out = self._results.pop(cid)
+            if out is None:
+                raise self._error
+            return out
+
+    def finish(self, cid: int):
+        with self._cv:
+            self._live -= 1
+            if self._pending and len(self._pending) >= self._live:
+                self._run_batch()
+
+
 class ExactGP:
     """
     Gaussian process class
@@ -141,7 +189,7 @@ class ExactGP:
     def _log_joint(self, sites, u, jitter: float, jacobian: bool, want_grad: bool = True, eng=None):
         """log p(y | theta) + log p(theta) [+ log |dtheta/du|] at theta = T(u) and its gradient
         w.r.t. u.  Returns (value, grad) — (-inf, zeros) when K(theta) is not positive definite.
-        `eng`: a libgpx context that already holds X_train (parallel chains); default: the shared one."""
+        `eng`: a libgpx context that already holds X_train; default: the shared one."""
         theta = self._unpack(sites, u)
         if eng is None:
             eng = self._engine()
@@ -149,14 +197,46 @@ class ExactGP:
         lml, info = eng.factor(self._kind, self._ell(theta), theta["k_scale"], theta["noise"], jitter, yres)
         if info != 0 or not np.isfinite(lml):
             return -np.inf, np.zeros_like(u)
-        val = lml
-        grad = np.zeros_like(u)
+        g = alpha = None
         if want_grad:
             g_ell, g_scale, g_noise, alpha = eng.lml_grad()
+            g = np.concatenate([g_ell, [g_scale, g_noise]])
+        return self._chain_rule(sites, u, theta, lml, g, alpha, jacobian)
+
+    def _log_joint_batch(self, sites, us, jitter: float, jacobian: bool, eng=None):
+        """_log_joint for a list of unconstrained vectors in ONE device pass (gpx_fit_batch: the chains of
+        a multi-chain NUTS run advance in lockstep, the chain being a grid dimension of every launch)."""
+        if eng is None:
+            eng = self._engine()
+        thetas = [self._unpack(sites, u) for u in us]
+        ells = np.stack([self._ell(t) for t in thetas])
+        scales = np.array([t["k_scale"] for t in thetas], dtype=np.float64)
+        noises = np.array([t["noise"] for t in thetas], dtype=np.float64)
+        if self.mean_fn is None:
+            yres = self.y_train
+        else:
+            yres = np.stack([self.y_train - self._mean(self.X_train, t) for t in thetas])
+        lml, info, grad, alpha = eng.fit_batch(self._kind, ells, scales, noises, jitter, yres, want_grad=True)
+        out = []
+        for b, u in enumerate(us):
+            if info[b] != 0 or not np.isfinite(lml[b]):
+                out.append((-np.inf, np.zeros_like(u)))
+            else:
+                out.append(self._chain_rule(sites, u, thetas[b], float(lml[b]), grad[b], alpha[b], jacobian))
+        return out
+
+    def _chain_rule(self, sites, u, theta, lml, g, alpha, jacobian: bool):
+        """Add the log-priors (and log-Jacobians) to the device log-likelihood and map its gradient
+        g = [d/d k_length.., (d/d period), d/d k_scale, d/d noise] to the unconstrained vector u."""
+        val = lml
+        grad = np.zeros_like(u)
+        want_grad = g is not None
+        if want_grad:
             d_ = self.kernel_dim
-            glik = {"k_length": g_ell[:d_], "k_scale": np.array([g_scale]), "noise": np.array([g_noise])}
+            ne = d_ + (1 if self.kernel_name == "Periodic" else 0)
+            glik = {"k_length": g[:d_], "k_scale": g[ne:ne + 1], "noise": g[ne + 1:ne + 2]}
             if self.kernel_name == "Periodic":
-                glik["period"] = g_ell[d_:d_ + 1]
+                glik["period"] = g[d_:d_ + 1]
         off = 0
         for s in sites:
             ui = u[off:off + s.size]
@@ -218,27 +298,25 @@ class ExactGP:
         rng = rng_from_key(rng_key)
         sites = self._sites()
         # one independent generator per chain (children of the key): chains do not depend on how they are
-        # scheduled.  chain_method 'parallel' / 'vectorized' run the chains concurrently, each on its own
-        # libgpx context on this GPU (the reference pmaps / vmaps them, gp.py:173-174,214); 'sequential'
-        # runs them one after the other on the shared context.
+        # scheduled.  chain_method 'parallel' / 'vectorized' advance the chains together, their gradient
+        # requests batched into one device pass per round (the reference pmaps / vmaps them,
+        # gp.py:173-174,214); 'sequential' runs them one after the other.
         chain_rngs = [rng] if num_chains == 1 else [np.random.default_rng(sd) for sd in rng.integers(0, 2 ** 63, num_chains)]
         concurrent = chain_method != "sequential" and num_chains > 1
-        engines = _lib.get_sweep_engines(self._device, n=num_chains) if concurrent else [None]
-        if concurrent and len(engines) > 1:
-            for e in engines:
-                e.set_train(self.X_train)
-                e._train_owner = None
-        else:
-            concurrent = False
         results = [None] * num_chains
         errors = []
+        lockstep = _Lockstep(num_chains, lambda us: self._log_joint_batch(sites, us, jitter, jacobian=True)) \
+            if concurrent else None
 
-        def run_chain(c, eng):
+        def run_chain(c):
             try:
                 crng = chain_rngs[c]
 
                 def potential(u):
-                    v, g = self._log_joint(sites, u, jitter, jacobian=True, eng=eng)
+                    if lockstep is not None:
+                        v, g = lockstep.evaluate(c, u)
+                    else:
+                        v, g = self._log_joint(sites, u, jitter, jacobian=True)
                     return (-v, -g) if np.isfinite(v) else (np.inf, np.zeros_like(u))
 
                 u0 = None
@@ -252,19 +330,23 @@ class ExactGP:
                 prog.close()
             except Exception as ex:
                 errors.append(ex)
+            finally:
+                if lockstep is not None:
+                    lockstep.finish(c)
 
         if concurrent:
+            # the chains advance in lockstep: every round, each live chain asks for one gradient and the
+            # requests are evaluated as ONE batched device pass (the chain is a grid dimension)
             import threading
-            waves = [list(range(i, min(i + len(engines), num_chains))) for i in range(0, num_chains, len(engines))]
-            for wave in waves:
-                ts = [threading.Thread(target=run_chain, args=(c, engines[k])) for k, c in enumerate(wave)]
-                for t in ts:
-                    t.start()
-                for t in ts:
-                    t.join()
+            self._engine()  # X_train resident on the shared context before the chains start
+            ts = [threading.Thread(target=run_chain, args=(c,)) for c in range(num_chains)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
         else:
             for c in range(num_chains):
-                run_chain(c, None)
+                run_chain(c)
         if errors:
             raise errors[0]
         chains = [r["draws"] for r in results]

@@ -85,6 +85,18 @@ int gpx_factor(gpx_ctx* ctx, int kind, const double* ell, double scale, double n
 int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* grad_noise,
                  double* alpha);
 
+/* ---- batched fit step: B hyper-parameter vectors through gpx_factor + gpx_lml_grad at once ----
+ * The chains of MCMC(num_chains > 1, chain_method='parallel'|'vectorized') (gpax/models/gp.py:173-174,
+ * 207-218) ask for one log-likelihood gradient each per leapfrog; this entry evaluates them as ONE
+ * launch sequence with the chain as a grid dimension.  For entry b:
+ *   theta_b = (ells[b*ne .. ), scales[b], noises[b]), ne = d (+1: period); yres_b = yres + b*yres_stride
+ *   lml[b], info[b] as gpx_factor; grad[b*(ne+2) ..] = [d/d ell.., d/d scale, d/d noise];
+ *   alpha[b*N ..] = K_b^-1 yres_b.  grad == NULL: values only.  Entries with info != 0 are NaN.
+ * The per-entry arithmetic is that of gpx_factor / gpx_lml_grad (bit-identical results). */
+int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const double* scales,
+                  const double* noises, double jitter, const double* yres, int64_t yres_stride,
+                  double* lml, int* info, double* grad, double* alpha);
+
 /* ---- posterior: ExactGP.get_mvn_posterior, gpax/models/gp.py:253-277 ----------------------
  * Must follow gpx_factor (same theta).  mean (M), cov (M*M, may be NULL), var (M, may be
  * NULL; = diag(cov), what viGP.predict returns, gpax/models/vigp.py:184-185).

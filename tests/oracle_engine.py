@@ -86,6 +86,24 @@ class OracleEngine:
         K = ref.PeriodicKernel(self.X, self.X, t["p"], t["noise"], jitter=t["jitter"])
         return g, gs, gn, np.linalg.solve(K, self._yres)
 
+    def fit_batch(self, kind, ells, scales, noises, jitter, yres, want_grad=True):
+        ells = np.asarray(ells, dtype=np.float64)
+        B = ells.shape[0]
+        yres = np.asarray(yres, dtype=np.float64)
+        lml, info = np.empty(B), np.zeros(B, dtype=np.int32)
+        grad, alpha = ([None] * B, [None] * B)
+        for b in range(B):
+            lml[b], info[b] = self.factor(kind, ells[b], scales[b], noises[b], jitter, yres if yres.ndim == 1 else yres[b])
+            if want_grad and info[b] == 0:
+                g_ell, gs, gn, alpha[b] = self.lml_grad()
+                grad[b] = np.concatenate([np.asarray(g_ell).reshape(-1), [gs, gn]])
+        if not want_grad:
+            return lml, info, None, None
+        ne = ells.shape[1] + 2
+        grad = np.stack([g if g is not None else np.full(ne, np.nan) for g in grad])
+        alpha = np.stack([a if a is not None else np.full(self.N, np.nan) for a in alpha])
+        return lml, info, grad, alpha
+
     def posterior(self, Xnew, noise_p, jitter, want_cov=True, want_var=False):
         t = self._theta
         Xnew = np.asarray(Xnew, dtype=np.float64)

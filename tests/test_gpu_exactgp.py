@@ -178,3 +178,34 @@ def test_batched_sweep_is_independent_of_batch_size(engine, kind, name, strided,
         m_ref, c_ref = ref.get_mvn_posterior(X, ys, Xnew, p, False, kernel=name, jitter=1e-6, route="inv")
         assert relerr(means[s], m_ref) < 1e-8
         assert relerr(draws[s], ref.mvn_sample(m_ref, c_ref, eps[s])) < 1e-6
+
+
+@pytest.mark.parametrize("kind,name", KINDS + [(2, "Periodic")])
+@pytest.mark.parametrize("N,d", [(90, 1), (391, 3), (700, 2)])
+def test_fit_batch_equals_single_fit_steps(engine, kind, name, N, d):
+    # gpx_fit_batch = B x (gpx_factor + gpx_lml_grad) with the chain as a grid dimension: bit-identical entries
+    B = 5
+    X, y, _, params = ref.synthetic_problem(N, d, 4, seed=5 * N + d)
+    rng = np.random.default_rng(N)
+    ne = d + (1 if kind == 2 else 0)
+    ells = np.tile(np.concatenate([np.broadcast_to(params["k_length"], (d,)), [2.3]])[:ne], (B, 1)) * rng.uniform(0.8, 1.25, (B, ne))
+    scales = params["k_scale"] * rng.uniform(0.8, 1.25, B)
+    noises = params["noise"] * rng.uniform(0.5, 2.0, B)
+    noises[3] = -1.0  # not PD: only this entry is NaN
+    yres = y[None, :] + 0.05 * rng.standard_normal((B, N))
+    engine.set_train(X)
+    for yr in (y, yres):
+        lml, info, grad, alpha = engine.fit_batch(kind, ells, scales, noises, 1e-6, yr)
+        assert info[3] != 0 and np.isnan(lml[3]) and np.all(np.isnan(grad[3]))
+        for b in range(B):
+            if b == 3:
+                continue
+            l1, i1 = engine.factor(kind, ells[b], scales[b], noises[b], 1e-6, yr if yr.ndim == 1 else yr[b])
+            g_ell, g_s, g_n, a1 = engine.lml_grad()
+            assert i1 == 0 and info[b] == 0
+            assert l1 == lml[b]
+            np.testing.assert_array_equal(np.concatenate([g_ell, [g_s, g_n]]), grad[b])
+            np.testing.assert_array_equal(a1, alpha[b])
+        lml2, info2, g2, a2 = engine.fit_batch(kind, ells, scales, noises, 1e-6, yr, want_grad=False)
+        assert g2 is None and a2 is None
+        np.testing.assert_array_equal(lml2[[0, 1, 2, 4]], lml[[0, 1, 2, 4]])
