@@ -58,11 +58,12 @@ def load_library() -> C.CDLL:
         "gpx_set_train": (C.c_int, [vp, _dp, C.c_int, C.c_int]),
         "gpx_factor": (C.c_int, [vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _ip]),
         "gpx_lml_grad": (C.c_int, [vp, _dp, _dp, _dp, _dp]),
-        "gpx_fit_batch": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, C.c_int64, _dp, _ip, _dp,
+        "gpx_fit_batch": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, C.c_int, _dp, _ip, _dp,
                                     _dp]),
+        "gpx_set_train_tasks": (C.c_int, [vp, _dp, C.c_int, C.c_int, C.c_int]),
         "gpx_posterior": (C.c_int, [vp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]),
         "gpx_mvn_draw": (C.c_int, [vp, _dp, C.c_int, _dp, _ip]),
-        "gpx_predict_sweep": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _dp,
+        "gpx_predict_sweep": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp,
                                         C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip]),
         "gpx_sgp_bound": (C.c_int, [vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp, C.c_int, _dp, C.c_int,
                                     _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
@@ -87,7 +88,7 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "gpx_init gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train "
+    "gpx_init gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks "
     "gpx_factor gpx_lml_grad gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
     "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
@@ -202,7 +203,15 @@ class Engine:
 
     # -- exact GP -----------------------------------------------------------------------------
     def set_train(self, X):
+        """X (N, d), or (T, N, d): T task-specific training sets (vExactGP) — then the batched entry points
+        treat entry b as task b % T."""
         X = _f64(X)
+        if X.ndim == 3:
+            self.T, self.N, self.d = X.shape
+            self._check(self._lib.gpx_set_train_tasks(self._ctx, _ptr(X), self.T, self.N, self.d),
+                        "gpx_set_train_tasks")
+            return
+        self.T = 1
         self.N, self.d = X.shape
         self._check(self._lib.gpx_set_train(self._ctx, _ptr(X), self.N, self.d), "gpx_set_train")
 
@@ -232,20 +241,16 @@ class Engine:
         ne = n_ell(kind, self.d)
         ells = _f64(ells, (B, ne))
         scales, noises = _f64(scales, (B,)), _f64(noises, (B,))
-        yres = _f64(yres)
-        stride = 0
-        if yres.ndim == 2:
-            yres = _f64(yres, (B, self.N))
-            stride = self.N
-        else:
-            yres = _f64(yres, (self.N,))
+        yres = _f64(yres)  # (N,) shared, (B, N) per entry or (T, N) per task
+        rows = 1 if yres.ndim == 1 else yres.shape[0]
+        yres = _f64(yres, (rows, self.N))
         lml = np.empty(B)
         info = np.zeros(B, dtype=np.int32)
         grad = np.empty((B, ne + 2)) if want_grad else None
         alpha = np.empty((B, self.N)) if want_grad else None
         self._last_kind = kind
         self._check(self._lib.gpx_fit_batch(self._ctx, kind, B, _ptr(ells), _ptr(scales), _ptr(noises), float(jitter),
-                                            _ptr(yres), stride, _ptr(lml), info.ctypes.data_as(_ip), _ptr(grad),
+                                            _ptr(yres), rows, _ptr(lml), info.ctypes.data_as(_ip), _ptr(grad),
                                             _ptr(alpha)), "gpx_fit_batch")
         return lml, info, grad, alpha
 
@@ -275,11 +280,11 @@ class Engine:
         ells = _f64(ells, (S, n_ell(kind, self.d)))
         scales = _f64(scales, (S,))
         noises = _f64(noises, (S,))
-        yres = _f64(yres)
-        stride = 0 if yres.ndim == 1 else self.N
-        yres = yres.reshape(-1)
-        Xnew = _f64(Xnew)
-        M = Xnew.shape[0]
+        yres = _f64(yres)  # (N,) shared, (S, N) per sample or (T, N) per task
+        rows = 1 if yres.ndim == 1 else yres.shape[0]
+        yres = _f64(yres, (rows, self.N))
+        Xnew = _f64(Xnew)  # (M, d), or (T, M, d) after set_train with task-specific inputs
+        M = Xnew.shape[-2]
         self.M = M
         n = 0 if eps is None else int(np.asarray(eps).shape[1])
         eps_c = None if n == 0 else _f64(eps, (S, n, M))
@@ -287,7 +292,7 @@ class Engine:
         samples = np.empty((S, n, M))
         infos = np.zeros(S, dtype=np.int32)
         self._check(self._lib.gpx_predict_sweep(
-            self._ctx, kind, S, _ptr(ells), _ptr(scales), _ptr(noises), _ptr(yres), stride, _ptr(Xnew), M,
+            self._ctx, kind, S, _ptr(ells), _ptr(scales), _ptr(noises), _ptr(yres), rows, _ptr(Xnew), M,
             int(bool(noiseless)), float(jitter), _ptr(eps_c), n, _ptr(means),
             _ptr(samples) if n else None, infos.ctypes.data_as(_ip)), "gpx_predict_sweep")
         return means, samples, infos

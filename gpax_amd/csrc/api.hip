@@ -59,6 +59,26 @@ CovSplit cov_split(const gpx_ctx* ctx) {
   return CovSplit{splits, kchunk};
 }
 
+// Per-task input strides: training inputs for both Gram operands / k_pX's second operand, X_new for
+// k_pX's first operand and k_pp.
+TaskStride ts_train(const gpx_ctx* ctx) {
+  TaskStride t;
+  if (ctx->T > 1) {
+    t.mod = ctx->T;
+    t.x_bs = t.z_bs = (int64_t)ctx->N * ctx->d;
+  }
+  return t;
+}
+TaskStride ts_new(const gpx_ctx* ctx) {
+  TaskStride t;
+  if (ctx->T > 1) {
+    t.mod = ctx->T;
+    t.x_bs = (int64_t)ctx->M * ctx->d;
+    t.z_bs = (int64_t)ctx->N * ctx->d;
+  }
+  return t;
+}
+
 // Plan over the context's own buffers: B samples per launch, sample b at base + b * stride.
 // B = 1 with th = nullptr is the eager single-theta path of gpx_factor / gpx_posterior.
 BatchPlan make_plan(gpx_ctx* ctx, int B, int n_pad, bool fused) {
@@ -90,12 +110,12 @@ int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
   GPX_TRY(ensure(ctx, ctx->Linv, (size_t)B * bp.linv_bs * sizeof(double)));
   double* K = ctx->K.d();
   GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->X.d(), N, N, ctx->X.d(), N, Np,
-                             ctx->noise + ctx->jitter, 1, 1, K, ctx->ldk, B, bp.k_bs, bp.th, 1));
-  GPX_TRY(launch_augment(ctx, K, ctx->ldk, N, Np, bp.yres, B, bp.k_bs, bp.y_bs));
+                             ctx->noise + ctx->jitter, 1, 1, K, ctx->ldk, B, bp.k_bs, bp.th, 1, ts_train(ctx)));
+  GPX_TRY(launch_augment(ctx, K, ctx->ldk, N, Np, bp.yres, B, bp.k_bs, bp.y_bs, bp.y_mod));
   if (fused) {
     // k_pX = kernel(X_new, X_train, params, jitter=0.0): no diagonal term (gp.py:268)
     GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->Xnew.d(), ctx->M, ctx->Mp, ctx->X.d(), N, Np, 0.0,
-                               0, 0, K + (int64_t)Np * ctx->ldk, ctx->ldk, B, bp.k_bs, bp.th, 0));
+                               0, 0, K + (int64_t)Np * ctx->ldk, ctx->ldk, B, bp.k_bs, bp.th, 0, ts_new(ctx)));
   }
   GPX_HIP(ctx, hipMemsetAsync(bp.info_train, 0, (size_t)B * sizeof(int), ctx->stream));
   GPX_TRY(potrf_lower(ctx, K, ctx->ldk, Np, extra, ctx->Linv.d(), bp.info_train, B, bp.k_bs, bp.linv_bs));
@@ -148,23 +168,24 @@ int dev_grad(gpx_ctx* ctx, const BatchPlan& bp) {
   GPX_TRY(ensure(ctx, ctx->part, (size_t)B * nt64 * (nt64 + 1) / 2 * (GPX_MAX_DIM + 3) * sizeof(double)));
   int nblocks = 0;
   GPX_TRY(launch_grad_contract(ctx, ctx->theta, ctx->X.d(), N, K, ctx->ldk, ctx->alpha.d(),
-                               ctx->part.d(), &nblocks, B, bp.k_bs, alpha_bs, bp.th));
+                               ctx->part.d(), &nblocks, B, bp.k_bs, alpha_bs, bp.th, ts_train(ctx)));
   GPX_TRY(launch_grad_reduce(ctx, ctx->part.d(), nblocks, n_ell(ctx->theta) + 2, bp.scal + SC_GRAD, B, bp.scal_bs));
   ctx->factored = false; // K now holds K^-1
   return 0;
 }
 int dev_grad(gpx_ctx* ctx) { return dev_grad(ctx, make_plan(ctx, 1, 0, false)); }
 
+// Xnew: (T, M, d) — T = ctx->T task-specific test sets (T = 1: the usual (M, d))
 int set_xnew(gpx_ctx* ctx, const double* Xnew, int M) {
   if (M < 1) return bad_arg(ctx, "M must be >= 1");
   ctx->M = M;
   ctx->Mp = round_up(M, TILE);
   ctx->ldv = pick_ld(ctx->Np);
   ctx->ldc = pick_ld(ctx->Mp);
-  GPX_TRY(ensure(ctx, ctx->Xnew, (size_t)M * ctx->d * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->Xnew, (size_t)ctx->T * M * ctx->d * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->mean, (size_t)ctx->Mp * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->var, (size_t)ctx->Mp * sizeof(double)));
-  GPX_HIP(ctx, hipMemcpyAsync(ctx->Xnew.d(), Xnew, (size_t)M * ctx->d * sizeof(double),
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->Xnew.d(), Xnew, (size_t)ctx->T * M * ctx->d * sizeof(double),
                               hipMemcpyHostToDevice, ctx->stream));
   return 0;
 }
@@ -227,7 +248,7 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov, const BatchPlan& bp) {
     GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, cs.splits, GPX_PROF_GEMM_OTHER, m * (m + 1.0) * ktot));
     GPX_TRY(launch_cov_finalize(ctx, kp, ctx->Xnew.d(), M, Mp, ctx->SplitK.d(), cs.splits, stride, ldp,
                                 ctx->noise_p + ctx->jitter, ctx->Cov.d(), ctx->ldc, B, bp.splitk_bs, bp.cov_bs,
-                                bp.th));
+                                bp.th, ts_new(ctx)));
   }
   ctx->have_post = want_cov && B == 1;
   return 0;
@@ -325,6 +346,7 @@ struct SweepIO {
   double jitter = 0.0;
   const double *ells = nullptr, *scales = nullptr, *noises = nullptr; // host tables
   const double* dYres = nullptr; // device (S, N) or nullptr: ctx->yres shared by all samples
+  int y_mod = 0;                 // > 0: dYres is (y_mod, N), sample s reads row s % y_mod (per-task residuals)
   const double* dEps = nullptr;  // device (S, n, M) or nullptr: whatever is resident in ctx->eps
   double* dMeans = nullptr;      // device outputs (nullptr: results stay in the batch buffers)
   double* dSamples = nullptr;
@@ -356,6 +378,10 @@ int pick_batch(gpx_ctx* ctx, int S, int n_pad, bool want_cov) {
   }
   if (B > S) B = S;
   if (B < 1) B = 1;
+  if (ctx->T > 1) { // batches start on a task boundary: entry b of a batch is task b % T
+    B -= B % ctx->T;
+    if (B < ctx->T) B = ctx->T;
+  }
   return B;
 }
 
@@ -408,7 +434,11 @@ int sweep_core(gpx_ctx* ctx, const SweepIO& io) {
     const int b = (S - s0 < B) ? S - s0 : B;
     bp.B = b;
     bp.th = table + s0;
-    if (io.dYres != nullptr) {
+    if (io.dYres != nullptr && io.y_mod > 0) {
+      bp.yres = io.dYres; // s0 is a multiple of y_mod (= T)
+      bp.y_bs = N;
+      bp.y_mod = io.y_mod;
+    } else if (io.dYres != nullptr) {
       bp.yres = io.dYres + (int64_t)s0 * N;
       bp.y_bs = N;
     } else {
@@ -569,21 +599,24 @@ int gpx_gram(gpx_ctx* ctx, int kind, const double* X, int n, const double* Z, in
   return 0;
 }
 
-int gpx_set_train(gpx_ctx* ctx, const double* X, int N, int d) {
+int gpx_set_train_tasks(gpx_ctx* ctx, const double* X, int T, int N, int d) {
   if (!ctx || ctx->device < 0) return -1;
   if (!X) return bad_arg(ctx, "null X");
   if (N < 1) return bad_arg(ctx, "N must be >= 1");
+  if (T < 1) return bad_arg(ctx, "T must be >= 1");
   if (d < 1 || d > GPX_MAX_DIM) return bad_arg(ctx, "input dimension must be 1..16");
   GPX_HIP(ctx, hipSetDevice(ctx->device));
   ctx->N = N;
   ctx->d = d;
+  ctx->T = T;
+  ctx->M = 0; // X_new of a previous training set does not carry over
   ctx->Np = round_up(N + 1, TILE);
   ctx->ldk = pick_ld(ctx->Np);
-  GPX_TRY(ensure(ctx, ctx->X, (size_t)N * d * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->X, (size_t)T * N * d * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->K, (size_t)ctx->Np * ctx->ldk * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->Linv, (size_t)(ctx->Np / TILE) * TILE * TILE * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->yres, (size_t)N * sizeof(double)));
-  GPX_HIP(ctx, hipMemcpyAsync(ctx->X.d(), X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice,
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->X.d(), X, (size_t)T * N * d * sizeof(double), hipMemcpyHostToDevice,
                               ctx->stream));
   GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->factored = false;
@@ -591,10 +624,13 @@ int gpx_set_train(gpx_ctx* ctx, const double* X, int N, int d) {
   return 0;
 }
 
+int gpx_set_train(gpx_ctx* ctx, const double* X, int N, int d) { return gpx_set_train_tasks(ctx, X, 1, N, d); }
+
 int gpx_factor(gpx_ctx* ctx, int kind, const double* ell, double scale, double noise,
                double jitter, const double* yres, double* lml, int* info) {
   if (!ctx || ctx->device < 0) return -1;
   if (ctx->N < 1) return bad_arg(ctx, "gpx_set_train must be called first");
+  if (ctx->T != 1) return bad_arg(ctx, "per-task training sets: use gpx_fit_batch / gpx_predict_sweep");
   if (!ell || !yres) return bad_arg(ctx, "null pointer");
   GPX_HIP(ctx, hipSetDevice(ctx->device));
   GPX_TRY(set_theta(ctx, kind, ctx->d, ell, scale));
@@ -642,13 +678,15 @@ int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* gra
 }
 
 int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const double* scales,
-                  const double* noises, double jitter, const double* yres, int64_t yres_stride,
+                  const double* noises, double jitter, const double* yres, int yres_rows,
                   double* lml, int* info, double* grad, double* alpha) {
   if (!ctx || ctx->device < 0) return -1;
   if (ctx->N < 1) return bad_arg(ctx, "gpx_set_train must be called first");
   if (B < 0) return bad_arg(ctx, "negative batch");
   if (B == 0) return 0;
   if (!ells || !scales || !noises || !yres || !lml) return bad_arg(ctx, "null pointer");
+  if (yres_rows != 1 && yres_rows != B && !(ctx->T > 1 && yres_rows == ctx->T))
+    return bad_arg(ctx, "yres_rows must be 1, B or the task count");
   GPX_HIP(ctx, hipSetDevice(ctx->device));
   const int N = ctx->N;
   constexpr int SB = 32; // doubles per sample in bscal
@@ -665,17 +703,17 @@ int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const doubl
   bp.th = static_cast<const ThetaDev*>(ctx->thtab.p);
   GPX_TRY(ensure(ctx, ctx->binfo, (size_t)2 * B * sizeof(int)));
   GPX_TRY(ensure(ctx, ctx->bscal, (size_t)B * SB * sizeof(double)));
-  GPX_TRY(ensure(ctx, ctx->byres, (size_t)B * N * sizeof(double)));
+  GPX_TRY(ensure(ctx, ctx->byres, (size_t)yres_rows * N * sizeof(double)));
   bp.info_train = ctx->binfo.i();
   bp.info_cov = ctx->binfo.i() + B;
   bp.scal = ctx->bscal.d();
   bp.scal_bs = SB;
-  if (yres_stride != 0) {
-    GPX_HIP(ctx, hipMemcpy2DAsync(ctx->byres.d(), (size_t)N * sizeof(double), yres,
-                                  (size_t)yres_stride * sizeof(double), (size_t)N * sizeof(double), B,
-                                  hipMemcpyHostToDevice, ctx->stream));
+  if (yres_rows != 1) {
+    GPX_HIP(ctx, hipMemcpyAsync(ctx->byres.d(), yres, (size_t)yres_rows * N * sizeof(double),
+                                hipMemcpyHostToDevice, ctx->stream));
     bp.yres = ctx->byres.d();
     bp.y_bs = N;
+    bp.y_mod = (yres_rows == B) ? 0 : yres_rows;
   } else {
     GPX_HIP(ctx, hipMemcpyAsync(ctx->yres.d(), yres, (size_t)N * sizeof(double), hipMemcpyHostToDevice,
                                 ctx->stream));
@@ -761,7 +799,7 @@ int gpx_mvn_draw(gpx_ctx* ctx, const double* eps, int n, double* out, int* info)
 }
 
 int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales,
-                      const double* noises, const double* yres, int64_t yres_stride,
+                      const double* noises, const double* yres, int yres_rows,
                       const double* Xnew, int M, int noiseless, double jitter,
                       const double* eps, int n, double* means, double* samples, int* infos) {
   if (!ctx || ctx->device < 0) return -1;
@@ -770,6 +808,8 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   if (S == 0) return 0;
   if (!ells || !scales || !noises || !yres || !Xnew || !means) return bad_arg(ctx, "null pointer");
   if (n > 0 && (!eps || !samples)) return bad_arg(ctx, "eps/samples required when n > 0");
+  if (yres_rows != 1 && yres_rows != S && !(ctx->T > 1 && yres_rows == ctx->T))
+    return bad_arg(ctx, "yres_rows must be 1, S or the task count");
   GPX_HIP(ctx, hipSetDevice(ctx->device));
   const int N = ctx->N;
   GPX_TRY(set_xnew(ctx, Xnew, M));
@@ -800,15 +840,14 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
       return fail(ctx, #expr, _e, __FILE__, __LINE__);             \
     }                                                              \
   } while (0)
-  const bool strided = yres_stride != 0;
+  const bool strided = yres_rows != 1;
   SWEEP_TRY(ensure(ctx, dMeans, (size_t)S * M * sizeof(double)));
   SWEEP_TRY(ensure(ctx, dInfos, (size_t)2 * S * sizeof(int)));
   SWEEP_HIP(hipMemsetAsync(dInfos.p, 0, (size_t)2 * S * sizeof(int), ctx->stream));
   if (strided) {
-    SWEEP_TRY(ensure(ctx, dYres, (size_t)S * N * sizeof(double)));
-    SWEEP_HIP(hipMemcpy2DAsync(dYres.d(), (size_t)N * sizeof(double), yres,
-                               (size_t)yres_stride * sizeof(double), (size_t)N * sizeof(double), S,
-                               hipMemcpyHostToDevice, ctx->stream));
+    SWEEP_TRY(ensure(ctx, dYres, (size_t)yres_rows * N * sizeof(double)));
+    SWEEP_HIP(hipMemcpyAsync(dYres.d(), yres, (size_t)yres_rows * N * sizeof(double), hipMemcpyHostToDevice,
+                             ctx->stream));
   } else {
     SWEEP_HIP(hipMemcpyAsync(ctx->yres.d(), yres, (size_t)N * sizeof(double), hipMemcpyHostToDevice,
                              ctx->stream));
@@ -829,6 +868,7 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   io.scales = scales;
   io.noises = noises;
   io.dYres = strided ? dYres.d() : nullptr;
+  io.y_mod = (strided && yres_rows != S) ? yres_rows : 0;
   io.dEps = n > 0 ? dEps.d() : nullptr;
   io.dMeans = dMeans.d();
   io.dSamples = n > 0 ? dSamples.d() : nullptr;

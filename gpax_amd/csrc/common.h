@@ -73,6 +73,13 @@ struct ThetaDev {
   double kdiag_pred; // k(x, x) + noise_p + jitter (diag of k_pp, for the variance-only path)
 };
 
+// Per-task inputs of a batched launch (vExactGP, gpax/models/vgp.py:70-78: T independent GPs, each
+// with its own X / X_new / y): batch entry b reads task (b % mod); mod = 0: one shared input.
+struct TaskStride {
+  int mod = 0;
+  int64_t x_bs = 0, z_bs = 0;
+};
+
 // Batch layout of the device-resident pipeline: B independent samples per launch (the vmap of
 // gpax/models/gp.py:393-395 as a grid dimension).  Element b lives at base + b * stride.
 struct BatchPlan {
@@ -80,6 +87,7 @@ struct BatchPlan {
   const ThetaDev* th = nullptr; // device table (B entries) or nullptr: by-value ctx->theta
   const double* yres = nullptr; // y residuals, element stride y_bs (0 = shared by the batch)
   int64_t y_bs = 0;
+  int y_mod = 0;                // > 0: entry b reads yres + (b % y_mod) * y_bs (per-task residuals)
   int64_t k_bs = 0, linv_bs = 0;                     // K / Linv
   int64_t mean_bs = 0;                               // mean, var
   int64_t cov_bs = 0, covlinv_bs = 0, splitk_bs = 0; // Cov, CovLinv, SplitK
@@ -111,9 +119,10 @@ struct gpx_ctx {
 
   // ---- training state -------------------------------------------------------------------
   int N = 0, d = 0;
+  int T = 1;         // tasks: X holds T training sets of N points (vExactGP); 1 everywhere else
   int Np = 0;        // padded order of the augmented matrix: round_up(N + 1, 128)
   int64_t ldk = 0;   // leading dimension of K/W buffers
-  gpx::DevBuf X;     // N x d
+  gpx::DevBuf X;     // T x N x d
   gpx::DevBuf K;     // Np x ldk : Gram -> L (lower) -> K^-1 (lower)
   gpx::DevBuf W;     // Np x ldk : L^-T (upper), allocated on first gradient
   gpx::DevBuf Linv;  // (Np/128) x 128 x 128 inverses of the diagonal blocks of L
@@ -129,7 +138,7 @@ struct gpx_ctx {
   // ---- posterior state ------------------------------------------------------------------
   int M = 0, Mp = 0;
   int64_t ldv = 0, ldc = 0;
-  gpx::DevBuf Xnew;   // M x d
+  gpx::DevBuf Xnew;   // T x M x d
   gpx::DevBuf Vt;     // Mp x ldv : k_pX -> k_pX L^-T
   gpx::DevBuf Cov;    // Mp x ldc : posterior covariance -> its Cholesky factor (lower)
   gpx::DevBuf CovLinv;// (Mp/128) x 128 x 128
@@ -222,9 +231,9 @@ int launch_gram(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, c
 int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, int n_pad,
                        const double* dZ, int m, int m_pad, double diag_add, int add_diag,
                        int lower_only, double* dOut, int64_t ld, int batch = 1, int64_t out_bs = 0,
-                       const ThetaDev* th = nullptr, int diag_sel = 0);
+                       const ThetaDev* th = nullptr, int diag_sel = 0, TaskStride ts = TaskStride());
 int launch_augment(gpx_ctx* ctx, double* dK, int64_t ld, int N, int Np, const double* dy,
-                   int batch = 1, int64_t k_bs = 0, int64_t y_bs = 0);
+                   int batch = 1, int64_t k_bs = 0, int64_t y_bs = 0, int y_mod = 0);
 int launch_pad_identity(gpx_ctx* ctx, double* dA, int64_t ld, int n, int np);
 
 // gemm_f64.hip
@@ -271,11 +280,12 @@ int launch_rowdot(gpx_ctx* ctx, const double* dV, int64_t ldv, int rows, int col
 int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXnew, int M, int Mp,
                         const double* dPart, int splits, int64_t split_stride, int64_t ldp,
                         double diag_add, double* dCov, int64_t ldc, int batch = 1,
-                        int64_t part_bs = 0, int64_t cov_bs = 0, const ThetaDev* th = nullptr);
+                        int64_t part_bs = 0, int64_t cov_bs = 0, const ThetaDev* th = nullptr,
+                        TaskStride ts = TaskStride());
 int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int N,
                          const double* dKinv, int64_t ld, const double* dalpha, double* dpart,
                          int* nblocks_out, int batch = 1, int64_t k_bs = 0, int64_t alpha_bs = 0,
-                         const ThetaDev* th = nullptr);
+                         const ThetaDev* th = nullptr, TaskStride ts = TaskStride());
 int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals, double* dout,
                        int batch = 1, int64_t out_bs = 0);
 void sgp_release(gpx_ctx* ctx);

@@ -37,7 +37,12 @@ __global__ __launch_bounds__(256) void gram_kernel(KernelParams kpv, const doubl
                                                    double diag_add, int add_diag, int lower_only,
                                                    double* __restrict__ out, int64_t ld,
                                                    int64_t out_bs, const ThetaDev* __restrict__ th,
-                                                   int diag_sel) {
+                                                   int diag_sel, TaskStride ts) {
+  if (ts.mod > 0) { // per-task inputs: batch entry z belongs to task z % mod
+    const int task = blockIdx.z % ts.mod;
+    X += task * ts.x_bs;
+    Z += task * ts.z_bs;
+  }
   const int j0 = blockIdx.x * GT_COLS;
   const int i0 = blockIdx.y * GT_ROWS;
   if (lower_only && j0 > i0 + GT_ROWS - 1) return;
@@ -123,27 +128,27 @@ template <int KIND>
 static void gram_dispatch(const KernelParams& kp, dim3 grid, hipStream_t s, const double* X, int n,
                           int n_pad, const double* Z, int m, int m_pad, double diag_add,
                           int add_diag, int lower_only, double* out, int64_t ld, int64_t out_bs,
-                          const ThetaDev* th, int diag_sel) {
+                          const ThetaDev* th, int diag_sel, TaskStride ts) {
   switch (kp.d) {
     case 1:
       gram_kernel<KIND, 1><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld, out_bs, th, diag_sel);
+                                                 lower_only, out, ld, out_bs, th, diag_sel, ts);
       break;
     case 2:
       gram_kernel<KIND, 2><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld, out_bs, th, diag_sel);
+                                                 lower_only, out, ld, out_bs, th, diag_sel, ts);
       break;
     case 3:
       gram_kernel<KIND, 3><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld, out_bs, th, diag_sel);
+                                                 lower_only, out, ld, out_bs, th, diag_sel, ts);
       break;
     case 4:
       gram_kernel<KIND, 4><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld, out_bs, th, diag_sel);
+                                                 lower_only, out, ld, out_bs, th, diag_sel, ts);
       break;
     default:
       gram_kernel<KIND, 0><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld, out_bs, th, diag_sel);
+                                                 lower_only, out, ld, out_bs, th, diag_sel, ts);
   }
 }
 
@@ -152,7 +157,7 @@ static void gram_dispatch(const KernelParams& kp, dim3 grid, hipStream_t s, cons
 int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, int n_pad,
                        const double* dZ, int m, int m_pad, double diag_add, int add_diag,
                        int lower_only, double* dOut, int64_t ld, int batch, int64_t out_bs,
-                       const ThetaDev* th, int diag_sel) {
+                       const ThetaDev* th, int diag_sel, TaskStride ts) {
   if (n_pad <= 0 || m_pad <= 0) return 0;
   if (batch > 1 && th == nullptr) return bad_arg(ctx, "batched Gram needs a device theta table");
   dim3 grid((m_pad + GT_COLS - 1) / GT_COLS, (n_pad + GT_ROWS - 1) / GT_ROWS, batch > 1 ? batch : 1);
@@ -161,13 +166,13 @@ int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, i
   ProfScope ps(ctx, GPX_PROF_GRAM, 8.0 * (double)n * (double)m * (batch > 1 ? batch : 1));
   if (kp.kind == GPX_KERNEL_RBF)
     gram_dispatch<GPX_KERNEL_RBF>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
-                                  add_diag, lower_only, dOut, ld, out_bs, th, diag_sel);
+                                  add_diag, lower_only, dOut, ld, out_bs, th, diag_sel, ts);
   else if (kp.kind == GPX_KERNEL_PERIODIC)
     gram_dispatch<GPX_KERNEL_PERIODIC>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
-                                       add_diag, lower_only, dOut, ld, out_bs, th, diag_sel);
+                                       add_diag, lower_only, dOut, ld, out_bs, th, diag_sel, ts);
   else
     gram_dispatch<GPX_KERNEL_MATERN52>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
-                                       add_diag, lower_only, dOut, ld, out_bs, th, diag_sel);
+                                       add_diag, lower_only, dOut, ld, out_bs, th, diag_sel, ts);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -184,9 +189,9 @@ int launch_gram(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, c
 // solve of the lml (NumPyro MVN log_prob's solve_triangular) costs no extra launch.
 __global__ __launch_bounds__(256) void augment_kernel(double* __restrict__ K, int64_t ld, int N,
                                                       int Np, const double* __restrict__ y,
-                                                      int64_t k_bs, int64_t y_bs) {
+                                                      int64_t k_bs, int64_t y_bs, int y_mod) {
   K += (int64_t)blockIdx.z * k_bs;
-  y += (int64_t)blockIdx.z * y_bs;
+  y += (int64_t)(y_mod > 0 ? blockIdx.z % y_mod : blockIdx.z) * y_bs;
   const int i = N + blockIdx.y;
   for (int j = blockIdx.x * 256 + threadIdx.x; j < Np; j += gridDim.x * 256) {
     double v;
@@ -199,9 +204,9 @@ __global__ __launch_bounds__(256) void augment_kernel(double* __restrict__ K, in
 }
 
 int launch_augment(gpx_ctx* ctx, double* dK, int64_t ld, int N, int Np, const double* dy, int batch,
-                   int64_t k_bs, int64_t y_bs) {
+                   int64_t k_bs, int64_t y_bs, int y_mod) {
   dim3 grid(min(64, (Np + 255) / 256), Np - N, batch > 1 ? batch : 1);
-  augment_kernel<<<grid, 256, 0, ctx->s>>>(dK, ld, N, Np, dy, k_bs, y_bs);
+  augment_kernel<<<grid, 256, 0, ctx->s>>>(dK, ld, N, Np, dy, k_bs, y_bs, y_mod);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }

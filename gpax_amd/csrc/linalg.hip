@@ -329,7 +329,9 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(KernelParams kpv,
                                                            int64_t ldp, double diag_add,
                                                            double* __restrict__ Cov, int64_t ldc,
                                                            int64_t part_bs, int64_t cov_bs,
-                                                           const ThetaDev* __restrict__ th) {
+                                                           const ThetaDev* __restrict__ th,
+                                                           TaskStride ts) {
+  if (ts.mod > 0) Xn += (blockIdx.z % ts.mod) * ts.x_bs; // per-task X_new
   const int b = blockIdx.x * 64 + (threadIdx.x & 63);
   const int a0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
   if (b >= Mp) return;
@@ -368,10 +370,10 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(KernelParams kpv,
 int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXnew, int M, int Mp,
                         const double* dPart, int splits, int64_t split_stride, int64_t ldp,
                         double diag_add, double* dCov, int64_t ldc, int batch, int64_t part_bs,
-                        int64_t cov_bs, const ThetaDev* th) {
+                        int64_t cov_bs, const ThetaDev* th, TaskStride ts) {
   dim3 grid((Mp + 63) / 64, (Mp + 15) / 16, batch > 1 ? batch : 1);
   cov_finalize_kernel<<<grid, 256, 0, ctx->s>>>(kp, dXnew, M, Mp, dPart, splits, split_stride,
-                                                ldp, diag_add, dCov, ldc, part_bs, cov_bs, th);
+                                                ldp, diag_add, dCov, ldc, part_bs, cov_bs, th, ts);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -397,8 +399,10 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernelParams kpv,
                                                             double* __restrict__ part,
                                                             int64_t k_bs, int64_t alpha_bs,
                                                             int64_t part_bs,
-                                                            const ThetaDev* __restrict__ th) {
+                                                            const ThetaDev* __restrict__ th,
+                                                            TaskStride ts) {
   constexpr int DM = (D > 0) ? D : GPX_MAX_DIM;
+  if (ts.mod > 0) X += (blockIdx.y % ts.mod) * ts.x_bs; // per-task training inputs
   const ThetaDev* t = (th != nullptr) ? th + blockIdx.y : nullptr;
   const double k_scale = t ? t->kp.scale : kpv.scale;
   const double pi_over_p = t ? t->kp.pi_over_p : kpv.pi_over_p;
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
 int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int N,
                          const double* dKinv, int64_t ld, const double* dalpha, double* dpart,
                          int* nblocks_out, int batch, int64_t k_bs, int64_t alpha_bs,
-                         const ThetaDev* th) {
+                         const ThetaDev* th, TaskStride ts) {
   const int nt = (N + GC_TILE - 1) / GC_TILE;
   const int nblocks = nt * (nt + 1) / 2;
   *nblocks_out = nblocks;
@@ -530,7 +534,7 @@ int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX,
   const int64_t part_bs = (int64_t)nblocks * GC_MAXV;
 #define GPX_GC_LAUNCH(KIND, DD)                                                                         \
   grad_contract_kernel<KIND, DD><<<grid, 256, 0, ctx->s>>>(kp, dX, N, dKinv, ld, dalpha, dpart, k_bs, \
-                                                           alpha_bs, part_bs, th)
+                                                           alpha_bs, part_bs, th, ts)
 #define GPX_GC_KIND(KIND)            \
   switch (kp.d) {                    \
     case 1: GPX_GC_LAUNCH(KIND, 1); break; \

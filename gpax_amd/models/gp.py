@@ -201,7 +201,7 @@ class ExactGP:
         if want_grad:
             g_ell, g_scale, g_noise, alpha = eng.lml_grad()
             g = np.concatenate([g_ell, [g_scale, g_noise]])
-        return self._chain_rule(sites, u, theta, lml, g, alpha, jacobian)
+        return self._chain_rule(sites, u, theta, lml, self._glik(g), alpha, jacobian)
 
     def _log_joint_batch(self, sites, us, jitter: float, jacobian: bool, eng=None):
         """_log_joint for a list of unconstrained vectors in ONE device pass (gpx_fit_batch: the chains of
@@ -222,21 +222,27 @@ class ExactGP:
             if info[b] != 0 or not np.isfinite(lml[b]):
                 out.append((-np.inf, np.zeros_like(u)))
             else:
-                out.append(self._chain_rule(sites, u, thetas[b], float(lml[b]), grad[b], alpha[b], jacobian))
+                out.append(self._chain_rule(sites, u, thetas[b], float(lml[b]), self._glik(grad[b]), alpha[b],
+                                            jacobian))
         return out
 
-    def _chain_rule(self, sites, u, theta, lml, g, alpha, jacobian: bool):
+    def _glik(self, g):
+        """Device gradient rows [..., (d/d k_length.., (d/d period), d/d k_scale, d/d noise)] -> site name -> array."""
+        if g is None:
+            return None
+        d_ = self.kernel_dim
+        ne = d_ + (1 if self.kernel_name == "Periodic" else 0)
+        glik = {"k_length": g[..., :d_], "k_scale": g[..., ne], "noise": g[..., ne + 1]}
+        if self.kernel_name == "Periodic":
+            glik["period"] = g[..., d_]
+        return glik
+
+    def _chain_rule(self, sites, u, theta, lml, glik, alpha, jacobian: bool):
         """Add the log-priors (and log-Jacobians) to the device log-likelihood and map its gradient
-        g = [d/d k_length.., (d/d period), d/d k_scale, d/d noise] to the unconstrained vector u."""
+        (glik: site name -> d lml / d site, any shape matching the site) to the unconstrained vector u."""
         val = lml
         grad = np.zeros_like(u)
-        want_grad = g is not None
-        if want_grad:
-            d_ = self.kernel_dim
-            ne = d_ + (1 if self.kernel_name == "Periodic" else 0)
-            glik = {"k_length": g[:d_], "k_scale": g[ne:ne + 1], "noise": g[ne + 1:ne + 2]}
-            if self.kernel_name == "Periodic":
-                glik["period"] = g[d_:d_ + 1]
+        want_grad = glik is not None
         off = 0
         for s in sites:
             ui = u[off:off + s.size]
@@ -254,7 +260,7 @@ class ExactGP:
                     tp[s.name] = float(x[0]) + h
                     tm[s.name] = float(x[0]) - h
                     dm = (self._mean(self.X_train, tp) - self._mean(self.X_train, tm)) / (2 * h)
-                    gx = np.array([float(alpha @ dm)])
+                    gx = np.array([float(np.sum(alpha * dm))])
                 gx = gx + s.dist.grad_log_prob(x)
                 gu = gx * s.dist.dx_du(ui)
                 if jacobian:
@@ -357,7 +363,7 @@ class ExactGP:
         for s in sites:
             ui = draws[:, :, off:off + s.size]
             x = s.dist.transform(ui)
-            samples[s.name] = x if s.shape else x[..., 0]
+            samples[s.name] = x.reshape(x.shape[:2] + tuple(s.shape)) if s.shape else x[..., 0]
             off += s.size
         self._samples = samples
         self._chain_shape = draws.shape[:2]

@@ -1,0 +1,205 @@
+"""
+vExactGP — fully Bayesian GP for vector-valued targets with the reference's surface
+(gpax/models/vgp.py:23-208): T independent exact GPs ("tasks"), each with its own inputs X[t], targets
+y[t] and kernel hyper-parameters, inferred jointly with NUTS.
+
+The reference vmaps the kernel and the MVN over the task axis (vgp.py:87-96,173-176).  Here the task is a
+grid dimension of the same batched launches the predictive sweep uses: one `gpx_fit_batch` evaluates the T
+log-likelihoods and gradients of a leapfrog, one `gpx_predict_sweep` the S x T posteriors of predict
+(entry b of a batch is task b % T, reading X[t] / X_new[t] / y[t] through per-task strides).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from .. import _lib
+from ..infer import dist
+from ..utils.utils import rng_from_key
+from .gp import ExactGP, _Site
+
+
+class vExactGP(ExactGP):
+    """
+    Gaussian process class for vector-valued targets
+
+    Args: as ExactGP.  X: (T, N) or (T, N, d); y: (T, N).
+    """
+
+    # -- data plumbing (vgp.py:199-208) -----------------------------------------------------------------
+    def _set_data(self, X, y=None):
+        X = np.asarray(X, dtype=np.float64)
+        X = X[..., None] if X.ndim == 2 else X  # add feature pseudo-dimension
+        X = np.ascontiguousarray(X)
+        if y is not None:
+            y = np.ascontiguousarray(np.asarray(y, dtype=np.float64))
+            if y.shape[0] != X.shape[0]:
+                raise AssertionError("Task dimensions must be identical in inputs and targets")
+            return X, y
+        return X
+
+    def _set_training_data(self, X_train_new=None, y_train_new=None, device=None) -> None:
+        if X_train_new is not None:
+            self.X_train = self._set_data(X_train_new)
+        if y_train_new is not None:
+            self.y_train = np.ascontiguousarray(np.asarray(y_train_new, dtype=np.float64))
+        if isinstance(device, int):
+            self._device = device
+
+    @property
+    def _tasks(self) -> int:
+        return self.X_train.shape[0]
+
+    # -- sample sites (vgp.py:98-120) -------------------------------------------------------------------
+    def _sites(self):
+        T = self._tasks
+        # The reference draws k_length from LogNormal(0, 1) unconditionally and hands `lengthscale_prior_dist`
+        # to k_scale (vgp.py:111-113); mirrored as is.
+        scale_dist = self.lengthscale_prior_dist if self.lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
+        noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
+        sites = [_Site("k_length", (T, self.kernel_dim), dist.LogNormal(0.0, 1.0)),
+                 _Site("k_scale", (T,), scale_dist)]
+        if self.kernel_name == "Periodic":
+            sites.append(_Site("period", (T,), dist.LogNormal(0.0, 1.0)))
+        sites.append(_Site("noise", (T,), noise_dist))  # plate "noise_plate", vgp.py:89-96
+        for name, d in self._mean_prior_dict().items():
+            sites.append(_Site(name, (), d))
+        return sites
+
+    def _ells(self, theta) -> np.ndarray:
+        """(T, n_ell): per-task lengthscales (+ period)."""
+        T, d = self._tasks, self.kernel_dim
+        ell = np.broadcast_to(np.asarray(theta["k_length"], dtype=np.float64).reshape(T, -1), (T, d))
+        if self.kernel_name == "Periodic":
+            ell = np.concatenate([ell, np.asarray(theta["period"], dtype=np.float64).reshape(T, 1)], axis=1)
+        return np.ascontiguousarray(ell)
+
+    def _residual(self, theta) -> np.ndarray:
+        if self.mean_fn is None:
+            return self.y_train
+        return self.y_train - self._mean(self.X_train, theta)
+
+    # -- log joint (vgp.py:62-96): sum of the T task log-likelihoods + priors ---------------------------
+    def _log_joint(self, sites, u, jitter: float, jacobian: bool, want_grad: bool = True, eng=None):
+        return self._log_joint_batch(sites, [u], jitter, jacobian, eng=eng)[0]
+
+    def _log_joint_batch(self, sites, us, jitter: float, jacobian: bool, eng=None):
+        if eng is None:
+            eng = self._engine()
+        T = self._tasks
+        thetas = [self._unpack(sites, u) for u in us]
+        ells = np.concatenate([self._ells(t) for t in thetas])
+        scales = np.concatenate([np.asarray(t["k_scale"], dtype=np.float64).reshape(T) for t in thetas])
+        noises = np.concatenate([np.asarray(t["noise"], dtype=np.float64).reshape(T) for t in thetas])
+        if self.mean_fn is None:
+            yres = self.y_train  # (T, N): entry b reads row b % T
+        else:
+            yres = np.concatenate([self._residual(t) for t in thetas])
+        lml, info, grad, alpha = eng.fit_batch(self._kind, ells, scales, noises, jitter, yres, want_grad=True)
+        out = []
+        for c, u in enumerate(us):
+            sl = slice(c * T, (c + 1) * T)
+            if np.any(info[sl] != 0) or not np.all(np.isfinite(lml[sl])):
+                out.append((-np.inf, np.zeros_like(u)))
+            else:
+                out.append(self._chain_rule(sites, u, thetas[c], float(np.sum(lml[sl])), self._glik(grad[sl]),
+                                            alpha[sl], jacobian))
+        return out
+
+    # -- posterior for one sample of the parameters (vgp.py:122-176) ------------------------------------
+    def get_mvn_posterior(self, X_new: np.ndarray, params: Dict[str, np.ndarray], noiseless: bool = False,
+                          **kwargs: float) -> Tuple[np.ndarray, np.ndarray]:
+        """mean (T, M) and cov (T, M, M) of the T task posteriors for a single sample of GP parameters."""
+        X_new = self._set_data(X_new)
+        jitter = float(kwargs.get("jitter", 1e-6))
+        T = self._tasks
+        ells = self._ells(params)
+        scales = np.broadcast_to(np.asarray(params["k_scale"], dtype=np.float64).reshape(-1), (T,))
+        noises = np.broadcast_to(np.asarray(params["noise"], dtype=np.float64).reshape(-1), (T,))
+        yres = self._residual(params)
+        eng = _lib.get_engine(self._device)
+        eng._train_owner = None  # the shared context is re-pointed at one task at a time below
+        means, covs = [], []
+        for t in range(T):
+            eng.set_train(self.X_train[t])
+            _, info = eng.factor(self._kind, ells[t], float(scales[t]), float(noises[t]), jitter, yres[t])
+            noise_p = float(noises[t]) * (1 - int(bool(noiseless)))
+            mean, cov, _ = eng.posterior(X_new[t], noise_p, jitter, want_cov=True)
+            if info != 0:
+                mean, cov = np.full_like(mean, np.nan), np.full_like(cov, np.nan)
+            means.append(mean)
+            covs.append(cov)
+        mean, cov = np.stack(means), np.stack(covs)
+        if self.mean_fn is not None:
+            mean = mean + self._mean(X_new, params)
+        return mean, cov
+
+    # -- predict (gp.py:351-399 through vgp.py's task vmap) ---------------------------------------------
+    def predict(self, rng_key, X_new: np.ndarray, samples: Optional[Dict[str, np.ndarray]] = None, n: int = 1,
+                filter_nans: bool = False, noiseless: bool = False, device=None,
+                **kwargs: float) -> Tuple[np.ndarray, np.ndarray]:
+        """Returns y_mean (T, M) and y_sampled (S, n, T, M)."""
+        X_new = self._set_data(X_new)
+        if samples is None:
+            samples = self.get_samples(chain_dim=False)
+        if isinstance(device, int):
+            self._device = device
+        jitter = float(kwargs.get("jitter", 1e-6))
+        T, M = self._tasks, X_new.shape[1]
+        S = len(next(iter(samples.values())))
+        per = [{k: np.asarray(v)[s] for k, v in samples.items()} for s in range(S)]
+        ells = np.concatenate([self._ells(p) for p in per])                        # entries ordered [s][t]
+        scales = np.asarray(samples["k_scale"], dtype=np.float64).reshape(S * T)
+        noises = np.asarray(samples["noise"], dtype=np.float64).reshape(S * T)
+        mean_shift = None
+        if self.mean_fn is not None:
+            yres = np.concatenate([self._residual(p) for p in per])                # (S*T, N)
+            mean_shift = np.stack([self._mean(X_new, p) for p in per])             # (S, T, M)
+        else:
+            yres = self.y_train                                                    # (T, N)
+        eps = rng_from_key(rng_key).standard_normal((S, n, T, M))
+        eng = self._engine()
+        means, draws, infos = eng.predict_sweep(self._kind, ells, scales, noises, yres, X_new, noiseless, jitter,
+                                                np.ascontiguousarray(eps.transpose(0, 2, 1, 3)).reshape(S * T, n, M))
+        means = means.reshape(S, T, M)
+        y_sampled = draws.reshape(S, T, n, M).transpose(0, 2, 1, 3)
+        if mean_shift is not None:
+            means = means + mean_shift
+            y_sampled = y_sampled + mean_shift[:, None]
+        if filter_nans:
+            keep = ~np.isnan(y_sampled).any(axis=(1, 2, 3))
+            y_sampled = y_sampled[keep]
+        return means.mean(0), np.ascontiguousarray(y_sampled)
+
+    def predict_in_batches(self, rng_key, X_new, batch_size=100, samples=None, n=1, filter_nans=False,
+                           predict_fn=None, noiseless=False, device=None, **kwargs):
+        """predict() over slices of the M axis of X_new (vgp.py:178-197)."""
+        X_new = self._set_data(X_new)
+        y_pred, y_sampled = self._predict_in_batches(rng_key, X_new, batch_size, 1, samples, n, filter_nans,
+                                                     predict_fn, noiseless, device, **kwargs)
+        return np.concatenate(y_pred, -1), np.concatenate(y_sampled, -1)
+
+    def sample_from_prior(self, rng_key, X: np.ndarray, num_samples: int = 10):
+        """Samples from the prior predictive distribution at X: (num_samples, T, N)."""
+        X = self._set_data(X)
+        rng = rng_from_key(rng_key)
+        eng = _lib.get_engine(self._device)
+        T, N = X.shape[0], X.shape[1]
+        saved = self.X_train
+        self.X_train = X  # the sites are sized by the task count of X
+        try:
+            out = np.empty((num_samples, T, N))
+            for i in range(num_samples):
+                theta = {s.name: (s.dist.sample(rng, s.shape) if s.shape else float(s.dist.sample(rng)))
+                         for s in self._sites()}
+                ells = self._ells(theta)
+                loc = self._mean(X, theta) if self.mean_fn is not None else np.zeros((T, N))
+                for t in range(T):
+                    K = eng.gram(self._kind, X[t], X[t], ells[t], float(theta["k_scale"][t]),
+                                 float(theta["noise"][t]) + 1e-6, True)
+                    L, info = eng.potrf(K)
+                    out[i, t] = loc[t] + L @ rng.standard_normal(N) if info == 0 else np.nan
+        finally:
+            self.X_train = saved
+        return out

@@ -69,6 +69,12 @@ int gpx_gram(gpx_ctx* ctx, int kind, const double* X, int n, const double* Z, in
  * Uploads X_train (N,d) and sizes the device workspaces (Gram/factor buffer etc.). */
 int gpx_set_train(gpx_ctx* ctx, const double* X, int N, int d);
 
+/* T independent training sets X (T,N,d) of vector-valued GPs (vExactGP._set_data / model,
+ * gpax/models/vgp.py:62-96,199-208: `jax.vmap(self.kernel)` over the task axis).  Afterwards the
+ * batched entry points (gpx_fit_batch, gpx_predict_sweep) treat entry b as task b % T — its own
+ * X[t], X_new[t] and (yres_rows = T) y residuals; the single-theta entry points refuse T > 1. */
+int gpx_set_train_tasks(gpx_ctx* ctx, const double* X, int T, int N, int d);
+
 /* ---- log marginal likelihood: ExactGP.model, gpax/models/gp.py:137-164 --------------------
  * (NumPyro MultivariateNormal(loc, covariance_matrix=k).log_prob(y): Cholesky, triangular
  * solve, sum log diag.)  Builds K = kernel(X,X,theta,noise,jitter) on device, factors it
@@ -89,12 +95,14 @@ int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* gra
  * The chains of MCMC(num_chains > 1, chain_method='parallel'|'vectorized') (gpax/models/gp.py:173-174,
  * 207-218) ask for one log-likelihood gradient each per leapfrog; this entry evaluates them as ONE
  * launch sequence with the chain as a grid dimension.  For entry b:
- *   theta_b = (ells[b*ne .. ), scales[b], noises[b]), ne = d (+1: period); yres_b = yres + b*yres_stride
+ *   theta_b = (ells[b*ne .. ), scales[b], noises[b]), ne = d (+1: period);
+ *   yres (yres_rows, N): yres_rows = 1 (shared), B (one per entry) or T (per task, row b % T);
+ *   after gpx_set_train_tasks entry b is task b % T: X[b % T] (vExactGP.model, vgp.py:62-96)
  *   lml[b], info[b] as gpx_factor; grad[b*(ne+2) ..] = [d/d ell.., d/d scale, d/d noise];
  *   alpha[b*N ..] = K_b^-1 yres_b.  grad == NULL: values only.  Entries with info != 0 are NaN.
  * The per-entry arithmetic is that of gpx_factor / gpx_lml_grad (bit-identical results). */
 int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const double* scales,
-                  const double* noises, double jitter, const double* yres, int64_t yres_stride,
+                  const double* noises, double jitter, const double* yres, int yres_rows,
                   double* lml, int* info, double* grad, double* alpha);
 
 /* ---- posterior: ExactGP.get_mvn_posterior, gpax/models/gp.py:253-277 ----------------------
@@ -120,13 +128,15 @@ int gpx_mvn_draw(gpx_ctx* ctx, const double* eps, int n, double* out, int* info)
  * materialised and small-N sweeps are not launch-bound.  Results do not depend on B.
  * For sample s:
  *   theta_s = (ells[s*d .. s*d+d), scales[s], noises[s]);
- *   yres_s  = yres + s*yres_stride (yres_stride = 0 when no mean function);
+ *   yres (yres_rows, N): yres_rows = 1 (no sampled mean-function parameters), S (one row per sample)
+ *   or T (per task, row s % T, after gpx_set_train_tasks — then Xnew is (T, M, d) and sample s is
+ *   task s % T: samples ordered [s][t], vExactGP.predict, gp.py:351-399 through vgp.py:151-176);
  *   mean_s, cov_s as gpx_posterior with noise_p = noiseless ? 0 : noises[s];
  *   samples[s] = mean_s + chol(cov_s) eps[s]   (n draws).
  * means (S*M), samples (S*n*M), infos (S; bit 0.. = train-factor info, negative = draw chol
  * failed).  Rows whose info != 0 are NaN-filled.  eps may be NULL when n == 0. */
 int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales,
-                      const double* noises, const double* yres, int64_t yres_stride,
+                      const double* noises, const double* yres, int yres_rows,
                       const double* Xnew, int M, int noiseless, double jitter,
                       const double* eps, int n, double* means, double* samples, int* infos);
 

@@ -29,8 +29,18 @@ class OracleEngine:
         self._post = None
 
     def set_train(self, X):
-        self.X = np.asarray(X, dtype=np.float64)
+        X = np.asarray(X, dtype=np.float64)
+        self._Xt = X if X.ndim == 3 else None  # (T, N, d): task-specific training sets (vExactGP)
+        self.T = X.shape[0] if X.ndim == 3 else 1
+        self.X = X[0] if X.ndim == 3 else X
         self.N, self.d = self.X.shape
+
+    def _row(self, arr, b, count):
+        """Row of a (N,) | (count, N) | (T, N) table for batch entry b."""
+        arr = np.asarray(arr, dtype=np.float64)
+        if arr.ndim == 1:
+            return arr
+        return arr[b] if arr.shape[0] == count else arr[b % self.T]
 
     def gram(self, kind, X, Z, ell, scale, diag_add, add_diag):
         X, Z = np.asarray(X, dtype=np.float64), np.asarray(Z, dtype=np.float64)
@@ -93,7 +103,9 @@ class OracleEngine:
         lml, info = np.empty(B), np.zeros(B, dtype=np.int32)
         grad, alpha = ([None] * B, [None] * B)
         for b in range(B):
-            lml[b], info[b] = self.factor(kind, ells[b], scales[b], noises[b], jitter, yres if yres.ndim == 1 else yres[b])
+            if self._Xt is not None:
+                self.X = self._Xt[b % self.T]
+            lml[b], info[b] = self.factor(kind, ells[b], scales[b], noises[b], jitter, self._row(yres, b, B))
             if want_grad and info[b] == 0:
                 g_ell, gs, gn, alpha[b] = self.lml_grad()
                 grad[b] = np.concatenate([np.asarray(g_ell).reshape(-1), [gs, gn]])
@@ -134,14 +146,16 @@ class OracleEngine:
         ells = np.asarray(ells, dtype=np.float64)
         S = ells.shape[0]
         Xnew = np.asarray(Xnew, dtype=np.float64)
-        M = Xnew.shape[0]
+        M = Xnew.shape[-2]
         n = 0 if eps is None else np.asarray(eps).shape[1]
         yres = np.asarray(yres, dtype=np.float64)
         means, samples, infos = np.empty((S, M)), np.empty((S, n, M)), np.zeros(S, dtype=np.int32)
         for s in range(S):
-            ys = yres if yres.ndim == 1 else yres[s]
-            lml, info = self.factor(kind, ells[s], scales[s], noises[s], jitter, ys)
-            m, cov, _ = self.posterior(Xnew, 0.0 if noiseless else noises[s], jitter)
+            if self._Xt is not None:
+                self.X = self._Xt[s % self.T]
+            lml, info = self.factor(kind, ells[s], scales[s], noises[s], jitter, self._row(yres, s, S))
+            m, cov, _ = self.posterior(Xnew if Xnew.ndim == 2 else Xnew[s % self.T], 0.0 if noiseless else noises[s],
+                                       jitter)
             means[s] = m
             infos[s] = info
             if n:
