@@ -64,7 +64,8 @@ def load_library() -> C.CDLL:
         "gpx_posterior": (C.c_int, [vp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]),
         "gpx_mvn_draw": (C.c_int, [vp, _dp, C.c_int, _dp, _ip]),
         "gpx_predict_sweep": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp,
-                                        C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip]),
+                                        C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip, _dp]),
+        "gpx_set_diag": (C.c_int, [vp, _dp, C.c_int]),
         "gpx_sgp_bound": (C.c_int, [vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp, C.c_int, _dp, C.c_int,
                                     _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
         "gpx_sgp_posterior": (C.c_int, [vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp, C.c_int, _dp, _dp,
@@ -88,7 +89,7 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "gpx_init gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks "
+    "gpx_init gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
     "gpx_factor gpx_lml_grad gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
     "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
@@ -206,6 +207,7 @@ class Engine:
         """X (N, d), or (T, N, d): T task-specific training sets (vExactGP) — then the batched entry points
         treat entry b as task b % T."""
         X = _f64(X)
+        self._diag_key = None  # gpx_set_train clears the per-point diagonal
         if X.ndim == 3:
             self.T, self.N, self.d = X.shape
             self._check(self._lib.gpx_set_train_tasks(self._ctx, _ptr(X), self.T, self.N, self.d),
@@ -273,8 +275,16 @@ class Engine:
         self._check(self._lib.gpx_mvn_draw(self._ctx, _ptr(eps), n, _ptr(out), C.byref(info)), "gpx_mvn_draw")
         return out, info.value
 
+    def set_diag(self, v) -> None:
+        """Per-point variances added to K's diagonal (None clears them); see gpx_set_diag."""
+        if v is None:
+            self._check(self._lib.gpx_set_diag(self._ctx, None, 0), "gpx_set_diag")
+            return
+        v = _f64(v, (self.N,))
+        self._check(self._lib.gpx_set_diag(self._ctx, _ptr(v), self.N), "gpx_set_diag")
+
     def predict_sweep(self, kind: int, ells, scales, noises, yres, Xnew, noiseless: bool, jitter: float,
-                      eps: Optional[np.ndarray]):
+                      eps: Optional[np.ndarray], want_var: bool = False):
         ells = _f64(ells)
         S = ells.shape[0]
         ells = _f64(ells, (S, n_ell(kind, self.d)))
@@ -291,10 +301,13 @@ class Engine:
         means = np.empty((S, M))
         samples = np.empty((S, n, M))
         infos = np.zeros(S, dtype=np.int32)
+        vars_ = np.empty((S, M)) if want_var else None
         self._check(self._lib.gpx_predict_sweep(
             self._ctx, kind, S, _ptr(ells), _ptr(scales), _ptr(noises), _ptr(yres), rows, _ptr(Xnew), M,
             int(bool(noiseless)), float(jitter), _ptr(eps_c), n, _ptr(means),
-            _ptr(samples) if n else None, infos.ctypes.data_as(_ip)), "gpx_predict_sweep")
+            _ptr(samples) if n else None, infos.ctypes.data_as(_ip), _ptr(vars_)), "gpx_predict_sweep")
+        if want_var:
+            return means, samples, infos, vars_
         return means, samples, infos
 
     # -- sparse GP ------------------------------------------------------------------------------

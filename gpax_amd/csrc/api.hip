@@ -110,7 +110,8 @@ int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
   GPX_TRY(ensure(ctx, ctx->Linv, (size_t)B * bp.linv_bs * sizeof(double)));
   double* K = ctx->K.d();
   GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->X.d(), N, N, ctx->X.d(), N, Np,
-                             ctx->noise + ctx->jitter, 1, 1, K, ctx->ldk, B, bp.k_bs, bp.th, 1, ts_train(ctx)));
+                             ctx->noise + ctx->jitter, 1, 1, K, ctx->ldk, B, bp.k_bs, bp.th, 1, ts_train(ctx),
+                             ctx->has_diag ? ctx->diagv.d() : nullptr));
   GPX_TRY(launch_augment(ctx, K, ctx->ldk, N, Np, bp.yres, B, bp.k_bs, bp.y_bs, bp.y_mod));
   if (fused) {
     // k_pX = kernel(X_new, X_train, params, jitter=0.0): no diagonal term (gp.py:268)
@@ -326,13 +327,16 @@ __global__ __launch_bounds__(256) void sweep_store_kernel(const double* __restri
                                                           const int* __restrict__ info_train,
                                                           const int* __restrict__ info_cov,
                                                           double* __restrict__ means, double* __restrict__ samples,
-                                                          int* __restrict__ infos) {
+                                                          int* __restrict__ infos,
+                                                          const double* __restrict__ var,
+                                                          double* __restrict__ vars) {
   const int a = blockIdx.x * 256 + threadIdx.x;
   const int r = blockIdx.y, b = blockIdx.z;
   if (a < M) {
-    if (r == 0)
+    if (r == 0) {
       means[(int64_t)b * M + a] = mean[(int64_t)b * mean_bs + a];
-    else
+      if (vars != nullptr) vars[(int64_t)b * M + a] = var[(int64_t)b * mean_bs + a];
+    } else
       samples[((int64_t)b * n + (r - 1)) * M + a] = draws[(int64_t)b * eps_bs + (int64_t)(r - 1) * ldc + a];
   }
   if (a == 0 && r == 0 && infos != nullptr) {
@@ -351,6 +355,7 @@ struct SweepIO {
   double* dMeans = nullptr;      // device outputs (nullptr: results stay in the batch buffers)
   double* dSamples = nullptr;
   int* dInfos = nullptr;
+  double* dVars = nullptr; // device (S, M) posterior variances (diag of cov) or nullptr
 };
 
 // Samples per launch: enough that the small-N pipeline fills the chip, bounded by memory.
@@ -459,7 +464,8 @@ int sweep_core(gpx_ctx* ctx, const SweepIO& io) {
       sweep_store_kernel<<<grid, 256, 0, ctx->stream>>>(
           ctx->mean.d(), bp.mean_bs, ctx->draws.d(), ctx->ldc, bp.eps_bs, n, M, bp.info_train, bp.info_cov,
           io.dMeans + (int64_t)s0 * M, io.dSamples ? io.dSamples + (int64_t)s0 * n * M : nullptr,
-          io.dInfos ? io.dInfos + 2 * s0 : nullptr);
+          io.dInfos ? io.dInfos + 2 * s0 : nullptr, ctx->var.d(),
+          io.dVars ? io.dVars + (int64_t)s0 * M : nullptr);
       GPX_HIP(ctx, hipGetLastError());
     }
     ctx->sweep_batches += 1;
@@ -536,7 +542,7 @@ void gpx_destroy(gpx_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->X,    &ctx->K,   &ctx->W,       &ctx->Linv,   &ctx->yres, &ctx->scal,
                       &ctx->part, &ctx->alpha, &ctx->Xnew,  &ctx->Vt,     &ctx->Cov,  &ctx->CovLinv,
                       &ctx->SplitK, &ctx->mean, &ctx->var,  &ctx->eps,    &ctx->draws, &ctx->tA,
-                      &ctx->tB,   &ctx->tC,  &ctx->thtab,   &ctx->binfo, &ctx->bscal, &ctx->byres};
+                      &ctx->tB,   &ctx->tC,  &ctx->thtab,   &ctx->binfo, &ctx->bscal, &ctx->byres, &ctx->diagv};
     for (DevBuf* b : bufs) b->release();
     sgp_release(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -610,6 +616,7 @@ int gpx_set_train_tasks(gpx_ctx* ctx, const double* X, int T, int N, int d) {
   ctx->d = d;
   ctx->T = T;
   ctx->M = 0; // X_new of a previous training set does not carry over
+  ctx->has_diag = false;
   ctx->Np = round_up(N + 1, TILE);
   ctx->ldk = pick_ld(ctx->Np);
   GPX_TRY(ensure(ctx, ctx->X, (size_t)T * N * d * sizeof(double)));
@@ -625,6 +632,24 @@ int gpx_set_train_tasks(gpx_ctx* ctx, const double* X, int T, int N, int d) {
 }
 
 int gpx_set_train(gpx_ctx* ctx, const double* X, int N, int d) { return gpx_set_train_tasks(ctx, X, 1, N, d); }
+
+int gpx_set_diag(gpx_ctx* ctx, const double* v, int n) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (v == nullptr || n == 0) {
+    ctx->has_diag = false;
+    ctx->factored = false;
+    return 0;
+  }
+  if (ctx->N < 1 || n != ctx->N) return bad_arg(ctx, "gpx_set_diag: need one value per training point");
+  if (ctx->T != 1) return bad_arg(ctx, "gpx_set_diag: not available with per-task training sets");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  GPX_TRY(ensure(ctx, ctx->diagv, (size_t)n * sizeof(double)));
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->diagv.d(), v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->has_diag = true;
+  ctx->factored = false;
+  return 0;
+}
 
 int gpx_factor(gpx_ctx* ctx, int kind, const double* ell, double scale, double noise,
                double jitter, const double* yres, double* lml, int* info) {
@@ -801,7 +826,7 @@ int gpx_mvn_draw(gpx_ctx* ctx, const double* eps, int n, double* out, int* info)
 int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales,
                       const double* noises, const double* yres, int yres_rows,
                       const double* Xnew, int M, int noiseless, double jitter,
-                      const double* eps, int n, double* means, double* samples, int* infos) {
+                      const double* eps, int n, double* means, double* samples, int* infos, double* vars) {
   if (!ctx || ctx->device < 0) return -1;
   if (ctx->N < 1) return bad_arg(ctx, "gpx_set_train must be called first");
   if (S < 0 || n < 0) return bad_arg(ctx, "negative count");
@@ -814,10 +839,11 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   const int N = ctx->N;
   GPX_TRY(set_xnew(ctx, Xnew, M));
   // device staging for all inputs/outputs of the sweep: nothing crosses PCIe inside the loop
-  DevBuf dEps, dYres, dMeans, dSamples, dInfos;
+  DevBuf dEps, dYres, dMeans, dSamples, dInfos, dVars;
   int rc = 0;
   auto cleanup = [&]() {
     (void)hipStreamSynchronize(ctx->stream); // nothing may still read the staging buffers
+    dVars.release();
     dEps.release();
     dYres.release();
     dMeans.release();
@@ -844,6 +870,7 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   SWEEP_TRY(ensure(ctx, dMeans, (size_t)S * M * sizeof(double)));
   SWEEP_TRY(ensure(ctx, dInfos, (size_t)2 * S * sizeof(int)));
   SWEEP_HIP(hipMemsetAsync(dInfos.p, 0, (size_t)2 * S * sizeof(int), ctx->stream));
+  if (vars) SWEEP_TRY(ensure(ctx, dVars, (size_t)S * M * sizeof(double)));
   if (strided) {
     SWEEP_TRY(ensure(ctx, dYres, (size_t)yres_rows * N * sizeof(double)));
     SWEEP_HIP(hipMemcpyAsync(dYres.d(), yres, (size_t)yres_rows * N * sizeof(double), hipMemcpyHostToDevice,
@@ -873,6 +900,7 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   io.dMeans = dMeans.d();
   io.dSamples = n > 0 ? dSamples.d() : nullptr;
   io.dInfos = dInfos.i();
+  io.dVars = vars ? dVars.d() : nullptr;
   SWEEP_TRY(sweep_core(ctx, io));
   std::vector<int> hinfos(2 * (size_t)S);
   SWEEP_HIP(hipMemcpyAsync(means, dMeans.d(), (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost,
@@ -882,6 +910,9 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
                              hipMemcpyDeviceToHost, ctx->stream));
   SWEEP_HIP(hipMemcpyAsync(hinfos.data(), dInfos.p, (size_t)2 * S * sizeof(int), hipMemcpyDeviceToHost,
                            ctx->stream));
+  if (vars)
+    SWEEP_HIP(hipMemcpyAsync(vars, dVars.d(), (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost,
+                             ctx->stream));
   SWEEP_HIP(hipStreamSynchronize(ctx->stream));
   cleanup();
 #undef SWEEP_TRY
@@ -893,7 +924,10 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
     const int code = it != 0 ? it : (ic != 0 ? -ic : 0);
     if (infos) infos[s] = code;
     if (it != 0)
-      for (int a = 0; a < M; ++a) means[(int64_t)s * M + a] = NAN;
+      for (int a = 0; a < M; ++a) {
+        means[(int64_t)s * M + a] = NAN;
+        if (vars) vars[(int64_t)s * M + a] = NAN;
+      }
     if (code != 0 && n > 0)
       for (int64_t t = 0; t < (int64_t)n * M; ++t) samples[(int64_t)s * n * M + t] = NAN;
   }
@@ -960,7 +994,8 @@ int gpx_time_stage(gpx_ctx* ctx, int stage, int reps, double* elapsed_ms) {
     switch (stage) {
       case GPX_STAGE_GRAM:
         GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->X.d(), ctx->N, ctx->N, ctx->X.d(), ctx->N,
-                                   ctx->Np, ctx->noise + ctx->jitter, 1, 1, ctx->K.d(), ctx->ldk));
+                                   ctx->Np, ctx->noise + ctx->jitter, 1, 1, ctx->K.d(), ctx->ldk, 1, 0, nullptr, 0,
+                                   TaskStride(), ctx->has_diag ? ctx->diagv.d() : nullptr));
         ctx->factored = false;
         break;
       case GPX_STAGE_POTRF:

@@ -127,6 +127,8 @@ struct gpx_ctx {
   gpx::DevBuf W;     // Np x ldk : L^-T (upper), allocated on first gradient
   gpx::DevBuf Linv;  // (Np/128) x 128 x 128 inverses of the diagonal blocks of L
   gpx::DevBuf yres;  // N
+  gpx::DevBuf diagv; // N: per-point variance added to K's diagonal (gpx_set_diag), when has_diag
+  bool has_diag = false;
   gpx::DevBuf scal;  // small device scalars (lml pieces, gradient, info)
   gpx::DevBuf part;  // reduction partials
   gpx::DevBuf alpha; // N
@@ -231,7 +233,8 @@ int launch_gram(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, c
 int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, int n_pad,
                        const double* dZ, int m, int m_pad, double diag_add, int add_diag,
                        int lower_only, double* dOut, int64_t ld, int batch = 1, int64_t out_bs = 0,
-                       const ThetaDev* th = nullptr, int diag_sel = 0, TaskStride ts = TaskStride());
+                       const ThetaDev* th = nullptr, int diag_sel = 0, TaskStride ts = TaskStride(),
+                       const double* diag_vec = nullptr);
 int launch_augment(gpx_ctx* ctx, double* dK, int64_t ld, int N, int Np, const double* dy,
                    int batch = 1, int64_t k_bs = 0, int64_t y_bs = 0, int y_mod = 0);
 int launch_pad_identity(gpx_ctx* ctx, double* dA, int64_t ld, int n, int np);

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void gram_kernel(KernelParams kpv, const doubl
                                                    double diag_add, int add_diag, int lower_only,
                                                    double* __restrict__ out, int64_t ld,
                                                    int64_t out_bs, const ThetaDev* __restrict__ th,
-                                                   int diag_sel, TaskStride ts) {
+                                                   int diag_sel, TaskStride ts,
+                                                   const double* __restrict__ diag_vec) {
   if (ts.mod > 0) { // per-task inputs: batch entry z belongs to task z % mod
     const int task = blockIdx.z % ts.mod;
     X += task * ts.x_bs;
@@ -108,9 +109,9 @@ __global__ __launch_bounds__(256) void gram_kernel(KernelParams kpv, const doubl
     }
     double v0 = kernel_value<KIND>(r20, k_scale);
     double v1 = kernel_value<KIND>(r21, k_scale);
-    if (add_diag) {
-      if (i == j) v0 += diag_add;
-      if (i == j + 1) v1 += diag_add;
+    if (add_diag) { // (noise + jitter) I, plus a per-point variance when given (measured noise, mngp.py:96)
+      if (i == j) v0 += diag_add + (diag_vec != nullptr && i < n ? diag_vec[i] : 0.0);
+      if (i == j + 1) v1 += diag_add + (diag_vec != nullptr && i < n ? diag_vec[i] : 0.0);
     }
     if (i >= n) v0 = v1 = 0.0;
     if (j >= m) v0 = 0.0;
@@ -128,27 +129,27 @@ template <int KIND>
 static void gram_dispatch(const KernelParams& kp, dim3 grid, hipStream_t s, const double* X, int n,
                           int n_pad, const double* Z, int m, int m_pad, double diag_add,
                           int add_diag, int lower_only, double* out, int64_t ld, int64_t out_bs,
-                          const ThetaDev* th, int diag_sel, TaskStride ts) {
+                          const ThetaDev* th, int diag_sel, TaskStride ts, const double* diag_vec) {
   switch (kp.d) {
     case 1:
       gram_kernel<KIND, 1><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld, out_bs, th, diag_sel, ts);
+                                                 lower_only, out, ld, out_bs, th, diag_sel, ts, diag_vec);
       break;
     case 2:
       gram_kernel<KIND, 2><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld, out_bs, th, diag_sel, ts);
+                                                 lower_only, out, ld, out_bs, th, diag_sel, ts, diag_vec);
       break;
     case 3:
       gram_kernel<KIND, 3><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld, out_bs, th, diag_sel, ts);
+                                                 lower_only, out, ld, out_bs, th, diag_sel, ts, diag_vec);
       break;
     case 4:
       gram_kernel<KIND, 4><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld, out_bs, th, diag_sel, ts);
+                                                 lower_only, out, ld, out_bs, th, diag_sel, ts, diag_vec);
       break;
     default:
       gram_kernel<KIND, 0><<<grid, 256, 0, s>>>(kp, X, n, n_pad, Z, m, m_pad, diag_add, add_diag,
-                                                 lower_only, out, ld, out_bs, th, diag_sel, ts);
+                                                 lower_only, out, ld, out_bs, th, diag_sel, ts, diag_vec);
   }
 }
 
@@ -157,7 +158,7 @@ static void gram_dispatch(const KernelParams& kp, dim3 grid, hipStream_t s, cons
 int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int n, int n_pad,
                        const double* dZ, int m, int m_pad, double diag_add, int add_diag,
                        int lower_only, double* dOut, int64_t ld, int batch, int64_t out_bs,
-                       const ThetaDev* th, int diag_sel, TaskStride ts) {
+                       const ThetaDev* th, int diag_sel, TaskStride ts, const double* diag_vec) {
   if (n_pad <= 0 || m_pad <= 0) return 0;
   if (batch > 1 && th == nullptr) return bad_arg(ctx, "batched Gram needs a device theta table");
   dim3 grid((m_pad + GT_COLS - 1) / GT_COLS, (n_pad + GT_ROWS - 1) / GT_ROWS, batch > 1 ? batch : 1);
@@ -166,13 +167,13 @@ int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, i
   ProfScope ps(ctx, GPX_PROF_GRAM, 8.0 * (double)n * (double)m * (batch > 1 ? batch : 1));
   if (kp.kind == GPX_KERNEL_RBF)
     gram_dispatch<GPX_KERNEL_RBF>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
-                                  add_diag, lower_only, dOut, ld, out_bs, th, diag_sel, ts);
+                                  add_diag, lower_only, dOut, ld, out_bs, th, diag_sel, ts, diag_vec);
   else if (kp.kind == GPX_KERNEL_PERIODIC)
     gram_dispatch<GPX_KERNEL_PERIODIC>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
-                                       add_diag, lower_only, dOut, ld, out_bs, th, diag_sel, ts);
+                                       add_diag, lower_only, dOut, ld, out_bs, th, diag_sel, ts, diag_vec);
   else
     gram_dispatch<GPX_KERNEL_MATERN52>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
-                                       add_diag, lower_only, dOut, ld, out_bs, th, diag_sel, ts);
+                                       add_diag, lower_only, dOut, ld, out_bs, th, diag_sel, ts, diag_vec);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }

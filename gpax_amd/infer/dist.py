@@ -15,7 +15,7 @@ import math
 import numpy as np
 from scipy import special
 
-__all__ = ["Distribution", "Normal", "LogNormal", "HalfNormal", "Gamma", "Uniform"]
+__all__ = ["Distribution", "Normal", "LogNormal", "HalfNormal", "HalfCauchy", "Gamma", "Uniform"]
 
 
 class Distribution:
@@ -133,6 +133,27 @@ class HalfNormal(Distribution):
 
     def median(self):
         return self.scale * 0.6744897501960817
+
+
+class HalfCauchy(Distribution):
+    """Prior of the LinReg noise scale (gpax/models/linreg.py:27)."""
+    support = "positive"
+
+    def __init__(self, scale=1.0):
+        self.scale = float(scale)
+
+    def log_prob(self, x):
+        z = x / self.scale
+        return math.log(2.0 / (math.pi * self.scale)) - np.log1p(z * z)
+
+    def grad_log_prob(self, x):
+        return -2.0 * x / (self.scale ** 2 + x * x)
+
+    def sample(self, rng, shape=()):
+        return np.abs(self.scale * np.tan(math.pi * (rng.uniform(size=shape) - 0.5)))
+
+    def median(self):
+        return self.scale
 
 
 class Gamma(Distribution):

@@ -62,7 +62,7 @@ def fit_delta(objective_and_grad: Callable[[np.ndarray], Tuple[float, np.ndarray
 
 def fit_normal(logdensity_and_grad: Callable[[np.ndarray], Tuple[float, np.ndarray]], dim: int, num_steps: int,
                step_size: float, rng: np.random.Generator, init_scale: float = 0.1, progress=None,
-               point0: np.ndarray = None):
+               point0: np.ndarray = None, b1: float = 0.5):
     """Mean-field Normal guide on the unconstrained density (log joint + log|J|) of the first `dim`
     variables; `point0` are additional point-estimated parameters (numpyro.param, e.g. the inducing
     points) appended to the argument of `logdensity_and_grad`.  Returns (loc, scale, losses[, point])."""
@@ -70,7 +70,7 @@ def fit_normal(logdensity_and_grad: Callable[[np.ndarray], Tuple[float, np.ndarr
     loc = rng.uniform(-2.0, 2.0, dim)
     rho = np.full(dim, _inv_softplus(init_scale))
     x = np.concatenate([loc, rho] + ([np.ravel(point0).astype(np.float64)] if npnt else []))
-    opt = Adam(2 * dim + npnt, step_size)
+    opt = Adam(2 * dim + npnt, step_size, b1=b1)
     losses = np.empty(num_steps)
     for it in range(num_steps):
         loc, rho, pnt = x[:dim], x[dim:2 * dim], x[2 * dim:]

@@ -69,6 +69,12 @@ int gpx_gram(gpx_ctx* ctx, int kind, const double* X, int n, const double* Z, in
  * Uploads X_train (N,d) and sizes the device workspaces (Gram/factor buffer etc.). */
 int gpx_set_train(gpx_ctx* ctx, const double* X, int N, int d);
 
+/* Per-point variances v (N) added to the diagonal of the training covariance on top of
+ * (noise + jitter): K + diag(v) — the measured noise of MeasuredNoiseGP.model
+ * (gpax/models/mngp.py:92-98).  Stays in force for every factorisation of this training set until
+ * cleared with v = NULL (or the next gpx_set_train). */
+int gpx_set_diag(gpx_ctx* ctx, const double* v, int n);
+
 /* T independent training sets X (T,N,d) of vector-valued GPs (vExactGP._set_data / model,
  * gpax/models/vgp.py:62-96,199-208: `jax.vmap(self.kernel)` over the task axis).  Afterwards the
  * batched entry points (gpx_fit_batch, gpx_predict_sweep) treat entry b as task b % T — its own
@@ -134,11 +140,13 @@ int gpx_mvn_draw(gpx_ctx* ctx, const double* eps, int n, double* out, int* info)
  *   mean_s, cov_s as gpx_posterior with noise_p = noiseless ? 0 : noises[s];
  *   samples[s] = mean_s + chol(cov_s) eps[s]   (n draws).
  * means (S*M), samples (S*n*M), infos (S; bit 0.. = train-factor info, negative = draw chol
- * failed).  Rows whose info != 0 are NaN-filled.  eps may be NULL when n == 0. */
+ * failed).  Rows whose info != 0 are NaN-filled.  eps may be NULL when n == 0.
+ * vars (S*M) or NULL: diag(cov_s), for callers that draw from the marginals only
+ * (MeasuredNoiseGP._predict, gpax/models/mngp.py:170-181). */
 int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales,
                       const double* noises, const double* yres, int yres_rows,
                       const double* Xnew, int M, int noiseless, double jitter,
-                      const double* eps, int n, double* means, double* samples, int* infos);
+                      const double* eps, int n, double* means, double* samples, int* infos, double* vars);
 
 /* ---- variational sparse GP: viSparseGP, gpax/models/sparse_gp.py ----------------------------
  * gpx_sgp_bound: the per-SVI-step objective of viSparseGP.model (sparse_gp.py:62-114): VFE bound =

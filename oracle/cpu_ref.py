@@ -99,6 +99,18 @@ def get_kernel(kernel="RBF"):
     return kernel
 
 
+def measured_noise_predict_one(X_train, y_train, X_new, params, noise_predicted, eps, noiseless=True, kernel="RBF",
+                               jitter=1e-6):
+    """MeasuredNoiseGP._predict, gpax/models/mngp.py:159-181, given the standard normals eps (n, M):
+    (mean, cov) = ExactGP.get_mvn_posterior with the deterministic noise = 0 (the training block carries NO
+    measured noise there), cov += diag(noise_predicted), draws from the marginals only."""
+    p = dict(params)
+    p["noise"] = 0.0
+    mean, cov = get_mvn_posterior(X_train, y_train, X_new, p, noiseless, kernel=kernel, jitter=jitter, route="inv")
+    sig = np.sqrt(np.clip(np.diag(cov) + np.asarray(noise_predicted, dtype=np.float64), 0.0, None))
+    return mean, mean[None, :] + sig[None, :] * np.asarray(eps, dtype=np.float64)
+
+
 # ------------------------------------------------------------------------------------------
 # NumPyro MultivariateNormal [knowledge]: log_prob = -1/2 |L^-1 (y-loc)|^2 - sum log L_ii
 #   - n/2 log 2 pi with L = cholesky(covariance_matrix); sample = loc + L @ eps
@@ -134,8 +146,11 @@ def _set_data(X, y=None):
     return X
 
 
-def exactgp_log_likelihood(X, y, params, kernel="RBF", jitter=1e-6, mean_fn=None, mean_params=None) -> float:
-    """log p(y | theta) of ExactGP.model, gpax/models/gp.py:137-164 (the `y` site only)."""
+def exactgp_log_likelihood(X, y, params, kernel="RBF", jitter=1e-6, mean_fn=None, mean_params=None,
+                           measured_noise=None) -> float:
+    """log p(y | theta) of ExactGP.model, gpax/models/gp.py:137-164 (the `y` site only).
+    measured_noise: MeasuredNoiseGP.model, gpax/models/mngp.py:92-98 — covariance k + diag(measured_noise)
+    (called there with params['noise'] = 0)."""
     X, y = _set_data(X, y)
     kfn = get_kernel(kernel)
     f_loc = np.zeros(X.shape[0])
@@ -143,10 +158,12 @@ def exactgp_log_likelihood(X, y, params, kernel="RBF", jitter=1e-6, mean_fn=None
         args = [X] if mean_params is None else [X, mean_params]
         f_loc = f_loc + np.asarray(mean_fn(*args)).squeeze()
     k = kfn(X, X, params, params["noise"], jitter=jitter)
+    if measured_noise is not None:
+        k = k + np.diag(np.asarray(measured_noise, dtype=np.float64))
     return mvn_log_prob(y, f_loc, k)
 
 
-def exactgp_log_likelihood_grad(X, y, params, kernel="RBF", jitter=1e-6, yres=None):
+def exactgp_log_likelihood_grad(X, y, params, kernel="RBF", jitter=1e-6, yres=None, measured_noise=None):
     """Analytic gradient of the log-likelihood w.r.t. (k_length[d], k_scale, noise) and
     alpha = K^-1 yres: 1/2 sum_ij (alpha alpha^T - K^-1)_ij dK_ij/dtheta.  (The reference gets
     this from JAX autodiff through gp.py:137-164; tests check it against central differences.)"""
@@ -158,6 +175,8 @@ def exactgp_log_likelihood_grad(X, y, params, kernel="RBF", jitter=1e-6, yres=No
     s = float(params["k_scale"])
     kfn = get_kernel(kernel)
     K = kfn(X, X, params, params["noise"], jitter=jitter)
+    if measured_noise is not None:
+        K = K + np.diag(np.asarray(measured_noise, dtype=np.float64))
     Kinv = np.linalg.inv(K)
     alpha = Kinv @ yres
     G = np.outer(alpha, alpha) - Kinv

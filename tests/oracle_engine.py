@@ -34,6 +34,11 @@ class OracleEngine:
         self.T = X.shape[0] if X.ndim == 3 else 1
         self.X = X[0] if X.ndim == 3 else X
         self.N, self.d = self.X.shape
+        self._diag = None
+        self._diag_key = None
+
+    def set_diag(self, v):
+        self._diag = None if v is None else np.asarray(v, dtype=np.float64).reshape(-1)
 
     def _row(self, arr, b, count):
         """Row of a (N,) | (count, N) | (T, N) table for batch entry b."""
@@ -61,6 +66,8 @@ class OracleEngine:
                            scale=float(scale), noise=float(noise))
         self._yres = np.asarray(yres, dtype=np.float64)
         K = self.gram(kind, self.X, self.X, ell, scale, noise + jitter, True)
+        if getattr(self, "_diag", None) is not None:
+            K = K + np.diag(self._diag)
         try:
             self._L = np.linalg.cholesky(K)
         except np.linalg.LinAlgError:
@@ -75,13 +82,14 @@ class OracleEngine:
         t = self._theta
         if t["kind"] != 2:
             return ref.exactgp_log_likelihood_grad(self.X, self._yres, t["p"], kernel=_NAMES[t["kind"]],
-                                                   jitter=t["jitter"], yres=self._yres)
+                                                   jitter=t["jitter"], yres=self._yres,
+                                                   measured_noise=getattr(self, "_diag", None))
         # periodic: central differences of the oracle lml (tests only)
         ell = np.asarray(t["ell"], dtype=np.float64).reshape(-1)
 
         def f(e, s, n):
             return ref.exactgp_log_likelihood(self.X, self._yres, _params(2, e, self.d, s, n), kernel="Periodic",
-                                              jitter=t["jitter"])
+                                              jitter=t["jitter"], measured_noise=getattr(self, "_diag", None))
 
         g = np.empty(ell.size)
         for m in range(ell.size):
@@ -94,6 +102,8 @@ class OracleEngine:
         gs = (f(ell, t["scale"] + hs, t["noise"]) - f(ell, t["scale"] - hs, t["noise"])) / (2 * hs)
         gn = (f(ell, t["scale"], t["noise"] + hn) - f(ell, t["scale"], t["noise"] - hn)) / (2 * hn)
         K = ref.PeriodicKernel(self.X, self.X, t["p"], t["noise"], jitter=t["jitter"])
+        if getattr(self, "_diag", None) is not None:
+            K = K + np.diag(self._diag)
         return g, gs, gn, np.linalg.solve(K, self._yres)
 
     def fit_batch(self, kind, ells, scales, noises, jitter, yres, want_grad=True):
@@ -142,7 +152,7 @@ class OracleEngine:
         out = ref.mvn_sample(mean, cov, np.asarray(eps))
         return out, int(np.isnan(out).any())
 
-    def predict_sweep(self, kind, ells, scales, noises, yres, Xnew, noiseless, jitter, eps):
+    def predict_sweep(self, kind, ells, scales, noises, yres, Xnew, noiseless, jitter, eps, want_var=False):
         ells = np.asarray(ells, dtype=np.float64)
         S = ells.shape[0]
         Xnew = np.asarray(Xnew, dtype=np.float64)
@@ -150,6 +160,7 @@ class OracleEngine:
         n = 0 if eps is None else np.asarray(eps).shape[1]
         yres = np.asarray(yres, dtype=np.float64)
         means, samples, infos = np.empty((S, M)), np.empty((S, n, M)), np.zeros(S, dtype=np.int32)
+        vars_ = np.empty((S, M))
         for s in range(S):
             if self._Xt is not None:
                 self.X = self._Xt[s % self.T]
@@ -157,11 +168,14 @@ class OracleEngine:
             m, cov, _ = self.posterior(Xnew if Xnew.ndim == 2 else Xnew[s % self.T], 0.0 if noiseless else noises[s],
                                        jitter)
             means[s] = m
+            vars_[s] = np.diag(cov)
             infos[s] = info
             if n:
                 samples[s], bad = self.mvn_draw(eps[s])
                 if bad and not info:
                     infos[s] = -1
+        if want_var:
+            return means, samples, infos, vars_
         return means, samples, infos
 
     # ---- sparse GP (tests only; gradient by central differences of the oracle bound) -----------------

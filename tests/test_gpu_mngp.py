@@ -1,0 +1,100 @@
+"""GPU parity of the measured-noise path (gpax/models/mngp.py): per-point diagonal vector in the training
+covariance (gpx_set_diag) and the variance output of the sweep, vs. the oracle."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind,name", [(0, "RBF"), (1, "Matern"), (2, "Periodic")])
+@pytest.mark.parametrize("N,d", [(60, 1), (300, 2)])
+def test_lml_and_gradient_with_measured_noise(engine, kind, name, N, d):
+    X, y, _, params = ref.synthetic_problem(N, d, 4, seed=N + d)
+    rng = np.random.default_rng(N)
+    v = rng.uniform(0.01, 0.4, N)
+    p = {"k_length": np.broadcast_to(params["k_length"], (d,)).copy(), "k_scale": params["k_scale"], "noise": 0.0}
+    ell = p["k_length"]
+    if kind == 2:
+        p["period"] = 2.7
+        ell = np.concatenate([ell, [2.7]])
+    engine.set_train(X)
+    engine.set_diag(v)
+    lml, info = engine.factor(kind, ell, p["k_scale"], 0.0, 1e-6, y)
+    assert info == 0
+    f = lambda q: ref.exactgp_log_likelihood(X, y, q, kernel=name, jitter=1e-6, measured_noise=v)
+    expect = f(p)
+    assert abs(lml - expect) <= 1e-10 * abs(expect)
+    g_ell, g_scale, g_noise, alpha = engine.lml_grad()
+    K = ref.get_kernel(name)(X, X, p, 0.0, jitter=1e-6) + np.diag(v)
+    assert np.linalg.norm(alpha - np.linalg.solve(K, y)) / np.linalg.norm(alpha) < 1e-9
+    if kind != 2:
+        e_ell, e_scale, e_noise, _ = ref.exactgp_log_likelihood_grad(X, y, p, kernel=name, jitter=1e-6, measured_noise=v)
+        sc = max(np.abs(e_ell).max(), abs(e_scale))
+        np.testing.assert_allclose(g_ell, e_ell, rtol=1e-8, atol=1e-8 * sc)
+        assert abs(g_scale - e_scale) <= 1e-8 * sc and abs(g_noise - e_noise) <= 1e-8 * max(sc, abs(e_noise))
+    # the batched fit step sees the same diagonal; clearing it changes the value
+    lb, ib, gb, ab = engine.fit_batch(kind, np.tile(ell, (3, 1)), np.full(3, p["k_scale"]), np.zeros(3), 1e-6, y)
+    assert np.all(lb == lml) and np.all(ib == 0)
+    np.testing.assert_array_equal(gb[1], np.concatenate([g_ell, [g_scale, g_noise]]))
+    engine.set_diag(None)
+    lml0, info0 = engine.factor(kind, ell, p["k_scale"], 0.05, 1e-6, y)
+    q = dict(p)
+    q["noise"] = 0.05
+    assert abs(lml0 - ref.exactgp_log_likelihood(X, y, q, kernel=name, jitter=1e-6)) <= 1e-10 * abs(lml0)
+    engine.set_diag(v)
+    engine.set_train(X)  # a new training set clears the per-point diagonal
+    lml1, _ = engine.factor(kind, ell, p["k_scale"], 0.05, 1e-6, y)
+    assert lml1 == lml0
+
+
+def test_sweep_variance_output(engine):
+    N, d, M, S = 200, 2, 45, 6
+    X, y, Xn, params = ref.synthetic_problem(N, d, M, seed=9)
+    th = ref.synthetic_theta_samples(S, d, seed=10)
+    engine.set_train(X)
+    for noiseless in (False, True):
+        means, _, infos, vars_ = engine.predict_sweep(1, th["k_length"], th["k_scale"], th["noise"], y, Xn, noiseless, 1e-6,
+                                                      None, want_var=True)
+        assert np.all(infos == 0) and vars_.shape == (S, M)
+        for s in range(S):
+            p = {"k_length": th["k_length"][s], "k_scale": th["k_scale"][s], "noise": th["noise"][s]}
+            m_ref, c_ref = ref.get_mvn_posterior(X, y, Xn, p, noiseless, kernel="Matern", jitter=1e-6, route="inv")
+            assert np.linalg.norm(means[s] - m_ref) / np.linalg.norm(m_ref) < 1e-8
+            assert np.linalg.norm(vars_[s] - np.diag(c_ref)) / np.linalg.norm(np.diag(c_ref)) < 1e-8
+    # with draws requested the variances are still those of the same posteriors
+    eps = np.random.default_rng(1).standard_normal((S, 2, M))
+    m2, d2, i2, v2 = engine.predict_sweep(1, th["k_length"], th["k_scale"], th["noise"], y, Xn, True, 1e-6, eps,
+                                          want_var=True)
+    np.testing.assert_array_equal(v2, vars_)
+
+
+def test_measured_noise_gp_on_gpu():
+    from gpax_amd import MeasuredNoiseGP
+    from gpax_amd.utils import get_keys
+    rng = np.random.default_rng(0)
+    f = lambda x: np.sin(x) * x
+    noise_sd = lambda x: 0.05 + 0.15 * x
+    X = np.linspace(0.5, 4.0, 30)
+    y_all = np.array([f(x) + rng.normal(0, noise_sd(x), 12) for x in X])
+    y, mn = y_all.mean(1), y_all.var(1) / 12  # variance of the mean
+    Xt = np.linspace(0.6, 3.9, 21)
+    k1, k2 = get_keys()
+    m = MeasuredNoiseGP(1, "Matern")
+    m.fit(k1, X, y, mn, num_warmup=100, num_samples=100, progress_bar=False, print_summary=False)
+    for method, kw in (("linreg", dict(num_iterations=1500)), ("gpreg", dict(num_steps=200))):
+        m.noise_predicted = None
+        ym, ys = m.predict(k2, Xt, n=4, noise_prediction_method=method, **kw)
+        assert ym.shape == (21,) and ys.shape == (100, 4, 21)
+        assert np.all(np.isfinite(ys))
+        assert np.sqrt(np.mean((ym - f(Xt)) ** 2)) < 0.25
+        assert m.noise_predicted.shape == (21,)
+    # the single-sample path agrees with the oracle restatement of mngp.py:159-181
+    s = m.get_samples()
+    p = {"k_length": s["k_length"][3], "k_scale": s["k_scale"][3], "noise": 0.0}
+    y_mean, y_sampled = m._predict(k2, Xt[:, None], p, m.noise_predicted, 3)
+    m_ref, _ = ref.measured_noise_predict_one(X[:, None], y, Xt[:, None], p, m.noise_predicted, np.zeros((3, 21)),
+                                              noiseless=False, kernel="Matern")
+    # training block = kernel + 1e-6 I (the reference's own conditioning): agreement limited by cond(K) ~ 1e8
+    assert np.linalg.norm(y_mean - m_ref) / np.linalg.norm(m_ref) < 1e-4
