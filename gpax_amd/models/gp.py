@@ -262,7 +262,8 @@ class ExactGP:
                     dm = (self._mean(self.X_train, tp) - self._mean(self.X_train, tm)) / (2 * h)
                     gx = np.array([float(np.sum(alpha * dm))])
                 gx = gx + s.dist.grad_log_prob(x)
-                gu = gx * s.dist.dx_du(ui)
+                with np.errstate(invalid="ignore"):  # inf * 0 far out in the tails: NUTS treats NaN as divergent
+                    gu = gx * s.dist.dx_du(ui)
                 if jacobian:
                     gu = gu + dlj
                 grad[off:off + s.size] = gu
