@@ -5,7 +5,7 @@ gpax_amd — MI355X-native exact-GP hot path behind the gpax API surface
 """
 from . import acquisition, kernels, utils
 from .infer import dist
-from .models import ExactGP, MeasuredNoiseGP, vExactGP, viGP, viSparseGP
+from .models import ExactGP, MeasuredNoiseGP, VarNoiseGP, vExactGP, viGP, viSparseGP
 
 __version__ = "0.1.0"
-__all__ = ["ExactGP", "vExactGP", "viGP", "viSparseGP", "MeasuredNoiseGP", "kernels", "utils", "acquisition", "dist"]
+__all__ = ["ExactGP", "vExactGP", "viGP", "viSparseGP", "MeasuredNoiseGP", "VarNoiseGP", "kernels", "utils", "acquisition", "dist"]

@@ -64,7 +64,8 @@ def load_library() -> C.CDLL:
         "gpx_posterior": (C.c_int, [vp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]),
         "gpx_mvn_draw": (C.c_int, [vp, _dp, C.c_int, _dp, _ip]),
         "gpx_predict_sweep": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp,
-                                        C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip, _dp]),
+                                        C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip, _dp, _dp]),
+        "gpx_lml_grad_diag": (C.c_int, [vp, _dp]),
         "gpx_set_diag": (C.c_int, [vp, _dp, C.c_int]),
         "gpx_sgp_bound": (C.c_int, [vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp, C.c_int, _dp, C.c_int,
                                     _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
@@ -90,7 +91,7 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = (
     "gpx_init gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
-    "gpx_factor gpx_lml_grad gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
+    "gpx_factor gpx_lml_grad gpx_lml_grad_diag gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
     "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf"
@@ -163,6 +164,8 @@ class Engine:
         self.N = 0
         self.d = 0
         self.M = 0
+        self.T = 1
+        self._diag_key = None
 
     # -- plumbing -----------------------------------------------------------------------------
     def _check(self, rc: int, what: str):
@@ -234,6 +237,12 @@ class Engine:
                                            _ptr(alpha)), "gpx_lml_grad")
         return g_ell, g_scale.value, g_noise.value, alpha
 
+    def lml_grad_diag(self) -> np.ndarray:
+        """d lml / d v of the per-point diagonal set by set_diag; call after lml_grad()."""
+        g = np.empty(self.N)
+        self._check(self._lib.gpx_lml_grad_diag(self._ctx, _ptr(g)), "gpx_lml_grad_diag")
+        return g
+
     def fit_batch(self, kind: int, ells, scales, noises, jitter: float, yres, want_grad: bool = True):
         """gpx_factor + gpx_lml_grad for B hyper-parameter vectors in one launch sequence.
         ells (B, n_ell); yres (N,) shared or (B, N).  Returns lml (B,), info (B,), grad (B, n_ell + 2) or None
@@ -284,7 +293,7 @@ class Engine:
         self._check(self._lib.gpx_set_diag(self._ctx, _ptr(v), self.N), "gpx_set_diag")
 
     def predict_sweep(self, kind: int, ells, scales, noises, yres, Xnew, noiseless: bool, jitter: float,
-                      eps: Optional[np.ndarray], want_var: bool = False):
+                      eps: Optional[np.ndarray], want_var: bool = False, pred_diag=None):
         ells = _f64(ells)
         S = ells.shape[0]
         ells = _f64(ells, (S, n_ell(kind, self.d)))
@@ -302,10 +311,11 @@ class Engine:
         samples = np.empty((S, n, M))
         infos = np.zeros(S, dtype=np.int32)
         vars_ = np.empty((S, M)) if want_var else None
+        pd = None if pred_diag is None else _f64(pred_diag, (S, M))
         self._check(self._lib.gpx_predict_sweep(
             self._ctx, kind, S, _ptr(ells), _ptr(scales), _ptr(noises), _ptr(yres), rows, _ptr(Xnew), M,
             int(bool(noiseless)), float(jitter), _ptr(eps_c), n, _ptr(means),
-            _ptr(samples) if n else None, infos.ctypes.data_as(_ip), _ptr(vars_)), "gpx_predict_sweep")
+            _ptr(samples) if n else None, infos.ctypes.data_as(_ip), _ptr(vars_), _ptr(pd)), "gpx_predict_sweep")
         if want_var:
             return means, samples, infos, vars_
         return means, samples, infos

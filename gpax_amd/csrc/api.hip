@@ -122,6 +122,7 @@ int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
   GPX_TRY(potrf_lower(ctx, K, ctx->ldk, Np, extra, ctx->Linv.d(), bp.info_train, B, bp.k_bs, bp.linv_bs));
   if (want_lml) GPX_TRY(launch_lml_terms(ctx, K, ctx->ldk, N, bp.scal + SC_QUAD, B, bp.k_bs, bp.scal_bs));
   ctx->factored = (B == 1);
+  ctx->have_kinv = false;
   ctx->fused_vt = fused;
   ctx->have_post = false;
   return 0;
@@ -172,6 +173,7 @@ int dev_grad(gpx_ctx* ctx, const BatchPlan& bp) {
                                ctx->part.d(), &nblocks, B, bp.k_bs, alpha_bs, bp.th, ts_train(ctx)));
   GPX_TRY(launch_grad_reduce(ctx, ctx->part.d(), nblocks, n_ell(ctx->theta) + 2, bp.scal + SC_GRAD, B, bp.scal_bs));
   ctx->factored = false; // K now holds K^-1
+  ctx->have_kinv = (B == 1);
   return 0;
 }
 int dev_grad(gpx_ctx* ctx) { return dev_grad(ctx, make_plan(ctx, 1, 0, false)); }
@@ -219,7 +221,7 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov, const BatchPlan& bp) {
   GPX_TRY(ensure(ctx, ctx->var, (size_t)B * bp.mean_bs * sizeof(double)));
   const double kd = kdiag_value(kp) + ctx->noise_p + ctx->jitter;
   GPX_TRY(launch_rowdot(ctx, Vt, ldv, M, N, K + (int64_t)N * ctx->ldk, kd, ctx->mean.d(), ctx->var.d(), 0, B, v_bs,
-                        bp.k_bs, bp.mean_bs, bp.th));
+                        bp.k_bs, bp.mean_bs, bp.th, bp.pred_diag, bp.pd_bs));
   ctx->cov_factored = false;
   if (want_cov) {
     const CovSplit cs = cov_split(ctx);
@@ -249,7 +251,7 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov, const BatchPlan& bp) {
     GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, cs.splits, GPX_PROF_GEMM_OTHER, m * (m + 1.0) * ktot));
     GPX_TRY(launch_cov_finalize(ctx, kp, ctx->Xnew.d(), M, Mp, ctx->SplitK.d(), cs.splits, stride, ldp,
                                 ctx->noise_p + ctx->jitter, ctx->Cov.d(), ctx->ldc, B, bp.splitk_bs, bp.cov_bs,
-                                bp.th, ts_new(ctx)));
+                                bp.th, ts_new(ctx), bp.pred_diag, bp.pd_bs));
   }
   ctx->have_post = want_cov && B == 1;
   return 0;
@@ -356,6 +358,7 @@ struct SweepIO {
   double* dSamples = nullptr;
   int* dInfos = nullptr;
   double* dVars = nullptr; // device (S, M) posterior variances (diag of cov) or nullptr
+  const double* dPredDiag = nullptr; // device (S, M): per-sample variances added to diag(cov_s) / var_s
 };
 
 // Samples per launch: enough that the small-N pipeline fills the chip, bounded by memory.
@@ -450,6 +453,8 @@ int sweep_core(gpx_ctx* ctx, const SweepIO& io) {
       bp.yres = ctx->yres.d();
       bp.y_bs = 0;
     }
+    bp.pred_diag = io.dPredDiag ? io.dPredDiag + (int64_t)s0 * M : nullptr;
+    bp.pd_bs = M;
     if (n > 0 && io.dEps != nullptr) {
       dim3 grid((M + 255) / 256, n, b);
       eps_gather_kernel<<<grid, 256, 0, ctx->stream>>>(ctx->eps.d(), ctx->ldc, bp.eps_bs,
@@ -702,6 +707,20 @@ int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* gra
   return 0;
 }
 
+int gpx_lml_grad_diag(gpx_ctx* ctx, double* grad_diag) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (!ctx->have_kinv) return bad_arg(ctx, "gpx_lml_grad_diag must follow gpx_lml_grad");
+  if (!grad_diag) return bad_arg(ctx, "null pointer");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  const int N = ctx->N;
+  GPX_TRY(ensure(ctx, ctx->byres, (size_t)N * sizeof(double)));
+  GPX_TRY(launch_grad_diag(ctx, ctx->K.d(), ctx->ldk, N, ctx->alpha.d(), ctx->byres.d()));
+  GPX_HIP(ctx, hipMemcpyAsync(grad_diag, ctx->byres.d(), (size_t)N * sizeof(double), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const double* scales,
                   const double* noises, double jitter, const double* yres, int yres_rows,
                   double* lml, int* info, double* grad, double* alpha) {
@@ -826,7 +845,8 @@ int gpx_mvn_draw(gpx_ctx* ctx, const double* eps, int n, double* out, int* info)
 int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales,
                       const double* noises, const double* yres, int yres_rows,
                       const double* Xnew, int M, int noiseless, double jitter,
-                      const double* eps, int n, double* means, double* samples, int* infos, double* vars) {
+                      const double* eps, int n, double* means, double* samples, int* infos, double* vars,
+                      const double* pred_diag) {
   if (!ctx || ctx->device < 0) return -1;
   if (ctx->N < 1) return bad_arg(ctx, "gpx_set_train must be called first");
   if (S < 0 || n < 0) return bad_arg(ctx, "negative count");
@@ -839,11 +859,12 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   const int N = ctx->N;
   GPX_TRY(set_xnew(ctx, Xnew, M));
   // device staging for all inputs/outputs of the sweep: nothing crosses PCIe inside the loop
-  DevBuf dEps, dYres, dMeans, dSamples, dInfos, dVars;
+  DevBuf dEps, dYres, dMeans, dSamples, dInfos, dVars, dPred;
   int rc = 0;
   auto cleanup = [&]() {
     (void)hipStreamSynchronize(ctx->stream); // nothing may still read the staging buffers
     dVars.release();
+    dPred.release();
     dEps.release();
     dYres.release();
     dMeans.release();
@@ -871,6 +892,11 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   SWEEP_TRY(ensure(ctx, dInfos, (size_t)2 * S * sizeof(int)));
   SWEEP_HIP(hipMemsetAsync(dInfos.p, 0, (size_t)2 * S * sizeof(int), ctx->stream));
   if (vars) SWEEP_TRY(ensure(ctx, dVars, (size_t)S * M * sizeof(double)));
+  if (pred_diag) {
+    SWEEP_TRY(ensure(ctx, dPred, (size_t)S * M * sizeof(double)));
+    SWEEP_HIP(hipMemcpyAsync(dPred.d(), pred_diag, (size_t)S * M * sizeof(double), hipMemcpyHostToDevice,
+                             ctx->stream));
+  }
   if (strided) {
     SWEEP_TRY(ensure(ctx, dYres, (size_t)yres_rows * N * sizeof(double)));
     SWEEP_HIP(hipMemcpyAsync(dYres.d(), yres, (size_t)yres_rows * N * sizeof(double), hipMemcpyHostToDevice,
@@ -901,6 +927,7 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   io.dSamples = n > 0 ? dSamples.d() : nullptr;
   io.dInfos = dInfos.i();
   io.dVars = vars ? dVars.d() : nullptr;
+  io.dPredDiag = pred_diag ? dPred.d() : nullptr;
   SWEEP_TRY(sweep_core(ctx, io));
   std::vector<int> hinfos(2 * (size_t)S);
   SWEEP_HIP(hipMemcpyAsync(means, dMeans.d(), (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost,

@@ -96,6 +96,8 @@ struct BatchPlan {
   int* info_cov = nullptr;
   double* scal = nullptr; // per sample [quad, sumlog, grad(ell.., scale, noise)], stride scal_bs
   int64_t scal_bs = 0;
+  const double* pred_diag = nullptr; // per-sample, per-test-point variance added to diag(cov) (M each)
+  int64_t pd_bs = 0;
 };
 
 struct ProfAcc {
@@ -135,6 +137,7 @@ struct gpx_ctx {
   gpx::KernelParams theta{};
   double noise = 0, jitter = 0;
   bool factored = false;
+  bool have_kinv = false; // K holds K^-1 and alpha is resident (after the gradient pass)
   bool fused_vt = false; // rows Np.. of K hold k_pX L^-T from a fused factorisation
 
   // ---- posterior state ------------------------------------------------------------------
@@ -279,12 +282,14 @@ int launch_lml_terms(gpx_ctx* ctx, const double* dL, int64_t ld, int N, double* 
 int launch_rowdot(gpx_ctx* ctx, const double* dV, int64_t ldv, int rows, int cols,
                   const double* dw, double kdiag, double* dmean, double* dvar,
                   int col_start_by_row, int batch = 1, int64_t v_bs = 0, int64_t w_bs = 0,
-                  int64_t out_bs = 0, const ThetaDev* th = nullptr);
+                  int64_t out_bs = 0, const ThetaDev* th = nullptr, const double* pred_diag = nullptr,
+                  int64_t pd_bs = 0);
+int launch_grad_diag(gpx_ctx* ctx, const double* dKinv, int64_t ld, int N, const double* dalpha, double* dout);
 int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXnew, int M, int Mp,
                         const double* dPart, int splits, int64_t split_stride, int64_t ldp,
                         double diag_add, double* dCov, int64_t ldc, int batch = 1,
                         int64_t part_bs = 0, int64_t cov_bs = 0, const ThetaDev* th = nullptr,
-                        TaskStride ts = TaskStride());
+                        TaskStride ts = TaskStride(), const double* pred_diag = nullptr, int64_t pd_bs = 0);
 int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX, int N,
                          const double* dKinv, int64_t ld, const double* dalpha, double* dpart,
                          int* nblocks_out, int batch = 1, int64_t k_bs = 0, int64_t alpha_bs = 0,

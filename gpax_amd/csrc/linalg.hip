@@ -275,7 +275,9 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ 
                                                      double* __restrict__ var,
                                                      int col_start_by_row, int64_t v_bs,
                                                      int64_t w_bs, int64_t out_bs,
-                                                     const ThetaDev* __restrict__ th) {
+                                                     const ThetaDev* __restrict__ th,
+                                                     const double* __restrict__ pred_diag,
+                                                     int64_t pd_bs) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wave;
   if (r >= rows) return;
@@ -295,18 +297,18 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ 
   q = wave_sum(q);
   if (lane == 0) {
     if (mean) mean[(int64_t)bb * out_bs + r] = m;
-    if (var) var[(int64_t)bb * out_bs + r] = kdiag - q;
+    if (var) var[(int64_t)bb * out_bs + r] = kdiag - q + (pred_diag ? pred_diag[(int64_t)bb * pd_bs + r] : 0.0);
   }
 }
 
 int launch_rowdot(gpx_ctx* ctx, const double* dV, int64_t ldv, int rows, int cols,
                   const double* dw, double kdiag, double* dmean, double* dvar,
                   int col_start_by_row, int batch, int64_t v_bs, int64_t w_bs, int64_t out_bs,
-                  const ThetaDev* th) {
+                  const ThetaDev* th, const double* pred_diag, int64_t pd_bs) {
   if (rows <= 0) return 0;
   dim3 grid((rows + 3) / 4, batch > 1 ? batch : 1);
   rowdot_kernel<<<grid, 256, 0, ctx->s>>>(dV, ldv, rows, cols, dw, kdiag, dmean, dvar,
-                                          col_start_by_row, v_bs, w_bs, out_bs, th);
+                                          col_start_by_row, v_bs, w_bs, out_bs, th, pred_diag, pd_bs);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -330,7 +332,9 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(KernelParams kpv,
                                                            double* __restrict__ Cov, int64_t ldc,
                                                            int64_t part_bs, int64_t cov_bs,
                                                            const ThetaDev* __restrict__ th,
-                                                           TaskStride ts) {
+                                                           TaskStride ts,
+                                                           const double* __restrict__ pred_diag,
+                                                           int64_t pd_bs) {
   if (ts.mod > 0) Xn += (blockIdx.z % ts.mod) * ts.x_bs; // per-task X_new
   const int b = blockIdx.x * 64 + (threadIdx.x & 63);
   const int a0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(KernelParams kpv,
         r2 = fma(u, u, r2);
       }
       v = kval_rt(kind, r2, k_scale);
-      if (a == b) v += diag_add;
+      if (a == b) v += diag_add + (pred_diag ? pred_diag[(int64_t)blockIdx.z * pd_bs + a] : 0.0);
       const int hi = a > b ? a : b, lo = a > b ? b : a;
       double acc = 0.0;
       for (int z = 0; z < splits; ++z) acc += P[(int64_t)z * split_stride + (int64_t)hi * ldp + lo];
@@ -370,10 +374,11 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(KernelParams kpv,
 int launch_cov_finalize(gpx_ctx* ctx, const KernelParams& kp, const double* dXnew, int M, int Mp,
                         const double* dPart, int splits, int64_t split_stride, int64_t ldp,
                         double diag_add, double* dCov, int64_t ldc, int batch, int64_t part_bs,
-                        int64_t cov_bs, const ThetaDev* th, TaskStride ts) {
+                        int64_t cov_bs, const ThetaDev* th, TaskStride ts, const double* pred_diag,
+                        int64_t pd_bs) {
   dim3 grid((Mp + 63) / 64, (Mp + 15) / 16, batch > 1 ? batch : 1);
   cov_finalize_kernel<<<grid, 256, 0, ctx->s>>>(kp, dXnew, M, Mp, dPart, splits, split_stride,
-                                                ldp, diag_add, dCov, ldc, part_bs, cov_bs, th, ts);
+                                                ldp, diag_add, dCov, ldc, part_bs, cov_bs, th, ts, pred_diag, pd_bs);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -560,6 +565,20 @@ int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals
                        int batch, int64_t out_bs) {
   grad_reduce_kernel<<<batch > 1 ? batch : 1, 256, 0, ctx->s>>>(dpart, nblocks, nvals, dout,
                                                                  (int64_t)nblocks * GC_MAXV, out_bs);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// d lml / d v_i for a per-point diagonal v (K = k + diag(v)): 1/2 (alpha_i^2 - Kinv_ii)
+__global__ __launch_bounds__(256) void grad_diag_kernel(const double* __restrict__ Kinv, int64_t ld, int N,
+                                                        const double* __restrict__ alpha,
+                                                        double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N) out[i] = 0.5 * (alpha[i] * alpha[i] - Kinv[(int64_t)i * ld + i]);
+}
+
+int launch_grad_diag(gpx_ctx* ctx, const double* dKinv, int64_t ld, int N, const double* dalpha, double* dout) {
+  grad_diag_kernel<<<(N + 255) / 256, 256, 0, ctx->s>>>(dKinv, ld, N, dalpha, dout);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -97,6 +97,11 @@ int gpx_factor(gpx_ctx* ctx, int kind, const double* ell, double scale, double n
 int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* grad_noise,
                  double* alpha);
 
+/* d lml / d v for the per-point diagonal of gpx_set_diag (K = k + (noise + jitter) I + diag(v)):
+ * grad_diag[i] = 1/2 (alpha_i^2 - (K^-1)_ii).  Call after gpx_lml_grad (K^-1 and alpha resident).
+ * VarNoiseGP.model (gpax/models/hskgp.py:124-153) differentiates through v = exp(log_var). */
+int gpx_lml_grad_diag(gpx_ctx* ctx, double* grad_diag);
+
 /* ---- batched fit step: B hyper-parameter vectors through gpx_factor + gpx_lml_grad at once ----
  * The chains of MCMC(num_chains > 1, chain_method='parallel'|'vectorized') (gpax/models/gp.py:173-174,
  * 207-218) ask for one log-likelihood gradient each per leapfrog; this entry evaluates them as ONE
@@ -142,11 +147,14 @@ int gpx_mvn_draw(gpx_ctx* ctx, const double* eps, int n, double* out, int* info)
  * means (S*M), samples (S*n*M), infos (S; bit 0.. = train-factor info, negative = draw chol
  * failed).  Rows whose info != 0 are NaN-filled.  eps may be NULL when n == 0.
  * vars (S*M) or NULL: diag(cov_s), for callers that draw from the marginals only
- * (MeasuredNoiseGP._predict, gpax/models/mngp.py:170-181). */
+ * (MeasuredNoiseGP._predict, gpax/models/mngp.py:170-181).
+ * pred_diag (S*M) or NULL: per-sample variances added to the diagonal of cov_s before the draw
+ * (the predicted noise variance of VarNoiseGP.get_mvn_posterior, gpax/models/hskgp.py:188-204). */
 int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales,
                       const double* noises, const double* yres, int yres_rows,
                       const double* Xnew, int M, int noiseless, double jitter,
-                      const double* eps, int n, double* means, double* samples, int* infos, double* vars);
+                      const double* eps, int n, double* means, double* samples, int* infos, double* vars,
+                      const double* pred_diag);
 
 /* ---- variational sparse GP: viSparseGP, gpax/models/sparse_gp.py ----------------------------
  * gpx_sgp_bound: the per-SVI-step objective of viSparseGP.model (sparse_gp.py:62-114): VFE bound =

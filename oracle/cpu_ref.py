@@ -99,6 +99,54 @@ def get_kernel(kernel="RBF"):
     return kernel
 
 
+def noise_kernel(name):
+    """gpax/utils/fn.py:119-147 `_set_noise_kernel_fn`: the named kernel reading k_noise_length / k_noise_scale."""
+    base = get_kernel(name)
+
+    def k(X, Z, params, noise=0, jitter=1e-6, **kwargs):
+        p = dict(params)
+        p["k_length"], p["k_scale"] = params["k_noise_length"], params["k_noise_scale"]
+        return base(X, Z, p, noise, jitter=jitter, **kwargs)
+    return k
+
+
+def varnoise_log_likelihood(X, y, params, kernel="RBF", noise_kernel_name="RBF", jitter=1e-6, noise_loc=None,
+                            f_loc=None) -> float:
+    """The two MVN terms of VarNoiseGP.model, gpax/models/hskgp.py:129-153:
+    log MVN(log_var; noise_loc, k_noise) + log MVN(y; f_loc, k + diag(exp(log_var)))."""
+    X, y = _set_data(X, y)
+    N = X.shape[0]
+    lv = np.asarray(params["log_var"], dtype=np.float64)
+    k_noise = noise_kernel(noise_kernel_name)(X, X, params, 0, jitter=jitter)
+    t1 = mvn_log_prob(lv, np.zeros(N) if noise_loc is None else noise_loc, k_noise)
+    k = get_kernel(kernel)(X, X, params, 0, jitter=jitter)
+    t2 = mvn_log_prob(y, np.zeros(N) if f_loc is None else f_loc, k + np.diag(np.exp(lv)))
+    return t1 + t2
+
+
+def varnoise_get_mvn_posterior(X_train, y_train, X_new, params, kernel="RBF", noise_kernel_name="RBF", jitter=1e-6,
+                               noise_loc_train=None, noise_loc_new=None):
+    """VarNoiseGP.get_mvn_posterior, gpax/models/hskgp.py:167-206 (explicit inverses, as there)."""
+    X_train, y_train = _set_data(X_train, y_train)
+    X_new = _set_data(X_new)
+    kfn, nfn = get_kernel(kernel), noise_kernel(noise_kernel_name)
+    k_pp = kfn(X_new, X_new, params, 0, jitter=jitter)
+    k_pX = kfn(X_new, X_train, params, jitter=0.0)
+    k_XX = kfn(X_train, X_train, params, 0, jitter=jitter)
+    K_xx_inv = np.linalg.inv(k_XX)
+    cov = k_pp - k_pX @ (K_xx_inv @ k_pX.T)
+    mean = k_pX @ (K_xx_inv @ y_train)
+    k_pX_noise = nfn(X_new, X_train, params, jitter=0.0)
+    k_XX_noise = nfn(X_train, X_train, params, 0, jitter=jitter)
+    lv_res = np.asarray(params["log_var"], dtype=np.float64).copy()
+    if noise_loc_train is not None:
+        lv_res = lv_res - noise_loc_train
+    plv = k_pX_noise @ (np.linalg.inv(k_XX_noise) @ lv_res)
+    if noise_loc_new is not None:
+        plv = plv + noise_loc_new
+    return mean, cov + np.diag(np.exp(plv))
+
+
 def measured_noise_predict_one(X_train, y_train, X_new, params, noise_predicted, eps, noiseless=True, kernel="RBF",
                                jitter=1e-6):
     """MeasuredNoiseGP._predict, gpax/models/mngp.py:159-181, given the standard normals eps (n, M):

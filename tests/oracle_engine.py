@@ -106,6 +106,15 @@ class OracleEngine:
             K = K + np.diag(self._diag)
         return g, gs, gn, np.linalg.solve(K, self._yres)
 
+    def lml_grad_diag(self):
+        t = self._theta
+        K = self.gram(t["kind"], self.X, self.X, t["ell"], t["scale"], t["noise"] + t["jitter"], True)
+        if getattr(self, "_diag", None) is not None:
+            K = K + np.diag(self._diag)
+        Kinv = np.linalg.inv(K)
+        a = Kinv @ self._yres
+        return 0.5 * (a * a - np.diag(Kinv))
+
     def fit_batch(self, kind, ells, scales, noises, jitter, yres, want_grad=True):
         ells = np.asarray(ells, dtype=np.float64)
         B = ells.shape[0]
@@ -152,7 +161,8 @@ class OracleEngine:
         out = ref.mvn_sample(mean, cov, np.asarray(eps))
         return out, int(np.isnan(out).any())
 
-    def predict_sweep(self, kind, ells, scales, noises, yres, Xnew, noiseless, jitter, eps, want_var=False):
+    def predict_sweep(self, kind, ells, scales, noises, yres, Xnew, noiseless, jitter, eps, want_var=False,
+                      pred_diag=None):
         ells = np.asarray(ells, dtype=np.float64)
         S = ells.shape[0]
         Xnew = np.asarray(Xnew, dtype=np.float64)
@@ -167,6 +177,9 @@ class OracleEngine:
             lml, info = self.factor(kind, ells[s], scales[s], noises[s], jitter, self._row(yres, s, S))
             m, cov, _ = self.posterior(Xnew if Xnew.ndim == 2 else Xnew[s % self.T], 0.0 if noiseless else noises[s],
                                        jitter)
+            if pred_diag is not None and self._post is not None and np.all(np.isfinite(cov)):
+                cov = cov + np.diag(np.asarray(pred_diag, dtype=np.float64)[s])
+                self._post = (m, cov)
             means[s] = m
             vars_[s] = np.diag(cov)
             infos[s] = info

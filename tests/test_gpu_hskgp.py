@@ -1,0 +1,97 @@
+"""GPU parity of the heteroskedastic path (gpax/models/hskgp.py): gradient w.r.t. the per-point diagonal,
+per-sample predicted variances on the diagonal of the sweep's covariances, and the model end to end."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind,name", [(0, "RBF"), (1, "Matern")])
+@pytest.mark.parametrize("N,d", [(50, 1), (260, 2)])
+def test_gradient_wrt_per_point_diagonal(engine, kind, name, N, d):
+    X, y, _, params = ref.synthetic_problem(N, d, 4, seed=2 * N + d)
+    rng = np.random.default_rng(N)
+    lv = rng.normal(-2.0, 0.5, N)
+    p = {"k_length": np.broadcast_to(params["k_length"], (d,)).copy(), "k_scale": params["k_scale"], "noise": 0.0}
+    engine.set_train(X)
+    engine.set_diag(np.exp(lv))
+    lml, info = engine.factor(kind, p["k_length"], p["k_scale"], 0.0, 1e-6, y)
+    assert info == 0
+    engine.lml_grad()
+    gdiag = engine.lml_grad_diag()
+    K = ref.get_kernel(name)(X, X, p, 0.0, jitter=1e-6) + np.diag(np.exp(lv))
+    Kinv = np.linalg.inv(K)
+    a = Kinv @ y
+    expect = 0.5 * (a * a - np.diag(Kinv))
+    np.testing.assert_allclose(gdiag, expect, rtol=1e-8, atol=1e-8 * np.abs(expect).max())
+    # and by central differences of the oracle lml through v = exp(lv), a few coordinates
+    f = lambda l: ref.exactgp_log_likelihood(X, y, p, kernel=name, jitter=1e-6, measured_noise=np.exp(l))
+    for i in (0, N // 2, N - 1):
+        lp, lm = lv.copy(), lv.copy()
+        lp[i] += 1e-5
+        lm[i] -= 1e-5
+        fd = (f(lp) - f(lm)) / 2e-5
+        assert abs(gdiag[i] * np.exp(lv[i]) - fd) < 1e-5 * max(1.0, abs(fd))
+    engine.set_diag(None)
+    with pytest.raises(RuntimeError):
+        engine.factor(kind, p["k_length"], p["k_scale"], 0.1, 1e-6, y)
+        engine.lml_grad_diag()  # needs the gradient pass first
+
+
+@pytest.mark.parametrize("kind,name", [(0, "RBF"), (1, "Matern")])
+def test_sweep_with_per_sample_predicted_variance(engine, kind, name, monkeypatch):
+    N, d, M, S, n = 180, 2, 33, 7, 2
+    X, y, Xn, params = ref.synthetic_problem(N, d, M, seed=31)
+    th = ref.synthetic_theta_samples(S, d, seed=32)
+    rng = np.random.default_rng(33)
+    pv = rng.uniform(0.01, 0.5, (S, M))
+    eps = rng.standard_normal((S, n, M))
+    engine.set_train(X)
+    outs = []
+    for B in ("0", "3"):
+        monkeypatch.setenv("GPX_SWEEP_BATCH", B)
+        outs.append(engine.predict_sweep(kind, th["k_length"], th["k_scale"], th["noise"], y, Xn, True, 1e-6, eps,
+                                         want_var=True, pred_diag=pv))
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    means, draws, infos, vars_ = outs[0]
+    assert np.all(infos == 0)
+    for s in range(S):
+        p = {"k_length": th["k_length"][s], "k_scale": th["k_scale"][s], "noise": th["noise"][s]}
+        m_ref, c_ref = ref.get_mvn_posterior(X, y, Xn, p, True, kernel=name, jitter=1e-6, route="inv")
+        c_ref = c_ref + np.diag(pv[s])
+        assert np.linalg.norm(means[s] - m_ref) / np.linalg.norm(m_ref) < 1e-8
+        assert np.linalg.norm(vars_[s] - np.diag(c_ref)) / np.linalg.norm(np.diag(c_ref)) < 1e-8
+        d_ref = ref.mvn_sample(m_ref, c_ref, eps[s])
+        assert np.linalg.norm(draws[s] - d_ref) / np.linalg.norm(d_ref) < 1e-8
+
+
+def test_varnoise_gp_on_gpu_recovers_heteroskedastic_noise():
+    from gpax_amd import VarNoiseGP
+    from gpax_amd.utils import get_keys
+    rng = np.random.default_rng(0)
+    N = 60
+    X = np.sort(rng.uniform(0, 6, N))
+    sd = 0.05 + 0.12 * X  # noise grows with x
+    y = np.sin(1.5 * X) + sd * rng.standard_normal(N)
+    k1, k2 = get_keys()
+    m = VarNoiseGP(1, "RBF", noise_kernel="RBF")
+    m.fit(k1, X, y, num_warmup=60, num_samples=40, progress_bar=False, print_summary=False)
+    s = m.get_samples()
+    assert s["log_var"].shape == (40, N)
+    v = np.median(m.get_data_var_samples(), axis=0)
+    # inferred variance is larger where the true noise is larger
+    assert np.mean(v[X > 4]) > 2.0 * np.mean(v[X < 2])
+    Xt = np.linspace(0.2, 5.8, 40)
+    ym, ys = m.predict(k2, Xt, n=3)
+    assert ym.shape == (40,) and ys.shape == (40, 3, 40) and np.all(np.isfinite(ys))
+    assert np.sqrt(np.mean((ym - np.sin(1.5 * Xt)) ** 2)) < 0.3
+    spread = ys.reshape(-1, 40).std(0)
+    assert np.mean(spread[Xt > 4]) > np.mean(spread[Xt < 2])
+    # single-sample path agrees with the oracle restatement of hskgp.py:167-206 (mean; conditioning-limited)
+    p = {k: val[5] for k, val in s.items()}
+    mean, cov = m.get_mvn_posterior(Xt, p)
+    m_ref, c_ref = ref.varnoise_get_mvn_posterior(X[:, None], y, Xt[:, None], p, kernel="RBF", noise_kernel_name="RBF")
+    assert np.linalg.norm(np.diag(cov) - np.diag(c_ref)) / np.linalg.norm(np.diag(c_ref)) < 1e-2
