@@ -1,0 +1,5 @@
+from .priors import (auto_lognormal_priors, auto_normal_priors, auto_priors, gamma_dist, halfnormal_dist, lognormal_dist,
+                     normal_dist, uniform_dist)
+
+__all__ = ["normal_dist", "lognormal_dist", "halfnormal_dist", "gamma_dist", "uniform_dist", "auto_priors",
+           "auto_normal_priors", "auto_lognormal_priors"]

@@ -117,3 +117,19 @@ def initialize_inducing_points(X, ratio=0.1, method='uniform', key=None):
     else:
         raise ValueError("Method must be 'uniform', 'random', or 'kmeans'")
     return inducing_points
+
+
+def set_fn(func):
+    """gpax/utils/fn.py:21-55: turn a deterministic function f(x, a, b, ...) into f(x, params) reading its
+    parameters from a dictionary.  (The reference rewrites the source; a keyword-forwarding wrapper has the same
+    behaviour.  set_kernel_fn — custom kernels — has no MI355X path.)"""
+    import inspect
+
+    names = list(inspect.signature(func).parameters.keys())[1:]
+
+    def wrapped(x, params):
+        return func(x, **{n: params[n] for n in names})
+
+    wrapped.__name__ = getattr(func, "__name__", "fn")
+    wrapped.__doc__ = func.__doc__
+    return wrapped
