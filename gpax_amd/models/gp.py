@@ -454,6 +454,20 @@ class ExactGP:
         if isinstance(device, int):
             self._device = device
         jitter = float(kwargs.get("jitter", 1e-6))
+        ells, scales, noises, yres, eps, mean_shift = self._sweep_inputs(rng_key, X_new, samples, n)
+        # several samples in flight per GPU: independent libgpx contexts on the same device
+        engines = _lib.get_sweep_engines(self._device)
+        for e in engines[1:]:
+            e._train_owner = None
+        if len(engines) > 1:
+            engines[0]._train_owner = None
+        means, y_sampled, infos = _lib.concurrent_sweep(engines, self.X_train, self._kind, ells, scales, noises, yres,
+                                                        X_new, noiseless, jitter, eps)
+        return self._sweep_outputs(means, y_sampled, mean_shift, filter_nans)
+
+    def _sweep_inputs(self, rng_key, X_new, samples, n):
+        """Per-sample tables of the predictive sweep: packed lengthscales (S, n_ell), scales, noises, the
+        residual(s) y - m(X), the standard normals of the draws and the mean-function shift at X_new."""
         S = len(next(iter(samples.values())))
         d, M = self.kernel_dim, X_new.shape[0]
         ells = np.asarray(samples["k_length"], dtype=np.float64).reshape(S, -1)
@@ -471,14 +485,10 @@ class ExactGP:
         else:
             yres = self.y_train
         eps = rng_from_key(rng_key).standard_normal((S, n, M))
-        # several samples in flight per GPU: independent libgpx contexts on the same device
-        engines = _lib.get_sweep_engines(self._device)
-        for e in engines[1:]:
-            e._train_owner = None
-        if len(engines) > 1:
-            engines[0]._train_owner = None
-        means, y_sampled, infos = _lib.concurrent_sweep(engines, self.X_train, self._kind, ells, scales, noises, yres,
-                                                        X_new, noiseless, jitter, eps)
+        return ells, scales, noises, yres, eps, mean_shift
+
+    @staticmethod
+    def _sweep_outputs(means, y_sampled, mean_shift, filter_nans):
         if mean_shift is not None:
             means = means + mean_shift
             y_sampled = y_sampled + mean_shift[:, None, :]
@@ -486,6 +496,36 @@ class ExactGP:
             keep = ~np.isnan(y_sampled).any(axis=(1, 2))
             y_sampled = y_sampled[keep]
         return means.mean(0), y_sampled
+
+    def predict_distributed(self, rng_key, X_new: np.ndarray, samples: Optional[Dict[str, np.ndarray]] = None,
+                            n: int = 1, filter_nans: bool = False, noiseless: bool = False,
+                            **kwargs: float) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        """predict() with the posterior samples sharded over the ranks of an initialised torch.distributed
+        group (one process per GPU, `python -m torch.distributed.run`; backend nccl = RCCL over xGMI).
+        A collective call: every rank enters it with a model of the same configuration; only rank 0 needs the
+        fitted state / arguments — they are broadcast, each rank sweeps its contiguous block of samples on its
+        own GPU, and rank 0 returns (y_mean, y_sampled); the other ranks return None (gp.py:351-399's vmap axis
+        is the only axis of the path that shards)."""
+        from ..parallel import Communicator, predict_sharded
+        comm = Communicator()
+        jitter = float(kwargs.get("jitter", 1e-6))
+        mean_shift = None
+        if comm.rank == 0:
+            X_new = self._set_data(X_new)
+            if samples is None:
+                samples = self.get_samples(chain_dim=False)
+            ells, scales, noises, yres, eps, mean_shift = self._sweep_inputs(rng_key, X_new, samples, n)
+            args = (self.X_train, yres, X_new, {"k_length": ells, "k_scale": scales, "noise": noises}, eps)
+        else:
+            args = (None, None, None, None, None)
+        engines = _lib.get_sweep_engines(self._device)
+        for e in engines:
+            e._train_owner = None
+        res = predict_sharded(engines, self._kind, *args, noiseless, jitter, comm)
+        if res is None:
+            return None
+        means, y_sampled, infos = res
+        return self._sweep_outputs(means, y_sampled, mean_shift, filter_nans)
 
     def sample_from_prior(self, rng_key, X: np.ndarray, num_samples: int = 10):
         """Samples from the prior predictive distribution at X (gp.py:401-408)."""

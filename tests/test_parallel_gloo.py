@@ -72,3 +72,37 @@ def test_sharded_sweep_equals_single_process(tmp_path, world):
     np.testing.assert_allclose(got["means"], means, rtol=1e-10)
     np.testing.assert_allclose(got["draws"], yy, rtol=1e-9, atol=1e-12)
     assert got["infos"].shape == (5,) and np.all(got["infos"] == 0)
+
+
+def _model_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpax_amd import ExactGP, _lib
+    from gpax_amd.utils import get_keys
+    from tests.oracle_engine import OracleEngine
+
+    _lib.set_engine(OracleEngine())
+    m = ExactGP(2, "Matern", mean_fn=lambda x: 0.3 * x[:, 0])
+    if rank == 0:  # only rank 0 holds data and samples
+        X, y, Xn, samples, _ = _problem()
+        m.X_train, m.y_train = m._set_data(X, y)
+        res = m.predict_distributed(get_keys()[1], Xn, samples, n=2)
+        single = m.predict(get_keys()[1], Xn, samples, n=2)
+        np.savez(os.path.join(outdir, "model.npz"), ym=res[0], ys=res[1], ym1=single[0], ys1=single[1])
+    else:
+        assert m.predict_distributed(None, None) is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_model_predict_distributed_equals_predict(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_model_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "model.npz")
+    np.testing.assert_allclose(got["ym"], got["ym1"], rtol=1e-12)
+    np.testing.assert_allclose(got["ys"], got["ys1"], rtol=1e-12)
+    assert got["ys"].shape == (5, 2, 17)
