@@ -53,6 +53,8 @@ class Communicator:
         meta = [None]
         if self.rank == src:
             arr = np.ascontiguousarray(arr)
+            if not arr.flags.writeable:  # torch.from_numpy wants a writable buffer (e.g. broadcast views)
+                arr = arr.copy()
             meta = [(tuple(arr.shape), str(arr.dtype))]
         dist.broadcast_object_list(meta, src=src)
         shape, dtype = meta[0]
