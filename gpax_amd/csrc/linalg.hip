@@ -108,11 +108,7 @@ static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int 
   return launch_gemm_nt(ctx, g, rows, cols, 0, prof_cls, 2.0 * K * entries);
 }
 
-int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,
-                int* dInfo, int batch, int64_t a_bs, int64_t linv_bs) {
-  const BatchStrides bs{batch > 1 ? batch : 1, a_bs, linv_bs};
-  const int nblk = np / TILE;
-  const int nouter = (nblk + OUTER_TILES - 1) / OUTER_TILES;
+static int ensure_events(gpx_ctx* ctx, int nouter) {
   while ((int)ctx->evP.size() < nouter + 1) {
     hipEvent_t e1, e2;
     GPX_HIP(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
@@ -120,6 +116,15 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     ctx->evP.push_back(e1);
     ctx->evU.push_back(e2);
   }
+  return 0;
+}
+
+int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,
+                int* dInfo, int batch, int64_t a_bs, int64_t linv_bs) {
+  const BatchStrides bs{batch > 1 ? batch : 1, a_bs, linv_bs};
+  const int nblk = np / TILE;
+  const int nouter = (nblk + OUTER_TILES - 1) / OUTER_TILES;
+  GPX_TRY(ensure_events(ctx, nouter));
   hipStream_t smain = ctx->stream, span = ctx->pstream;
   // the panel stream starts after everything already queued on the main stream (Gram etc.)
   GPX_HIP(ctx, hipEventRecord(ctx->evU[nouter], smain));
@@ -156,21 +161,43 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
 // Column block i:  X_i = B_i * Linv_i^T, then B_{>i} -= X_i * L[>i, i]^T.  Two-level blocking
 // as in potrf_lower.  upper_rows != 0: B is upper triangular (the L^-T build of the gradient),
 // so column block i only involves row tiles 0..i.
+// Same two-stream look-ahead as potrf_lower: the latency-bound column steps of outer block k + 1 and the
+// update of just its columns (U1) run on the panel stream while the bulk update U2(k) of everything further
+// right runs on the main stream.
 int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const double* dL,
                   int64_t ldl, const double* dLinv, int nblk, int upper_rows, int batch,
                   int64_t b_bs, int64_t l_bs, int64_t linv_bs) {
   if (batch < 1) batch = 1;
-  for (int ob = 0; ob < nblk; ob += OUTER_TILES) {
+  const int nouter = (nblk + OUTER_TILES - 1) / OUTER_TILES;
+  GPX_TRY(ensure_events(ctx, nouter));
+  hipStream_t smain = ctx->stream, span = ctx->pstream;
+  GPX_HIP(ctx, hipEventRecord(ctx->evU[nouter], smain));
+  GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[nouter], 0));
+  // rest update of outer block [ob, oe): B[:, c0:c1) -= B[:, ob:oe) L[c0:c1, ob:oe)^T
+  auto rest_update = [&](int ob, int oe, int c0, int c1) -> int {
+    if (c1 <= c0) return 0;
+    const int rt = upper_rows ? oe : rows_t;
+    const int K = (oe - ob) * TILE;
+    const double* Lsub = dL + (int64_t)c0 * TILE * ldl + (int64_t)ob * TILE;
+    GemmArgs g = gemm_args(dB + (int64_t)ob * TILE, ldb, Lsub, ldl, dB + (int64_t)c0 * TILE, ldb, K, -1.0, 1.0);
+    set_batch(g, batch, b_bs, l_bs, b_bs);
+    return launch_gemm_nt(ctx, g, rt, c1 - c0, 0, GPX_PROF_GEMM_OTHER, 2.0 * rt * (c1 - c0) * (double)TILE * TILE * K);
+  };
+  int rc = 0;
+  for (int k = 0; k < nouter && rc >= 0; ++k) {
+    const int ob = k * OUTER_TILES;
     const int oe = (ob + OUTER_TILES < nblk) ? ob + OUTER_TILES : nblk;
-    for (int i = ob; i < oe; ++i) {
+    const int oe2 = (oe + OUTER_TILES < nblk) ? oe + OUTER_TILES : nblk;
+    ctx->s = span;
+    for (int i = ob; i < oe && rc >= 0; ++i) {
       const int rt = upper_rows ? (i + 1) : rows_t;
       double* Bi = dB + (int64_t)i * TILE;
       {
         GemmArgs g = gemm_args(Bi, ldb, dLinv + (int64_t)i * TILE * TILE, TILE, Bi, ldb, TILE, 1.0,
                                0.0);
         set_batch(g, batch, b_bs, linv_bs, b_bs);
-        GPX_TRY(launch_gemm_nt(ctx, g, rt, 1, 0, GPX_PROF_GEMM_OTHER,
-                               2.0 * rt * TILE * (double)TILE * TILE));
+        rc = launch_gemm_nt(ctx, g, rt, 1, 0, GPX_PROF_GEMM_OTHER, 2.0 * rt * TILE * (double)TILE * TILE);
+        if (rc < 0) break;
       }
       const int inner_cols = oe - i - 1;
       if (inner_cols > 0) {
@@ -178,23 +205,25 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
         GemmArgs g = gemm_args(Bi, ldb, Lsub, ldl, dB + (int64_t)(i + 1) * TILE, ldb, TILE, -1.0,
                                1.0);
         set_batch(g, batch, b_bs, l_bs, b_bs);
-        GPX_TRY(launch_gemm_nt(ctx, g, rt, inner_cols, 0, GPX_PROF_GEMM_OTHER,
-                               2.0 * rt * inner_cols * (double)TILE * TILE * TILE));
+        rc = launch_gemm_nt(ctx, g, rt, inner_cols, 0, GPX_PROF_GEMM_OTHER,
+                            2.0 * rt * inner_cols * (double)TILE * TILE * TILE);
       }
     }
-    const int rest = nblk - oe;
-    if (rest > 0) {
-      const int rt = upper_rows ? oe : rows_t;
-      const int K = (oe - ob) * TILE;
-      const double* Lsub = dL + (int64_t)oe * TILE * ldl + (int64_t)ob * TILE;
-      GemmArgs g = gemm_args(dB + (int64_t)ob * TILE, ldb, Lsub, ldl, dB + (int64_t)oe * TILE, ldb,
-                             K, -1.0, 1.0);
-      set_batch(g, batch, b_bs, l_bs, b_bs);
-      GPX_TRY(launch_gemm_nt(ctx, g, rt, rest, 0, GPX_PROF_GEMM_OTHER,
-                             2.0 * rt * rest * (double)TILE * TILE * K));
+    if (rc < 0) break;
+    GPX_HIP(ctx, hipEventRecord(ctx->evP[k], span));
+    GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
+    if (oe < nblk) {
+      // U1(k): the next outer block's columns, after U2(k-1) which also wrote them (fixed accumulation order)
+      if (k > 0) GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
+      rc = rest_update(ob, oe, oe, oe2);
+      if (rc < 0) break;
+      ctx->s = smain;
+      rc = rest_update(ob, oe, oe2, nblk);
+      GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain));
     }
   }
-  return 0;
+  ctx->s = smain;
+  return rc;
 }
 
 // ---- small kernels ---------------------------------------------------------------------------
