@@ -276,6 +276,22 @@ __device__ __forceinline__ void diag16(double* D, double* Dinv, double* col /* 2
   }
 }
 
+// Phase tracing for tools/exp/potf2_phase.hip (compiled only with -DGPX_POTF2_TRACE): shader-clock stamps at
+// every barrier.  Measured per panel: dump 1650, diagonal factor 5750 (16 dependent column steps, each an LDS
+// write -> read round trip + the reciprocal), TRSM 1800, update 4300 .. 960 cycles; the diagonal factor is 45 %
+// of the 46 us.  Variants measured and rejected: gathering the column with ds_bpermute / v_readlane instead of
+// LDS (7150 cycles per factor), and a wave-specialised pipeline that overlaps the diagonal factor of panel p+1
+// with the trailing update of panel p (three worker waves; 53 vs 49 us — the factor stays the critical path).
+#ifdef GPX_POTF2_TRACE
+__device__ long long gpx_potf2_trace[64];
+#define GPX_TRACE(slot)                                                     \
+  do {                                                                      \
+    if (threadIdx.x == 0) gpx_potf2_trace[(slot)] = (long long)clock64();   \
+  } while (0)
+#else
+#define GPX_TRACE(slot) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t lda, double* Linv, int* info,
                                                             int info_base, int64_t a_bs, int64_t linv_bs) {
   A += (int64_t)blockIdx.x * a_bs; // one workgroup per batch entry
@@ -313,6 +329,7 @@ __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t l
   for (int u = 0; u < 7; ++u) R[u] = pd4_t{0.0, 0.0, 0.0, 0.0};
   int bad = 0;
 
+  GPX_TRACE(0);
   for (int p = 0; p < 8; ++p) {
     // ---- A: dump column p of C and row p of R -----------------------------------------------
 #pragma unroll
@@ -328,6 +345,7 @@ __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t l
       if (i == p) acc_to_lds(R[u], Rrow + c * TSZ, lane);
     }
     __syncthreads();
+    GPX_TRACE(1 + 4 * p);
     // ---- B: diagonal tile -----------------------------------------------------------------------
     if (w == 0) {
       diag16(Pbuf + p * TSZ, Dinv, col, lane, bad, p * TS);
@@ -340,6 +358,7 @@ __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t l
       }
     }
     __syncthreads();
+    GPX_TRACE(2 + 4 * p);
     // ---- C: panel TRSM and inverse row ----------------------------------------------------------
     for (int m = w; m < 7; m += 4) {
       if (m < 7 - p) { // L(i,p) = C(i,p) Linv_pp^T
@@ -357,6 +376,7 @@ __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t l
       }
     }
     __syncthreads();
+    GPX_TRACE(3 + 4 * p);
     // ---- D: trailing updates --------------------------------------------------------------------
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -371,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t l
       if (i > p && c <= p) R[u] = mma_nn(R[u], Pbuf + i * TSZ, (c == p) ? Dinv : Rrow + c * TSZ, lane, -1.0);
     }
     __syncthreads();
+    GPX_TRACE(4 + 4 * p);
   }
   if (tid == 0 && bad != 0 && info != nullptr) {
     if (*info == 0) *info = info_base + bad;
