@@ -31,8 +31,8 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2.4 GHz x 32 flop/clk/SIMD (SU
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=36)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--N", type=int, default=16384)
     ap.add_argument("--d", type=int, default=2)
     ap.add_argument("--M", type=int, default=1024)
