@@ -280,8 +280,13 @@ __device__ __forceinline__ void diag16(double* D, double* Dinv, double* col /* 2
 // every barrier.  Measured per panel: dump 1650, diagonal factor 5750 (16 dependent column steps, each an LDS
 // write -> read round trip + the reciprocal), TRSM 1800, update 4300 .. 960 cycles; the diagonal factor is 45 %
 // of the 46 us.  Variants measured and rejected: gathering the column with ds_bpermute / v_readlane instead of
-// LDS (7150 cycles per factor), and a wave-specialised pipeline that overlaps the diagonal factor of panel p+1
-// with the trailing update of panel p (three worker waves; 53 vs 49 us — the factor stays the critical path).
+// LDS (7150 cycles per factor); a wave-specialised pipeline that overlaps the diagonal factor of panel p+1
+// with the trailing update of panel p (three worker waves; 53 vs 49 us — the factor stays the critical path);
+// and a "chain wave" version (wave 0 runs only diag(p) -> L(p+1,p) -> C(p+1,p+1) -> diag(p+1) out of LDS, two
+// barriers per panel, bit-identical results): its chain costs 7750 cycles per panel as planned, but the three
+// worker waves need 9700 - 12700 (each 16x16 tile update is 4 dependent MFMAs behind their own LDS operand
+// reads, ~480 cycles per tile), so the chain wave waits for them and the block still takes ~50 us.  The next
+// step for this kernel is software-pipelining the workers' operand reads, not more overlap.
 #ifdef GPX_POTF2_TRACE
 __device__ long long gpx_potf2_trace[64];
 #define GPX_TRACE(slot)                                                     \
