@@ -197,6 +197,8 @@ class Engine:
     def gram(self, kind: int, X, Z, ell, scale: float, diag_add: float, add_diag: bool) -> np.ndarray:
         X = _f64(X)
         Z = _f64(Z)
+        if X.ndim != 2 or Z.ndim != 2 or X.shape[1] != Z.shape[1]:
+            raise ValueError(f"gram: X {X.shape} and Z {Z.shape} must be (n, d) and (m, d)")
         n, d = X.shape
         m = Z.shape[0]
         ell = pack_ell(kind, ell, d)
@@ -265,8 +267,23 @@ class Engine:
                                             _ptr(alpha)), "gpx_fit_batch")
         return lml, info, grad, alpha
 
-    def posterior(self, Xnew, noise_p: float, jitter: float, want_cov: bool = True, want_var: bool = False):
+    def _xu(self, Xu) -> np.ndarray:
+        Xu = _f64(Xu)
+        if Xu.ndim != 2 or Xu.shape[1] != self.d:
+            raise ValueError(f"inducing points have shape {Xu.shape}; expected (M_ind, d={self.d})")
+        return Xu
+
+    def _xnew(self, Xnew) -> np.ndarray:
+        """Test inputs as the C-ABI reads them: (M, d) — or (T, M, d) with task-specific training sets."""
         Xnew = _f64(Xnew)
+        want = 3 if getattr(self, "T", 1) > 1 else 2
+        if Xnew.ndim != want or Xnew.shape[-1] != self.d or (want == 3 and Xnew.shape[0] != self.T):
+            raise ValueError(f"X_new has shape {Xnew.shape}; expected "
+                             f"{'(T=%d, M, d=%d)' % (self.T, self.d) if want == 3 else '(M, d=%d)' % self.d}")
+        return Xnew
+
+    def posterior(self, Xnew, noise_p: float, jitter: float, want_cov: bool = True, want_var: bool = False):
+        Xnew = self._xnew(Xnew)
         M = Xnew.shape[0]
         self.M = M
         mean = np.empty(M)
@@ -302,7 +319,7 @@ class Engine:
         yres = _f64(yres)  # (N,) shared, (S, N) per sample or (T, N) per task
         rows = 1 if yres.ndim == 1 else yres.shape[0]
         yres = _f64(yres, (rows, self.N))
-        Xnew = _f64(Xnew)  # (M, d), or (T, M, d) after set_train with task-specific inputs
+        Xnew = self._xnew(Xnew)  # (M, d), or (T, M, d) after set_train with task-specific inputs
         M = Xnew.shape[-2]
         self.M = M
         n = 0 if eps is None else int(np.asarray(eps).shape[1])
@@ -325,7 +342,7 @@ class Engine:
         """VFE bound of viSparseGP.model and (optionally) its gradient w.r.t. (ell, scale, noise, Xu)
         plus d bound / d yres.  Returns (bound, info, grads-or-None)."""
         ell = broadcast_lengthscale(ell, self.d)
-        Xu = _f64(Xu)
+        Xu = self._xu(Xu)
         Mi = Xu.shape[0]
         yres = _f64(yres, (self.N,))
         bound, info = C.c_double(), C.c_int()
@@ -346,9 +363,9 @@ class Engine:
     def sgp_posterior(self, kind: int, ell, scale: float, noise: float, jitter: float, Xu, yres, Xnew, noise_p: float,
                       want_cov: bool = True, want_var: bool = False):
         ell = broadcast_lengthscale(ell, self.d)
-        Xu = _f64(Xu)
+        Xu = self._xu(Xu)
         yres = _f64(yres, (self.N,))
-        Xnew = _f64(Xnew)
+        Xnew = self._xnew(Xnew)
         Ms = Xnew.shape[0]
         mean = np.empty(Ms)
         cov = np.empty((Ms, Ms)) if want_cov else None

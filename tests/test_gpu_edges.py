@@ -1,0 +1,139 @@
+"""GPU edge cases of the hot path through the C-ABI: tiny and ragged sizes, the maximum input dimension,
+means-only sweeps, near-singular and non-PD hyper-parameters (NaN rows, never a crash)."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_posterior(engine, kind, name, X, y, Xn, p, tol=1e-8):
+    engine.set_train(X)
+    lml, info = engine.factor(kind, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+    assert info == 0
+    expect = ref.exactgp_log_likelihood(X, y, p, kernel=name, jitter=1e-6)
+    assert abs(lml - expect) <= 1e-10 * max(1.0, abs(expect))
+    mean, cov, var = engine.posterior(Xn, p["noise"], 1e-6, want_cov=True, want_var=True)
+    m_ref, c_ref = ref.get_mvn_posterior(X, y, Xn, p, False, kernel=name, jitter=1e-6, route="inv")
+    assert np.linalg.norm(mean - m_ref) <= tol * max(np.linalg.norm(m_ref), 1e-12)
+    assert np.linalg.norm(cov - c_ref) <= tol * np.linalg.norm(c_ref)
+    np.testing.assert_allclose(var, np.diag(c_ref), rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind,name", [(0, "RBF"), (1, "Matern")])
+@pytest.mark.parametrize("N,M", [(2, 1), (3, 5), (2, 130), (127, 1), (129, 129)])
+def test_tiny_and_ragged_sizes(engine, kind, name, N, M):
+    rng = np.random.default_rng(N * 131 + M)
+    X, Xn = rng.uniform(0, 4, (N, 2)), rng.uniform(0, 4, (M, 2))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(N)
+    p = {"k_length": np.array([1.0, 1.4]), "k_scale": 1.2, "noise": 0.2}
+    _check_posterior(engine, kind, name, X, y, Xn, p)
+    eps = rng.standard_normal((3, 2, M))
+    th = {"k_length": np.tile(p["k_length"], (3, 1)) * rng.uniform(0.9, 1.1, (3, 2)), "k_scale": np.full(3, 1.2),
+          "noise": np.array([0.2, 0.25, 0.3])}
+    means, draws, infos = engine.predict_sweep(kind, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps)
+    assert np.all(infos == 0) and means.shape == (3, M) and draws.shape == (3, 2, M)
+    for s in range(3):
+        q = {"k_length": th["k_length"][s], "k_scale": 1.2, "noise": th["noise"][s]}
+        m_ref, c_ref = ref.get_mvn_posterior(X, y, Xn, q, False, kernel=name, jitter=1e-6, route="inv")
+        assert np.linalg.norm(means[s] - m_ref) <= 1e-8 * max(np.linalg.norm(m_ref), 1e-12)
+        assert np.linalg.norm(draws[s] - ref.mvn_sample(m_ref, c_ref, eps[s])) <= 1e-7 * np.linalg.norm(draws[s])
+
+
+def test_single_training_point_closed_form(engine):
+    # N = 1 (the reference's y.squeeze() makes y 0-d there, gp.py:412; the device path has no such limit)
+    x, yv, s2, noise, ell = 0.7, 1.3, 1.5, 0.2, 0.9
+    Xn = np.array([[0.1], [0.7], [2.0]])
+    engine.set_train(np.array([[x]]))
+    lml, info = engine.factor(0, [ell], s2, noise, 1e-6, np.array([yv]))
+    kxx = s2 + noise + 1e-6
+    assert info == 0 and abs(lml - (-0.5 * yv * yv / kxx - 0.5 * np.log(kxx) - 0.5 * np.log(2 * np.pi))) < 1e-12
+    mean, cov, var = engine.posterior(Xn, noise, 1e-6, want_cov=True, want_var=True)
+    kp = s2 * np.exp(-0.5 * ((Xn[:, 0] - x) / ell) ** 2)
+    np.testing.assert_allclose(mean, kp * yv / kxx, rtol=1e-12)
+    kpp = s2 * np.exp(-0.5 * ((Xn[:, None, 0] - Xn[None, :, 0]) / ell) ** 2) + (noise + 1e-6) * np.eye(3)
+    np.testing.assert_allclose(cov, kpp - np.outer(kp, kp) / kxx, rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(var, np.diag(cov), rtol=1e-11)
+
+
+@pytest.mark.parametrize("kind,name", [(0, "RBF"), (1, "Matern"), (2, "Periodic")])
+def test_maximum_input_dimension(engine, kind, name):
+    N, M, d = 150, 40, 16  # GPX_MAX_DIM: the generic (non-templated) paths of Gram / k_pp / gradient
+    rng = np.random.default_rng(7)
+    X, Xn = rng.uniform(0, 1, (N, d)), rng.uniform(0, 1, (M, d))
+    y = np.sin(X.sum(1))
+    p = {"k_length": rng.uniform(1.0, 3.0, d), "k_scale": 1.1, "noise": 0.1}
+    ell = p["k_length"]
+    if kind == 2:
+        p["period"] = 3.1
+        ell = np.concatenate([ell, [3.1]])
+    engine.set_train(X)
+    lml, info = engine.factor(kind, ell, p["k_scale"], p["noise"], 1e-6, y)
+    assert info == 0 and abs(lml - ref.exactgp_log_likelihood(X, y, p, kernel=name, jitter=1e-6)) <= 1e-10 * abs(lml)
+    g_ell, g_scale, g_noise, alpha = engine.lml_grad()
+    assert g_ell.shape == (d + (kind == 2),)
+    if kind != 2:
+        e_ell, e_scale, e_noise, _ = ref.exactgp_log_likelihood_grad(X, y, p, kernel=name, jitter=1e-6)
+        sc = max(np.abs(e_ell).max(), abs(e_scale), abs(e_noise))
+        np.testing.assert_allclose(g_ell, e_ell, rtol=1e-8, atol=1e-8 * sc)
+    engine.factor(kind, ell, p["k_scale"], p["noise"], 1e-6, y)
+    mean, cov, _ = engine.posterior(Xn, p["noise"], 1e-6)
+    m_ref, c_ref = ref.get_mvn_posterior(X, y, Xn, p, False, kernel=name, jitter=1e-6, route="inv")
+    assert np.linalg.norm(mean - m_ref) <= 1e-8 * np.linalg.norm(m_ref)
+    assert np.linalg.norm(cov - c_ref) <= 1e-8 * np.linalg.norm(c_ref)
+    with pytest.raises(RuntimeError):
+        engine.set_train(rng.uniform(0, 1, (10, 17)))  # d > GPX_MAX_DIM is refused, not truncated
+    engine.set_train(X)
+
+
+def test_means_only_sweep_and_single_sample(engine):
+    N, d, M = 90, 2, 21
+    X, y, Xn, p = ref.synthetic_problem(N, d, M, seed=4)
+    th = ref.synthetic_theta_samples(1, d, seed=5)
+    engine.set_train(X)
+    means, draws, infos = engine.predict_sweep(1, th["k_length"], th["k_scale"], th["noise"], y, Xn, True, 1e-6, None)
+    assert means.shape == (1, M) and draws.shape == (1, 0, M) and infos[0] == 0
+    q = {"k_length": th["k_length"][0], "k_scale": th["k_scale"][0], "noise": th["noise"][0]}
+    m_ref, _ = ref.get_mvn_posterior(X, y, Xn, q, True, kernel="Matern", jitter=1e-6, route="inv")
+    assert np.linalg.norm(means[0] - m_ref) <= 1e-8 * np.linalg.norm(m_ref)
+
+
+def test_degenerate_hyperparameters_give_nan_rows_not_crashes(engine):
+    N, d, M, S = 200, 1, 30, 6
+    rng = np.random.default_rng(0)
+    X = np.sort(rng.uniform(0, 1, (N, 1)), axis=0)
+    X[50] = X[49]  # duplicated input
+    y = np.sin(6 * X[:, 0])
+    Xn = rng.uniform(0, 1, (M, 1))
+    ells = np.array([[0.3], [1e6], [1e-9], [0.3], [0.3], [0.3]])  # 1e6: K ~ rank one; 1e-9: K ~ diagonal
+    scales = np.array([1.0, 1.0, 1.0, 1e-300, 1.0, 1.0])
+    noises = np.array([0.05, 0.0, 0.0, 0.05, -1.0, np.nan])
+    eps = rng.standard_normal((S, 1, M))
+    engine.set_train(X)
+    means, draws, infos = engine.predict_sweep(0, ells, scales, noises, y, Xn, False, 1e-6, eps)
+    assert infos[0] == 0 and np.all(np.isfinite(means[0])) and np.all(np.isfinite(draws[0]))
+    assert infos[2] == 0 and np.all(np.isfinite(means[2]))        # diagonal K + jitter is fine
+    assert infos[4] != 0 and np.all(np.isnan(means[4])) and np.all(np.isnan(draws[4]))
+    assert np.all(np.isnan(means[5])) or infos[5] != 0             # NaN noise poisons only its own row
+    for s in (1, 3):  # numerically singular: either a clean failure (NaN row) or finite numbers, never garbage shapes
+        assert (infos[s] != 0 and np.all(np.isnan(draws[s]))) or np.all(np.isfinite(means[s]))
+    # the context is still usable afterwards
+    lml, info = engine.factor(0, [0.3], 1.0, 0.05, 1e-6, y)
+    assert info == 0 and np.isfinite(lml)
+
+
+def test_bad_arguments_are_errors_not_crashes(engine):
+    X, y, Xn, p = ref.synthetic_problem(20, 2, 5, seed=1)
+    engine.set_train(X)
+    with pytest.raises(NotImplementedError):
+        from gpax_amd import _lib
+        _lib.kernel_kind("NNGP")
+    with pytest.raises(RuntimeError):
+        engine.factor(7, p["k_length"], 1.0, 0.1, 1e-6, y)          # unknown kernel kind
+    with pytest.raises(RuntimeError):
+        engine.lml_grad()                                            # no factorisation to differentiate
+    with pytest.raises(Exception):
+        engine.predict_sweep(1, np.ones((2, 2)), np.ones(2), np.ones(2), y, Xn[:, :1], False, 1e-6, None)  # d mismatch
+    lml, info = engine.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+    assert info == 0
