@@ -45,11 +45,20 @@ double kdiag_value(const KernelParams& kp) {
 struct CovSplit {
   int splits, kchunk;
 };
-CovSplit cov_split(const gpx_ctx* ctx) {
+// Samples per launch the sweep aims for at this N (before the memory / S caps): ~2 (16384 / Np)^2.
+int nominal_batch(const gpx_ctx* ctx) {
+  const double r = 16384.0 / (double)ctx->Np;
+  int B = (int)(2.0 * r * r);
+  return B < 1 ? 1 : (B > 256 ? 256 : B);
+}
+
+// `sweep`: the slab count is sized for the sweep's nominal batch at this N (a function of N only, so that a
+// sweep's results do not depend on the batch size actually used); otherwise for a single sample.
+CovSplit cov_split(const gpx_ctx* ctx, bool sweep = false) {
   const int nt = (ctx->N + TILE - 1) / TILE;
   const int mt = ctx->Mp / TILE;
   const int ktot = nt * TILE;
-  const int lower_tiles = mt * (mt + 1) / 2;
+  const int lower_tiles = mt * (mt + 1) / 2 * (sweep ? nominal_batch(ctx) : 1);
   int splits = (512 + lower_tiles - 1) / lower_tiles;
   const int max_splits = ktot / 256 > 0 ? ktot / 256 : 1;
   if (splits > max_splits) splits = max_splits;
@@ -81,16 +90,17 @@ TaskStride ts_new(const gpx_ctx* ctx) {
 
 // Plan over the context's own buffers: B samples per launch, sample b at base + b * stride.
 // B = 1 with th = nullptr is the eager single-theta path of gpx_factor / gpx_posterior.
-BatchPlan make_plan(gpx_ctx* ctx, int B, int n_pad, bool fused) {
+BatchPlan make_plan(gpx_ctx* ctx, int B, int n_pad, bool fused, bool sweep = false) {
   BatchPlan p;
   p.B = B;
+  p.sweep = sweep;
   p.yres = ctx->yres.d();
   p.k_bs = (int64_t)(ctx->Np + (fused ? ctx->Mp : 0)) * ctx->ldk;
   p.linv_bs = (int64_t)(ctx->Np / TILE) * TILE * TILE;
   p.mean_bs = ctx->Mp;
   p.cov_bs = (int64_t)ctx->Mp * ctx->ldc;
   p.covlinv_bs = (int64_t)(ctx->Mp / TILE) * TILE * TILE;
-  p.splitk_bs = (ctx->Mp > 0) ? (int64_t)cov_split(ctx).splits * p.cov_bs : 0;
+  p.splitk_bs = (ctx->Mp > 0) ? (int64_t)cov_split(ctx, sweep).splits * p.cov_bs : 0;
   p.eps_bs = (int64_t)n_pad * ctx->ldc;
   p.info_train = sc_int(ctx) + SI_TRAIN;
   p.info_cov = sc_int(ctx) + SI_COV;
@@ -224,7 +234,7 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov, const BatchPlan& bp) {
                         bp.k_bs, bp.mean_bs, bp.th, bp.pred_diag, bp.pd_bs));
   ctx->cov_factored = false;
   if (want_cov) {
-    const CovSplit cs = cov_split(ctx);
+    const CovSplit cs = cov_split(ctx, bp.sweep);
     const int ktot = nt * TILE;
     const int64_t ldp = ctx->ldc;
     const int64_t stride = (int64_t)Mp * ldp;
@@ -367,10 +377,9 @@ int pick_batch(gpx_ctx* ctx, int S, int n_pad, bool want_cov) {
   if (const char* e = getenv("GPX_SWEEP_BATCH")) forced = atoi(e);
   // auto: ~2 * (16384 / Np)^2 — 1 at N = 16384 (the trailing SYRK alone fills the chip), 7 at 8192,
   // 30 at 4096, 256 (cap) from N ~ 1400 down; measured in tools/small_n_sweep.py / multi_ctx.py
-  const double r = 16384.0 / (double)ctx->Np;
-  int B = forced > 0 ? forced : (int)(2.0 * r * r);
+  int B = forced > 0 ? forced : nominal_batch(ctx);
   if (B > 256) B = 256;
-  const BatchPlan p = make_plan(ctx, 1, n_pad, true);
+  const BatchPlan p = make_plan(ctx, 1, n_pad, true, true);
   double per = (double)p.k_bs + p.linv_bs + 2.0 * p.mean_bs;
   if (want_cov) per += (double)p.cov_bs + p.splitk_bs + p.covlinv_bs + 2.0 * p.eps_bs;
   per *= sizeof(double);
@@ -425,7 +434,7 @@ int sweep_core(gpx_ctx* ctx, const SweepIO& io) {
   ctx->jitter = io.jitter;
   GPX_TRY(fill_theta_table(ctx, io));
   const int B = pick_batch(ctx, S, n_pad, n > 0);
-  BatchPlan bp = make_plan(ctx, B, n_pad, true);
+  BatchPlan bp = make_plan(ctx, B, n_pad, true, true);
   GPX_TRY(ensure(ctx, ctx->binfo, (size_t)2 * B * sizeof(int)));
   bp.info_train = ctx->binfo.i();
   bp.info_cov = ctx->binfo.i() + B;
@@ -547,8 +556,11 @@ void gpx_destroy(gpx_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->X,    &ctx->K,   &ctx->W,       &ctx->Linv,   &ctx->yres, &ctx->scal,
                       &ctx->part, &ctx->alpha, &ctx->Xnew,  &ctx->Vt,     &ctx->Cov,  &ctx->CovLinv,
                       &ctx->SplitK, &ctx->mean, &ctx->var,  &ctx->eps,    &ctx->draws, &ctx->tA,
-                      &ctx->tB,   &ctx->tC,  &ctx->thtab,   &ctx->binfo, &ctx->bscal, &ctx->byres, &ctx->diagv};
+                      &ctx->tB,   &ctx->tC,  &ctx->thtab,   &ctx->binfo, &ctx->bscal, &ctx->byres, &ctx->diagv, &ctx->st_eps, &ctx->st_yres,
+                      &ctx->st_means, &ctx->st_samples, &ctx->st_infos, &ctx->st_vars, &ctx->st_pred};
     for (DevBuf* b : bufs) b->release();
+    ctx->pin_in.release();
+    ctx->pin_out.release();
     sgp_release(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -858,18 +870,14 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   GPX_HIP(ctx, hipSetDevice(ctx->device));
   const int N = ctx->N;
   GPX_TRY(set_xnew(ctx, Xnew, M));
-  // device staging for all inputs/outputs of the sweep: nothing crosses PCIe inside the loop
-  DevBuf dEps, dYres, dMeans, dSamples, dInfos, dVars, dPred;
+  // device staging for all inputs/outputs of the sweep: nothing crosses PCIe inside the loop.  The staging
+  // buffers live in the context and only grow: a hipMalloc / hipFree pair per call costs ~20 ms once the
+  // context holds multi-GB batch buffers (measured at N = 512, B = 256), more than the sweep itself.
+  DevBuf &dEps = ctx->st_eps, &dYres = ctx->st_yres, &dMeans = ctx->st_means, &dSamples = ctx->st_samples,
+         &dInfos = ctx->st_infos, &dVars = ctx->st_vars, &dPred = ctx->st_pred;
   int rc = 0;
   auto cleanup = [&]() {
-    (void)hipStreamSynchronize(ctx->stream); // nothing may still read the staging buffers
-    dVars.release();
-    dPred.release();
-    dEps.release();
-    dYres.release();
-    dMeans.release();
-    dSamples.release();
-    dInfos.release();
+    (void)hipStreamSynchronize(ctx->stream); // nothing may still read the caller's host buffers
   };
 #define SWEEP_TRY(expr)  \
   do {                   \
@@ -905,11 +913,13 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
     SWEEP_HIP(hipMemcpyAsync(ctx->yres.d(), yres, (size_t)N * sizeof(double), hipMemcpyHostToDevice,
                              ctx->stream));
   }
+  const size_t draws_b = (size_t)S * n * M * sizeof(double), means_b = (size_t)S * M * sizeof(double);
   if (n > 0) {
-    SWEEP_TRY(ensure(ctx, dEps, (size_t)S * n * M * sizeof(double)));
-    SWEEP_TRY(ensure(ctx, dSamples, (size_t)S * n * M * sizeof(double)));
-    SWEEP_HIP(hipMemcpyAsync(dEps.d(), eps, (size_t)S * n * M * sizeof(double), hipMemcpyHostToDevice,
-                             ctx->stream));
+    SWEEP_TRY(ensure(ctx, dEps, draws_b));
+    SWEEP_TRY(ensure(ctx, dSamples, draws_b));
+    SWEEP_HIP(ctx->pin_in.ensure(draws_b));
+    std::memcpy(ctx->pin_in.p, eps, draws_b);
+    SWEEP_HIP(hipMemcpyAsync(dEps.d(), ctx->pin_in.p, draws_b, hipMemcpyHostToDevice, ctx->stream));
   }
   SweepIO io;
   io.kind = kind;
@@ -929,18 +939,19 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   io.dVars = vars ? dVars.d() : nullptr;
   io.dPredDiag = pred_diag ? dPred.d() : nullptr;
   SWEEP_TRY(sweep_core(ctx, io));
-  std::vector<int> hinfos(2 * (size_t)S);
-  SWEEP_HIP(hipMemcpyAsync(means, dMeans.d(), (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost,
-                           ctx->stream));
-  if (n > 0)
-    SWEEP_HIP(hipMemcpyAsync(samples, dSamples.d(), (size_t)S * n * M * sizeof(double),
-                             hipMemcpyDeviceToHost, ctx->stream));
-  SWEEP_HIP(hipMemcpyAsync(hinfos.data(), dInfos.p, (size_t)2 * S * sizeof(int), hipMemcpyDeviceToHost,
-                           ctx->stream));
-  if (vars)
-    SWEEP_HIP(hipMemcpyAsync(vars, dVars.d(), (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost,
-                             ctx->stream));
+  // results come back through the page-locked buffer: [means | samples | vars | infos]
+  const size_t infos_b = (size_t)2 * S * sizeof(int);
+  SWEEP_HIP(ctx->pin_out.ensure(2 * means_b + draws_b + infos_b));
+  char* po = static_cast<char*>(ctx->pin_out.p);
+  SWEEP_HIP(hipMemcpyAsync(po, dMeans.d(), means_b, hipMemcpyDeviceToHost, ctx->stream));
+  if (n > 0) SWEEP_HIP(hipMemcpyAsync(po + means_b, dSamples.d(), draws_b, hipMemcpyDeviceToHost, ctx->stream));
+  if (vars) SWEEP_HIP(hipMemcpyAsync(po + means_b + draws_b, dVars.d(), means_b, hipMemcpyDeviceToHost, ctx->stream));
+  SWEEP_HIP(hipMemcpyAsync(po + 2 * means_b + draws_b, dInfos.p, infos_b, hipMemcpyDeviceToHost, ctx->stream));
   SWEEP_HIP(hipStreamSynchronize(ctx->stream));
+  std::memcpy(means, po, means_b);
+  if (n > 0) std::memcpy(samples, po + means_b, draws_b);
+  if (vars) std::memcpy(vars, po + means_b + draws_b, means_b);
+  const int* hinfos = reinterpret_cast<const int*>(po + 2 * means_b + draws_b);
   cleanup();
 #undef SWEEP_TRY
 #undef SWEEP_HIP

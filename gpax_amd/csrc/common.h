@@ -55,6 +55,31 @@ struct DevBuf {
   int* i() const { return static_cast<int*>(p); }
 };
 
+// Pinned host staging buffer (grow-only): bulk sweep inputs / outputs cross PCIe from page-locked memory, so
+// that hipMemcpyAsync is a plain DMA enqueue and never falls into the runtime's pageable-copy path.
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipHostFree(p);
+      p = nullptr;
+      cap = 0;
+      if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  double* d() const { return static_cast<double*>(p); }
+};
+
 struct KernelParams {
   int kind;
   int d;
@@ -84,6 +109,7 @@ struct TaskStride {
 // gpax/models/gp.py:393-395 as a grid dimension).  Element b lives at base + b * stride.
 struct BatchPlan {
   int B = 1;
+  bool sweep = false;           // predictive sweep (sizes split-K for the nominal batch at this N)
   const ThetaDev* th = nullptr; // device table (B entries) or nullptr: by-value ctx->theta
   const double* yres = nullptr; // y residuals, element stride y_bs (0 = shared by the batch)
   int64_t y_bs = 0;
@@ -157,6 +183,8 @@ struct gpx_ctx {
   bool cov_factored = false;
 
   // ---- batched sweep state (gpx_predict_sweep / gpx_sweep_resident) -----------------------
+  gpx::DevBuf st_eps, st_yres, st_means, st_samples, st_infos, st_vars, st_pred; // sweep I/O staging (grow-only)
+  gpx::PinBuf pin_in, pin_out;                                                   // page-locked host side of it
   gpx::DevBuf thtab;   // S x ThetaDev
   gpx::DevBuf binfo;   // 2 x B ints (train / cov pivots of the batch in flight)
   gpx::DevBuf bscal;   // B x 32 doubles: lml pieces + gradient of every entry of a fit batch

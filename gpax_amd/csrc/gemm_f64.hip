@@ -212,8 +212,16 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   ProfScope ps(ctx, prof_cls, work * (g.batch > 1 ? g.batch : 1));
   if (prof_cls == GPX_PROF_GEMM_TRAILING) return launch_variant<1, 4, 4, 16, true>(ctx, g, tiles_m, tiles_n, splits);
   // latency-bound launches (too few 128x128 tiles to fill 256 CUs x 2): smaller workgroup tiles
+  // Workgroups the launch would have with 128x128 tiles (batch entries included).  The choice of shape does
+  // not change results: every C element accumulates its k range in the same order in all shapes (the k ranges
+  // trimmed by ktri / kupper only drop structural zeros), so batched and single-sample launches stay
+  // bit-identical even when they pick different shapes.
+  // Short-K launches (the K = 128 panel steps) keep the small shapes whatever the batch: their cost is the
+  // per-workgroup prologue / epilogue, which the 64x64 shapes hide with 3x the occupancy (N = 512 sweep:
+  // 126 000 vs 50 000 posteriors/s); long-K launches count the batch entries.
   const int nsplit = splits > 0 ? splits : 1;
-  const double tiles = (double)tiles_m * tiles_n * nsplit * (g.lower ? 0.55 : 1.0);
+  const int bmul = (g.batch > 1 && g.K >= 512) ? g.batch : 1;
+  const double tiles = (double)tiles_m * tiles_n * nsplit * (g.lower ? 0.55 : 1.0) * bmul;
   static int small_ok = -1;
   if (small_ok < 0) {
     const char* e = getenv("GPX_GEMM_SMALL");

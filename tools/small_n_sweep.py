@@ -8,7 +8,10 @@ kind = 1
 S = int(os.environ.get("S", "1024"))
 ctxs = [int(c) for c in os.environ.get("CTX", "1,3,6,8,12").split(",")]
 engs = [_lib.Engine(0) for _ in range(max(ctxs))]
-for N, d, M in [(256, 1, 100), (512, 1, 100), (1024, 2, 256), (2048, 2, 1024), (4096, 2, 1024)]:
+SIZES = [(256, 1, 100), (512, 1, 100), (1024, 2, 256), (2048, 2, 1024), (4096, 2, 1024)]
+if os.environ.get("SIZES"):  # e.g. SIZES=512,1,100
+    SIZES = [tuple(int(v) for v in os.environ["SIZES"].split(","))]
+for N, d, M in SIZES:
     X, y, Xn, p = ref.synthetic_problem(N, d, M, seed=0)
     th = ref.synthetic_theta_samples(S, d, seed=1)
     eps = np.random.default_rng(2).standard_normal((S, 1, M))
