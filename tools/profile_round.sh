@@ -16,6 +16,9 @@ run() {
   tail -c 300 $O/bench_under_$name.json | head -c 300; echo
 }
 run trace "" --kernel-trace --stats
+# one theta in flight: the dominant kernel's average duration here is the one bench.py's roofline block measures
+# (its profile pass runs on a single context); with 3 contexts in flight (pass above) concurrent kernels stretch
+run trace1 "--inflight 1" --kernel-trace --stats
 run fetch "--steps 1 --warmup 0" --pmc FETCH_SIZE
 run write "--steps 1 --warmup 0" --pmc WRITE_SIZE
 run sq "--steps 1 --warmup 0" --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
