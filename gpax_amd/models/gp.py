@@ -190,6 +190,8 @@ class ExactGP:
         """log p(y | theta) + log p(theta) [+ log |dtheta/du|] at theta = T(u) and its gradient
         w.r.t. u.  Returns (value, grad) — (-inf, zeros) when K(theta) is not positive definite.
         `eng`: a libgpx context that already holds X_train; default: the shared one."""
+        if want_grad:  # value + gradient in ONE device call and one synchronisation (gpx_fit_batch with B = 1)
+            return self._log_joint_batch(sites, [u], jitter, jacobian, eng=eng)[0]
         theta = self._unpack(sites, u)
         if eng is None:
             eng = self._engine()
@@ -197,11 +199,7 @@ class ExactGP:
         lml, info = eng.factor(self._kind, self._ell(theta), theta["k_scale"], theta["noise"], jitter, yres)
         if info != 0 or not np.isfinite(lml):
             return -np.inf, np.zeros_like(u)
-        g = alpha = None
-        if want_grad:
-            g_ell, g_scale, g_noise, alpha = eng.lml_grad()
-            g = np.concatenate([g_ell, [g_scale, g_noise]])
-        return self._chain_rule(sites, u, theta, lml, self._glik(g), alpha, jacobian)
+        return self._chain_rule(sites, u, theta, lml, None, None, jacobian)
 
     def _log_joint_batch(self, sites, us, jitter: float, jacobian: bool, eng=None):
         """_log_joint for a list of unconstrained vectors in ONE device pass (gpx_fit_batch: the chains of
