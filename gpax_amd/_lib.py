@@ -64,7 +64,7 @@ def load_library() -> C.CDLL:
         "gpx_posterior": (C.c_int, [vp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]),
         "gpx_mvn_draw": (C.c_int, [vp, _dp, C.c_int, _dp, _ip]),
         "gpx_predict_sweep": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp,
-                                        C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip, _dp, _dp]),
+                                        C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip, _dp, _dp, C.c_int]),
         "gpx_lml_grad_diag": (C.c_int, [vp, _dp]),
         "gpx_set_diag": (C.c_int, [vp, _dp, C.c_int]),
         "gpx_sgp_bound": (C.c_int, [vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp, C.c_int, _dp, C.c_int,
@@ -310,7 +310,7 @@ class Engine:
         self._check(self._lib.gpx_set_diag(self._ctx, _ptr(v), self.N), "gpx_set_diag")
 
     def predict_sweep(self, kind: int, ells, scales, noises, yres, Xnew, noiseless: bool, jitter: float,
-                      eps: Optional[np.ndarray], want_var: bool = False, pred_diag=None):
+                      eps: Optional[np.ndarray], want_var: bool = False, pred_diag=None, m_slice: int = 0):
         ells = _f64(ells)
         S = ells.shape[0]
         ells = _f64(ells, (S, n_ell(kind, self.d)))
@@ -332,7 +332,8 @@ class Engine:
         self._check(self._lib.gpx_predict_sweep(
             self._ctx, kind, S, _ptr(ells), _ptr(scales), _ptr(noises), _ptr(yres), rows, _ptr(Xnew), M,
             int(bool(noiseless)), float(jitter), _ptr(eps_c), n, _ptr(means),
-            _ptr(samples) if n else None, infos.ctypes.data_as(_ip), _ptr(vars_), _ptr(pd)), "gpx_predict_sweep")
+            _ptr(samples) if n else None, infos.ctypes.data_as(_ip), _ptr(vars_), _ptr(pd), int(m_slice)),
+            "gpx_predict_sweep")
         if want_var:
             return means, samples, infos, vars_
         return means, samples, infos
@@ -492,7 +493,7 @@ def get_sweep_engines(device: Optional[int] = None, n: Optional[int] = None) -> 
 
 
 def concurrent_sweep(engines: list, X, kind: int, ells, scales, noises, yres, Xnew, noiseless: bool, jitter: float,
-                     eps):
+                     eps, m_slice: int = 0):
     """gpx_predict_sweep over S samples, split in contiguous blocks across `engines` (one host
     thread per context; ctypes releases the GIL).  Same results as a single sweep, sample by sample."""
     import threading
@@ -504,7 +505,8 @@ def concurrent_sweep(engines: list, X, kind: int, ells, scales, noises, yres, Xn
         n = 1  # the batched sweep already fills the GPU from one context (measured: extra contexts do not help)
     if n == 1:
         engines[0].set_train(X)
-        return engines[0].predict_sweep(kind, ells, scales, noises, yres, Xnew, noiseless, jitter, eps)
+        return engines[0].predict_sweep(kind, ells, scales, noises, yres, Xnew, noiseless, jitter, eps,
+                                        m_slice=m_slice)
     yres = np.asarray(yres, dtype=np.float64)
     bounds = [(S * i) // n for i in range(n + 1)]
     out: list = [None] * n
@@ -517,7 +519,8 @@ def concurrent_sweep(engines: list, X, kind: int, ells, scales, noises, yres, Xn
             e.set_train(X)
             yr = yres if yres.ndim == 1 else yres[lo:hi]
             out[i] = e.predict_sweep(kind, ells[lo:hi], np.asarray(scales)[lo:hi], np.asarray(noises)[lo:hi], yr, Xnew,
-                                     noiseless, jitter, None if eps is None else np.asarray(eps)[lo:hi])
+                                     noiseless, jitter, None if eps is None else np.asarray(eps)[lo:hi],
+                                     m_slice=m_slice)
         except Exception as ex:  # surface worker failures in the caller
             err.append(ex)
 

@@ -56,7 +56,7 @@ int nominal_batch(const gpx_ctx* ctx) {
 // sweep's results do not depend on the batch size actually used); otherwise for a single sample.
 CovSplit cov_split(const gpx_ctx* ctx, bool sweep = false) {
   const int nt = (ctx->N + TILE - 1) / TILE;
-  const int mt = ctx->Mp / TILE;
+  const int mt = ctx->cMp / TILE;
   const int ktot = nt * TILE;
   const int lower_tiles = mt * (mt + 1) / 2 * (sweep ? nominal_batch(ctx) : 1);
   int splits = (512 + lower_tiles - 1) / lower_tiles;
@@ -98,9 +98,9 @@ BatchPlan make_plan(gpx_ctx* ctx, int B, int n_pad, bool fused, bool sweep = fal
   p.k_bs = (int64_t)(ctx->Np + (fused ? ctx->Mp : 0)) * ctx->ldk;
   p.linv_bs = (int64_t)(ctx->Np / TILE) * TILE * TILE;
   p.mean_bs = ctx->Mp;
-  p.cov_bs = (int64_t)ctx->Mp * ctx->ldc;
-  p.covlinv_bs = (int64_t)(ctx->Mp / TILE) * TILE * TILE;
-  p.splitk_bs = (ctx->Mp > 0) ? (int64_t)cov_split(ctx, sweep).splits * p.cov_bs : 0;
+  p.cov_bs = (int64_t)ctx->cMp * ctx->ldc;
+  p.covlinv_bs = (int64_t)(ctx->cMp / TILE) * TILE * TILE;
+  p.splitk_bs = (ctx->cMp > 0) ? (int64_t)cov_split(ctx, sweep).splits * p.cov_bs : 0;
   p.eps_bs = (int64_t)n_pad * ctx->ldc;
   p.info_train = sc_int(ctx) + SI_TRAIN;
   p.info_cov = sc_int(ctx) + SI_COV;
@@ -193,8 +193,10 @@ int set_xnew(gpx_ctx* ctx, const double* Xnew, int M) {
   if (M < 1) return bad_arg(ctx, "M must be >= 1");
   ctx->M = M;
   ctx->Mp = round_up(M, TILE);
+  ctx->cM = M;
+  ctx->cMp = ctx->Mp;
   ctx->ldv = pick_ld(ctx->Np);
-  ctx->ldc = pick_ld(ctx->Mp);
+  ctx->ldc = pick_ld(ctx->cMp);
   GPX_TRY(ensure(ctx, ctx->Xnew, (size_t)ctx->T * M * ctx->d * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->mean, (size_t)ctx->Mp * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->var, (size_t)ctx->Mp * sizeof(double)));
@@ -203,11 +205,14 @@ int set_xnew(gpx_ctx* ctx, const double* Xnew, int M) {
   return 0;
 }
 
-// k_pX -> Vt = k_pX L^-T, mean = Vt w, var, and (optionally) cov = k_pp - Vt Vt^T.
-int dev_posterior(gpx_ctx* ctx, bool want_cov, const BatchPlan& bp) {
+// k_pX -> Vt = k_pX L^-T, mean = Vt w, var (all M test points; skipped when !want_mean), and (optionally)
+// cov = k_pp - Vt Vt^T for the covariance block of mc test points starting at m0 (default: all of them).
+int dev_posterior(gpx_ctx* ctx, bool want_cov, const BatchPlan& bp, bool want_mean = true, int m0 = 0, int mc = -1) {
   const int N = ctx->N, M = ctx->M, Mp = ctx->Mp, B = bp.B;
   const int nt = (N + TILE - 1) / TILE;
   const int mt = Mp / TILE;
+  if (mc < 0) mc = ctx->cM;
+  const int cMp = ctx->cMp, cmt = cMp / TILE;
   const double* K = ctx->K.d();
   KernelParams kp = ctx->theta;
   double* Vt;
@@ -227,23 +232,26 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov, const BatchPlan& bp) {
                                bp.th, 0));
     GPX_TRY(trsm_right_lt(ctx, Vt, ldv, mt, K, ctx->ldk, ctx->Linv.d(), nt, 0));
   }
-  GPX_TRY(ensure(ctx, ctx->mean, (size_t)B * bp.mean_bs * sizeof(double)));
-  GPX_TRY(ensure(ctx, ctx->var, (size_t)B * bp.mean_bs * sizeof(double)));
-  const double kd = kdiag_value(kp) + ctx->noise_p + ctx->jitter;
-  GPX_TRY(launch_rowdot(ctx, Vt, ldv, M, N, K + (int64_t)N * ctx->ldk, kd, ctx->mean.d(), ctx->var.d(), 0, B, v_bs,
-                        bp.k_bs, bp.mean_bs, bp.th, bp.pred_diag, bp.pd_bs));
+  if (want_mean) {
+    GPX_TRY(ensure(ctx, ctx->mean, (size_t)B * bp.mean_bs * sizeof(double)));
+    GPX_TRY(ensure(ctx, ctx->var, (size_t)B * bp.mean_bs * sizeof(double)));
+    const double kd = kdiag_value(kp) + ctx->noise_p + ctx->jitter;
+    GPX_TRY(launch_rowdot(ctx, Vt, ldv, M, N, K + (int64_t)N * ctx->ldk, kd, ctx->mean.d(), ctx->var.d(), 0, B, v_bs,
+                          bp.k_bs, bp.mean_bs, bp.th, bp.pred_diag, bp.pd_bs));
+  }
   ctx->cov_factored = false;
   if (want_cov) {
     const CovSplit cs = cov_split(ctx, bp.sweep);
     const int ktot = nt * TILE;
     const int64_t ldp = ctx->ldc;
-    const int64_t stride = (int64_t)Mp * ldp;
+    const int64_t stride = (int64_t)cMp * ldp;
+    const double* Vs = Vt + (int64_t)m0 * ldv; // rows of this covariance block
     GPX_TRY(ensure(ctx, ctx->Cov, (size_t)B * bp.cov_bs * sizeof(double)));
     GPX_TRY(ensure(ctx, ctx->SplitK, (size_t)B * cs.splits * stride * sizeof(double)));
     GemmArgs g{};
-    g.A = Vt;
+    g.A = Vs;
     g.lda = ldv;
-    g.B = Vt;
+    g.B = Vs;
     g.ldb = ldv;
     g.C = ctx->SplitK.d();
     g.ldc = ldp;
@@ -257,12 +265,13 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov, const BatchPlan& bp) {
     g.a_bs = v_bs;
     g.b_bs = v_bs;
     g.c_bs = bp.splitk_bs;
-    const double m = (double)Mp;
-    GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, cs.splits, GPX_PROF_GEMM_OTHER, m * (m + 1.0) * ktot));
-    GPX_TRY(launch_cov_finalize(ctx, kp, ctx->Xnew.d(), M, Mp, ctx->SplitK.d(), cs.splits, stride, ldp,
-                                ctx->noise_p + ctx->jitter, ctx->Cov.d(), ctx->ldc, B, bp.splitk_bs, bp.cov_bs,
-                                bp.th, ts_new(ctx), bp.pred_diag, bp.pd_bs));
+    const double m = (double)cMp;
+    GPX_TRY(launch_gemm_nt(ctx, g, cmt, cmt, cs.splits, GPX_PROF_GEMM_OTHER, m * (m + 1.0) * ktot));
+    GPX_TRY(launch_cov_finalize(ctx, kp, ctx->Xnew.d() + (int64_t)m0 * ctx->d, mc, cMp, ctx->SplitK.d(), cs.splits,
+                                stride, ldp, ctx->noise_p + ctx->jitter, ctx->Cov.d(), ctx->ldc, B, bp.splitk_bs,
+                                bp.cov_bs, bp.th, ts_new(ctx), bp.pred_diag ? bp.pred_diag + m0 : nullptr, bp.pd_bs));
   }
+  (void)mt;
   ctx->have_post = want_cov && B == 1;
   return 0;
 }
@@ -271,11 +280,14 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov) {
 }
 
 // chol(cov) (once per posterior) and draws = mean + eps Lc^T; eps already on device, padded.
-int dev_draw(gpx_ctx* ctx, int n_pad, int n, const BatchPlan& bp) {
-  const int Mp = ctx->Mp, mt = Mp / TILE, B = bp.B;
+// m0 / mc: the covariance block the resident Cov belongs to (its mean starts at mean + m0).
+int dev_draw(gpx_ctx* ctx, int n_pad, int n, const BatchPlan& bp, int m0 = 0, int mc = -1) {
+  const int Mp = ctx->cMp, mt = Mp / TILE, B = bp.B;
+  if (mc < 0) mc = ctx->cM;
   if (!ctx->cov_factored) {
     GPX_TRY(ensure(ctx, ctx->CovLinv, (size_t)B * bp.covlinv_bs * sizeof(double)));
-    GPX_HIP(ctx, hipMemsetAsync(bp.info_cov, 0, (size_t)B * sizeof(int), ctx->stream));
+    // first block resets the pivot report; later blocks keep the first failure (potf2 only writes a zero slot)
+    if (m0 == 0) GPX_HIP(ctx, hipMemsetAsync(bp.info_cov, 0, (size_t)B * sizeof(int), ctx->stream));
     GPX_TRY(potrf_lower(ctx, ctx->Cov.d(), ctx->ldc, Mp, 0, ctx->CovLinv.d(), bp.info_cov, B, bp.cov_bs,
                         bp.covlinv_bs));
     ctx->cov_factored = (B == 1);
@@ -297,7 +309,7 @@ int dev_draw(gpx_ctx* ctx, int n_pad, int n, const BatchPlan& bp) {
   g.c_bs = bp.eps_bs;
   GPX_TRY(launch_gemm_nt(ctx, g, n_pad / TILE, mt, 0, GPX_PROF_GEMM_OTHER,
                          2.0 * n_pad * (double)Mp * Mp / 2.0));
-  GPX_TRY(launch_add_mean(ctx, ctx->draws.d(), ctx->ldc, n, ctx->M, ctx->mean.d(), B, bp.eps_bs, bp.mean_bs));
+  GPX_TRY(launch_add_mean(ctx, ctx->draws.d(), ctx->ldc, n, mc, ctx->mean.d() + m0, B, bp.eps_bs, bp.mean_bs));
   return 0;
 }
 int dev_draw(gpx_ctx* ctx, int n_pad, int n) { return dev_draw(ctx, n_pad, n, make_plan(ctx, 1, n_pad, ctx->fused_vt)); }
@@ -323,38 +335,42 @@ int upload_eps(gpx_ctx* ctx, const double* eps, int n, int* n_pad_out) {
 // Each sample's arithmetic is the single-sample arithmetic (same kernels, same tile shapes, same
 // accumulation order): results do not depend on B.
 
-// eps (S, n, M) contiguous -> per-sample padded slabs dst[b][n_pad][ldc]
+// eps (S, n, Mtot) contiguous -> per-sample padded slabs dst[b][n_pad][ldc] of the covariance block
+// [m0, m0 + mc) of the test points
 __global__ __launch_bounds__(256) void eps_gather_kernel(double* __restrict__ dst, int64_t ldc,
                                                          int64_t eps_bs, const double* __restrict__ src,
-                                                         int n, int M) {
+                                                         int n, int Mtot, int m0, int mc) {
   const int a = blockIdx.x * 256 + threadIdx.x;
   const int r = blockIdx.y, b = blockIdx.z;
-  if (a < M) dst[(int64_t)b * eps_bs + (int64_t)r * ldc + a] = src[((int64_t)b * n + r) * M + a];
+  if (a < mc) dst[(int64_t)b * eps_bs + (int64_t)r * ldc + a] = src[((int64_t)b * n + r) * Mtot + m0 + a];
 }
 
-// per-batch results -> the sweep's contiguous outputs: means (b, M), samples (b, n, M), infos (b, 2)
-__global__ __launch_bounds__(256) void sweep_store_kernel(const double* __restrict__ mean, int64_t mean_bs,
-                                                          const double* __restrict__ draws, int64_t ldc,
-                                                          int64_t eps_bs, int n, int M,
+// per-batch means / variances / pivot reports -> the sweep's contiguous outputs (b, M), (b, 2)
+__global__ __launch_bounds__(256) void sweep_store_kernel(const double* __restrict__ mean, int64_t mean_bs, int M,
                                                           const int* __restrict__ info_train,
-                                                          const int* __restrict__ info_cov,
-                                                          double* __restrict__ means, double* __restrict__ samples,
-                                                          int* __restrict__ infos,
+                                                          const int* __restrict__ info_cov, int has_cov,
+                                                          double* __restrict__ means, int* __restrict__ infos,
                                                           const double* __restrict__ var,
                                                           double* __restrict__ vars) {
   const int a = blockIdx.x * 256 + threadIdx.x;
-  const int r = blockIdx.y, b = blockIdx.z;
+  const int b = blockIdx.z;
   if (a < M) {
-    if (r == 0) {
-      means[(int64_t)b * M + a] = mean[(int64_t)b * mean_bs + a];
-      if (vars != nullptr) vars[(int64_t)b * M + a] = var[(int64_t)b * mean_bs + a];
-    } else
-      samples[((int64_t)b * n + (r - 1)) * M + a] = draws[(int64_t)b * eps_bs + (int64_t)(r - 1) * ldc + a];
+    means[(int64_t)b * M + a] = mean[(int64_t)b * mean_bs + a];
+    if (vars != nullptr) vars[(int64_t)b * M + a] = var[(int64_t)b * mean_bs + a];
   }
-  if (a == 0 && r == 0 && infos != nullptr) {
+  if (a == 0 && infos != nullptr) {
     infos[2 * b] = info_train[b];
-    infos[2 * b + 1] = (n > 0) ? info_cov[b] : 0;
+    infos[2 * b + 1] = has_cov ? info_cov[b] : 0;
   }
+}
+
+// draws of one covariance block -> samples (b, n, Mtot)[.., m0 : m0 + mc]
+__global__ __launch_bounds__(256) void draws_store_kernel(const double* __restrict__ draws, int64_t ldc,
+                                                          int64_t eps_bs, int n, int Mtot, int m0, int mc,
+                                                          double* __restrict__ samples) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y, b = blockIdx.z;
+  if (a < mc) samples[((int64_t)b * n + r) * Mtot + m0 + a] = draws[(int64_t)b * eps_bs + (int64_t)r * ldc + a];
 }
 
 struct SweepIO {
@@ -369,6 +385,7 @@ struct SweepIO {
   int* dInfos = nullptr;
   double* dVars = nullptr; // device (S, M) posterior variances (diag of cov) or nullptr
   const double* dPredDiag = nullptr; // device (S, M): per-sample variances added to diag(cov_s) / var_s
+  int m_slice = 0; // > 0: covariances / draws per block of m_slice test points (predict_in_batches semantics)
 };
 
 // Samples per launch: enough that the small-N pipeline fills the chip, bounded by memory.
@@ -432,6 +449,16 @@ int sweep_core(gpx_ctx* ctx, const SweepIO& io) {
   const int N = ctx->N, M = ctx->M, n = io.n, S = io.S;
   const int n_pad = round_up(n > 0 ? n : 1, TILE);
   ctx->jitter = io.jitter;
+  // covariance blocks: all M test points at once, or slices of m_slice points that share ONE factorisation
+  // per sample (ExactGP.predict_in_batches, gp.py:325-349, re-factorises K for every slice)
+  const int Ms = (io.m_slice > 0 && io.m_slice < M) ? io.m_slice : M;
+  const int J = (M + Ms - 1) / Ms;
+  ctx->cM = Ms;
+  ctx->cMp = round_up(Ms, TILE);
+  ctx->ldc = pick_ld(ctx->cMp);
+  // ride-along rows must cover the (padded) last block: rows beyond M are zero
+  ctx->Mp = round_up(M, TILE);
+  if ((J - 1) * Ms + ctx->cMp > ctx->Mp) ctx->Mp = round_up((J - 1) * Ms + ctx->cMp, TILE);
   GPX_TRY(fill_theta_table(ctx, io));
   const int B = pick_batch(ctx, S, n_pad, n > 0);
   BatchPlan bp = make_plan(ctx, B, n_pad, true, true);
@@ -464,22 +491,32 @@ int sweep_core(gpx_ctx* ctx, const SweepIO& io) {
     }
     bp.pred_diag = io.dPredDiag ? io.dPredDiag + (int64_t)s0 * M : nullptr;
     bp.pd_bs = M;
-    if (n > 0 && io.dEps != nullptr) {
-      dim3 grid((M + 255) / 256, n, b);
-      eps_gather_kernel<<<grid, 256, 0, ctx->stream>>>(ctx->eps.d(), ctx->ldc, bp.eps_bs,
-                                                        io.dEps + (int64_t)s0 * n * M, n, M);
-      GPX_HIP(ctx, hipGetLastError());
-    }
     GPX_TRY(dev_factor(ctx, true, bp, false));
-    GPX_TRY(dev_posterior(ctx, n > 0, bp));
-    if (n > 0) GPX_TRY(dev_draw(ctx, n_pad, n, bp));
+    GPX_TRY(dev_posterior(ctx, false, bp)); // means / variances of all M test points
+    for (int j = 0; j < J && n > 0; ++j) {
+      const int m0 = j * Ms, mc = (M - m0 < Ms) ? M - m0 : Ms;
+      if (io.dEps != nullptr) {
+        if (mc < Ms) // ragged last block: clear the columns the previous block filled
+          GPX_HIP(ctx, hipMemsetAsync(ctx->eps.p, 0, (size_t)b * bp.eps_bs * sizeof(double), ctx->stream));
+        dim3 grid((mc + 255) / 256, n, b);
+        eps_gather_kernel<<<grid, 256, 0, ctx->stream>>>(ctx->eps.d(), ctx->ldc, bp.eps_bs,
+                                                          io.dEps + (int64_t)s0 * n * M, n, M, m0, mc);
+        GPX_HIP(ctx, hipGetLastError());
+      }
+      GPX_TRY(dev_posterior(ctx, true, bp, false, m0, mc));
+      GPX_TRY(dev_draw(ctx, n_pad, n, bp, m0, mc));
+      if (io.dSamples != nullptr) {
+        dim3 grid((mc + 255) / 256, n, b);
+        draws_store_kernel<<<grid, 256, 0, ctx->stream>>>(ctx->draws.d(), ctx->ldc, bp.eps_bs, n, M, m0, mc,
+                                                           io.dSamples + (int64_t)s0 * n * M);
+        GPX_HIP(ctx, hipGetLastError());
+      }
+    }
     if (io.dMeans != nullptr) {
-      dim3 grid((M + 255) / 256, n + 1, b);
+      dim3 grid((M + 255) / 256, 1, b);
       sweep_store_kernel<<<grid, 256, 0, ctx->stream>>>(
-          ctx->mean.d(), bp.mean_bs, ctx->draws.d(), ctx->ldc, bp.eps_bs, n, M, bp.info_train, bp.info_cov,
-          io.dMeans + (int64_t)s0 * M, io.dSamples ? io.dSamples + (int64_t)s0 * n * M : nullptr,
-          io.dInfos ? io.dInfos + 2 * s0 : nullptr, ctx->var.d(),
-          io.dVars ? io.dVars + (int64_t)s0 * M : nullptr);
+          ctx->mean.d(), bp.mean_bs, M, bp.info_train, bp.info_cov, n > 0 ? 1 : 0, io.dMeans + (int64_t)s0 * M,
+          io.dInfos ? io.dInfos + 2 * s0 : nullptr, ctx->var.d(), io.dVars ? io.dVars + (int64_t)s0 * M : nullptr);
       GPX_HIP(ctx, hipGetLastError());
     }
     ctx->sweep_batches += 1;
@@ -858,7 +895,7 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
                       const double* noises, const double* yres, int yres_rows,
                       const double* Xnew, int M, int noiseless, double jitter,
                       const double* eps, int n, double* means, double* samples, int* infos, double* vars,
-                      const double* pred_diag) {
+                      const double* pred_diag, int m_slice) {
   if (!ctx || ctx->device < 0) return -1;
   if (ctx->N < 1) return bad_arg(ctx, "gpx_set_train must be called first");
   if (S < 0 || n < 0) return bad_arg(ctx, "negative count");
@@ -938,6 +975,7 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   io.dInfos = dInfos.i();
   io.dVars = vars ? dVars.d() : nullptr;
   io.dPredDiag = pred_diag ? dPred.d() : nullptr;
+  io.m_slice = m_slice;
   SWEEP_TRY(sweep_core(ctx, io));
   // results come back through the page-locked buffer: [means | samples | vars | infos]
   const size_t infos_b = (size_t)2 * S * sizeof(int);
@@ -958,7 +996,7 @@ int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const d
   for (int s = 0; s < S; ++s) {
     int it = hinfos[2 * s], ic = hinfos[2 * s + 1];
     if (it > N) it = 0;
-    if (ic > M) ic = 0;
+    if (ic > ctx->cM) ic = 0;
     const int code = it != 0 ? it : (ic != 0 ? -ic : 0);
     if (infos) infos[s] = code;
     if (it != 0)

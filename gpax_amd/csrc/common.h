@@ -167,7 +167,9 @@ struct gpx_ctx {
   bool fused_vt = false; // rows Np.. of K hold k_pX L^-T from a fused factorisation
 
   // ---- posterior state ------------------------------------------------------------------
-  int M = 0, Mp = 0;
+  int M = 0, Mp = 0;   // test points riding along in the factorisation (Mp: padded rows)
+  int cM = 0, cMp = 0; // covariance block: cov / chol / draws are formed for cM test points at a time
+                       // (= M unless a sweep slices X_new, predict_in_batches)
   int64_t ldv = 0, ldc = 0;
   gpx::DevBuf Xnew;   // T x M x d
   gpx::DevBuf Vt;     // Mp x ldv : k_pX -> k_pX L^-T

@@ -433,7 +433,13 @@ class ExactGP:
 
     def predict_in_batches(self, rng_key, X_new, batch_size=100, samples=None, n=1, filter_nans=False,
                            predict_fn=None, noiseless=False, device=None, **kwargs):
-        """predict() over slices of X_new (gp.py:325-349); same rng_key for every slice."""
+        """predict() over slices of X_new (gp.py:325-349); same rng_key for every slice.
+        With the default predict the slices become covariance blocks of ONE sweep: K(theta) is factored once per
+        sample instead of once per sample and slice (identical values: every slice's posterior and draws are what
+        predict() on that slice alone returns)."""
+        if predict_fn is None and type(self).predict is ExactGP.predict:
+            return self.predict(rng_key, X_new, samples, n, filter_nans, noiseless, device,
+                                _m_slice=int(batch_size), **kwargs)
         y_pred, y_sampled = self._predict_in_batches(rng_key, X_new, batch_size, 0, samples, n, filter_nans,
                                                      predict_fn, noiseless, device, **kwargs)
         return np.concatenate(y_pred, 0), np.concatenate(y_sampled, -1)
@@ -452,7 +458,8 @@ class ExactGP:
         if isinstance(device, int):
             self._device = device
         jitter = float(kwargs.get("jitter", 1e-6))
-        ells, scales, noises, yres, eps, mean_shift = self._sweep_inputs(rng_key, X_new, samples, n)
+        m_slice = int(kwargs.pop("_m_slice", 0))  # predict_in_batches: covariance blocks of this many test points
+        ells, scales, noises, yres, eps, mean_shift = self._sweep_inputs(rng_key, X_new, samples, n, m_slice)
         # several samples in flight per GPU: independent libgpx contexts on the same device
         engines = _lib.get_sweep_engines(self._device)
         for e in engines[1:]:
@@ -460,10 +467,10 @@ class ExactGP:
         if len(engines) > 1:
             engines[0]._train_owner = None
         means, y_sampled, infos = _lib.concurrent_sweep(engines, self.X_train, self._kind, ells, scales, noises, yres,
-                                                        X_new, noiseless, jitter, eps)
+                                                        X_new, noiseless, jitter, eps, m_slice=m_slice)
         return self._sweep_outputs(means, y_sampled, mean_shift, filter_nans)
 
-    def _sweep_inputs(self, rng_key, X_new, samples, n):
+    def _sweep_inputs(self, rng_key, X_new, samples, n, m_slice: int = 0):
         """Per-sample tables of the predictive sweep: packed lengthscales (S, n_ell), scales, noises, the
         residual(s) y - m(X), the standard normals of the draws and the mean-function shift at X_new."""
         S = len(next(iter(samples.values())))
@@ -482,7 +489,11 @@ class ExactGP:
             mean_shift = np.stack([self._mean(X_new, p) for p in per])
         else:
             yres = self.y_train
-        eps = rng_from_key(rng_key).standard_normal((S, n, M))
+        if 0 < m_slice < M:  # the same key for every slice, as predict_in_batches passes it (gp.py:344-347)
+            eps = np.concatenate([rng_from_key(rng_key).standard_normal((S, n, min(m_slice, M - m0)))
+                                  for m0 in range(0, M, m_slice)], axis=-1)
+        else:
+            eps = rng_from_key(rng_key).standard_normal((S, n, M))
         return ells, scales, noises, yres, eps, mean_shift
 
     @staticmethod

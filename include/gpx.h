@@ -148,13 +148,17 @@ int gpx_mvn_draw(gpx_ctx* ctx, const double* eps, int n, double* out, int* info)
  * failed).  Rows whose info != 0 are NaN-filled.  eps may be NULL when n == 0.
  * vars (S*M) or NULL: diag(cov_s), for callers that draw from the marginals only
  * (MeasuredNoiseGP._predict, gpax/models/mngp.py:170-181).
+ * m_slice > 0: ExactGP.predict_in_batches (gpax/models/gp.py:325-349) — the test points are treated in blocks
+ * of m_slice: cov / chol / draws per block (draws of different blocks are independent, as when predict is
+ * called per slice), but K(theta_s) is factored ONCE per sample, all blocks' k_pX rows riding along; eps and
+ * samples keep the (S, n, M) layout.  0: one block of M points.
  * pred_diag (S*M) or NULL: per-sample variances added to the diagonal of cov_s before the draw
  * (the predicted noise variance of VarNoiseGP.get_mvn_posterior, gpax/models/hskgp.py:188-204). */
 int gpx_predict_sweep(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales,
                       const double* noises, const double* yres, int yres_rows,
                       const double* Xnew, int M, int noiseless, double jitter,
                       const double* eps, int n, double* means, double* samples, int* infos, double* vars,
-                      const double* pred_diag);
+                      const double* pred_diag, int m_slice);
 
 /* ---- variational sparse GP: viSparseGP, gpax/models/sparse_gp.py ----------------------------
  * gpx_sgp_bound: the per-SVI-step objective of viSparseGP.model (sparse_gp.py:62-114): VFE bound =

@@ -162,7 +162,23 @@ class OracleEngine:
         return out, int(np.isnan(out).any())
 
     def predict_sweep(self, kind, ells, scales, noises, yres, Xnew, noiseless, jitter, eps, want_var=False,
-                      pred_diag=None):
+                      pred_diag=None, m_slice=0):
+        Xnew = np.asarray(Xnew, dtype=np.float64)
+        Mtot = Xnew.shape[-2]
+        if 0 < m_slice < Mtot:  # the reference's predict_in_batches: an independent predict per slice of X_new
+            outs = []
+            for m0 in range(0, Mtot, m_slice):
+                sl = slice(m0, min(m0 + m_slice, Mtot))
+                outs.append(self.predict_sweep(kind, ells, scales, noises, yres, Xnew[..., sl, :], noiseless, jitter,
+                                               None if eps is None else np.asarray(eps)[..., sl], True,
+                                               None if pred_diag is None else np.asarray(pred_diag)[:, sl]))
+            means = np.concatenate([o[0] for o in outs], axis=-1)
+            samples = np.concatenate([o[1] for o in outs], axis=-1)
+            infos = np.zeros(means.shape[0], dtype=np.int32)
+            for o in outs:
+                infos = np.where(infos != 0, infos, o[2])
+            vars_ = np.concatenate([o[3] for o in outs], axis=-1)
+            return (means, samples, infos, vars_) if want_var else (means, samples, infos)
         ells = np.asarray(ells, dtype=np.float64)
         S = ells.shape[0]
         Xnew = np.asarray(Xnew, dtype=np.float64)

@@ -209,3 +209,34 @@ def test_fit_batch_equals_single_fit_steps(engine, kind, name, N, d):
         lml2, info2, g2, a2 = engine.fit_batch(kind, ells, scales, noises, 1e-6, yr, want_grad=False)
         assert g2 is None and a2 is None
         np.testing.assert_array_equal(lml2[[0, 1, 2, 4]], lml[[0, 1, 2, 4]])
+
+
+@pytest.mark.parametrize("kind,name", KINDS)
+@pytest.mark.parametrize("M,ms", [(300, 100), (300, 128), (257, 100), (90, 200)])
+def test_sliced_sweep_equals_slice_by_slice_sweeps(engine, kind, name, M, ms):
+    # predict_in_batches semantics inside one sweep: covariance blocks of `ms` test points share ONE factorisation
+    # per sample; every block must equal the sweep run on that slice of X_new alone
+    N, d, S, n = 260, 2, 7, 2
+    X, y, Xn, params = ref.synthetic_problem(N, d, M, seed=M + ms)
+    th = ref.synthetic_theta_samples(S, d, seed=3)
+    rng = np.random.default_rng(4)
+    eps = rng.standard_normal((S, n, M))
+    yres = y[None, :] + 0.01 * rng.standard_normal((S, N))
+    engine.set_train(X)
+    means, draws, infos, vars_ = engine.predict_sweep(kind, th["k_length"], th["k_scale"], th["noise"], yres, Xn, False,
+                                                      1e-6, eps, want_var=True, m_slice=ms)
+    assert np.all(infos == 0) and means.shape == (S, M) and draws.shape == (S, n, M)
+    for m0 in range(0, M, ms):
+        sl = slice(m0, min(m0 + ms, M))
+        m1, d1, i1, v1 = engine.predict_sweep(kind, th["k_length"], th["k_scale"], th["noise"], yres, Xn[sl], False, 1e-6,
+                                              np.ascontiguousarray(eps[:, :, sl]), want_var=True)
+        np.testing.assert_array_equal(means[:, sl], m1)
+        np.testing.assert_array_equal(vars_[:, sl], v1)
+        # the block's covariance tiles start at a different row of the ride-along matrix: same arithmetic per element
+        np.testing.assert_array_equal(draws[:, :, sl], d1)
+    s = 2
+    q = {"k_length": th["k_length"][s], "k_scale": th["k_scale"][s], "noise": th["noise"][s]}
+    sl = slice(0, min(ms, M))
+    m_ref, c_ref = ref.get_mvn_posterior(X, yres[s], Xn[sl], q, False, kernel=name, jitter=1e-6, route="inv")
+    assert relerr(means[s, sl], m_ref) < 1e-8
+    assert relerr(draws[s][:, sl], ref.mvn_sample(m_ref, c_ref, eps[s][:, sl])) < 1e-6

@@ -289,3 +289,25 @@ def test_periodic_kernel_model_surface():
     assert mean.shape == (7,) and np.all(var > 0)
     with pytest.raises(NotImplementedError):
         viSparseGP(1, "Periodic")
+
+
+def test_predict_in_batches_equals_slice_by_slice_predict():
+    # gp.py:325-349: predict per slice of X_new with the SAME key; the default path runs them as covariance blocks of
+    # one sweep (one factorisation per sample) and must return exactly what the slice-by-slice loop returns
+    X, y, Xn, p = ref.synthetic_problem(40, 2, 23, seed=3)
+    rng = np.random.default_rng(0)
+    samples = {"k_length": np.exp(0.2 * rng.standard_normal((6, 2))), "k_scale": np.exp(0.2 * rng.standard_normal(6)),
+               "noise": 0.1 * np.exp(0.2 * rng.standard_normal(6))}
+    m = ExactGP(2, "Matern")
+    m.X_train, m.y_train = m._set_data(X, y)
+    key = get_keys()[1]
+    ym, ys = m.predict_in_batches(key, Xn, batch_size=10, samples=samples, n=3)
+    assert ym.shape == (23,) and ys.shape == (6, 3, 23)
+    parts = [m.predict(key, Xn[i:i + 10], samples, n=3) for i in range(0, 23, 10)]
+    np.testing.assert_allclose(ym, np.concatenate([q[0] for q in parts]), rtol=1e-12)
+    np.testing.assert_allclose(ys, np.concatenate([q[1] for q in parts], axis=-1), rtol=1e-12)
+    # a user-supplied predict_fn still goes slice by slice
+    calls = []
+    fn = lambda xi: (calls.append(len(xi)) or m.predict(key, xi, samples, n=1))
+    m.predict_in_batches(key, Xn, batch_size=10, samples=samples, predict_fn=fn)
+    assert calls == [10, 10, 3]
