@@ -80,6 +80,20 @@ def cpu_baseline(N, d, M, kernel, budget_s=25.0):
     dti = time.perf_counter() - t0
     inv = {"value": 1.0 / dti, "unit": f"posteriors/s at N={Ni}", "seconds": dti, "N": Ni,
            "route": "explicit inverse, as gpax/models/gp.py:271-273"}
+    # and the Cholesky route on ONE core (SURVEY.md 8d asks for both ends), at a size that stays within a few seconds
+    one = None
+    try:
+        from threadpoolctl import threadpool_limits
+        N1 = 2048
+        X1, y1, Xn1, p1 = ref.synthetic_problem(N1, d, M, seed=0)
+        with threadpool_limits(limits=1):
+            t0 = time.perf_counter()
+            ref.predict_one(X1, y1, Xn1, p1, eps, False, kernel=kernel, jitter=1e-6, route="chol")
+            dt1 = time.perf_counter() - t0
+        one = {"value": 1.0 / dt1, "unit": f"posteriors/s at N={N1}", "seconds": dt1, "N": N1, "cores": 1,
+               "all_cores_seconds_at_this_N": t_small}
+    except Exception:
+        pass
     return {
         "value": 1.0 / dt,
         "unit": f"posteriors/s at N={Ns}",
@@ -90,6 +104,7 @@ def cpu_baseline(N, d, M, kernel, budget_s=25.0):
         "seconds": dt,
         "N": Ns,
         "inv_route": inv,
+        "one_core": one,
     }
 
 
@@ -190,8 +205,8 @@ def main():
         stages = {}
         for name, st in [("gram", _lib.STAGE_GRAM), ("potrf", _lib.STAGE_POTRF), ("fit_step", _lib.STAGE_FITSTEP),
                          ("posterior", _lib.STAGE_POSTERIOR), ("predict", _lib.STAGE_PREDICT)]:
-            eng.time_stage(st, 1)
-            stages[name + "_ms"] = eng.time_stage(st, 2) / 2
+            eng.time_stage(st, 1)  # warm-up
+            stages[name + "_ms"] = float(np.median([eng.time_stage(st, 1) for _ in range(5)]))
         # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
         # (profiles/r01/traffic.json; FETCH_SIZE doubled per the gfx950 correction, MI355X_MICROARCH.md §HBM)
         traffic, traffic_note = None, None
