@@ -200,8 +200,15 @@ int set_xnew(gpx_ctx* ctx, const double* Xnew, int M) {
   GPX_TRY(ensure(ctx, ctx->Xnew, (size_t)ctx->T * M * ctx->d * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->mean, (size_t)ctx->Mp * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->var, (size_t)ctx->Mp * sizeof(double)));
-  GPX_HIP(ctx, hipMemcpyAsync(ctx->Xnew.d(), Xnew, (size_t)ctx->T * M * ctx->d * sizeof(double),
-                              hipMemcpyHostToDevice, ctx->stream));
+  const size_t xb = (size_t)ctx->T * M * ctx->d * sizeof(double);
+  if (xb > (64u << 10)) { // large X_new (predict_in_batches grids): through page-locked staging, see DESIGN.md 10
+    GPX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the previous use of the staging buffer has been consumed
+    GPX_HIP(ctx, ctx->pin_x.ensure(xb));
+    std::memcpy(ctx->pin_x.p, Xnew, xb);
+    GPX_HIP(ctx, hipMemcpyAsync(ctx->Xnew.d(), ctx->pin_x.p, xb, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    GPX_HIP(ctx, hipMemcpyAsync(ctx->Xnew.d(), Xnew, xb, hipMemcpyHostToDevice, ctx->stream));
+  }
   return 0;
 }
 
@@ -598,6 +605,7 @@ void gpx_destroy(gpx_ctx* ctx) {
     for (DevBuf* b : bufs) b->release();
     ctx->pin_in.release();
     ctx->pin_out.release();
+    ctx->pin_x.release();
     sgp_release(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

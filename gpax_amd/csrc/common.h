@@ -186,7 +186,7 @@ struct gpx_ctx {
 
   // ---- batched sweep state (gpx_predict_sweep / gpx_sweep_resident) -----------------------
   gpx::DevBuf st_eps, st_yres, st_means, st_samples, st_infos, st_vars, st_pred; // sweep I/O staging (grow-only)
-  gpx::PinBuf pin_in, pin_out;                                                   // page-locked host side of it
+  gpx::PinBuf pin_in, pin_out, pin_x;                                            // page-locked host side of it
   gpx::DevBuf thtab;   // S x ThetaDev
   gpx::DevBuf binfo;   // 2 x B ints (train / cov pivots of the batch in flight)
   gpx::DevBuf bscal;   // B x 32 doubles: lml pieces + gradient of every entry of a fit batch
