@@ -85,6 +85,7 @@ class _Lockstep:
 
 
 class ExactGP:
+
     """
     Gaussian process class
 
@@ -99,6 +100,8 @@ class ExactGP:
         noise_prior_dist: prior on the noise variance (default LogNormal(0, 1))
         lengthscale_prior_dist: prior on the lengthscales (default LogNormal(0, 1))
     """
+
+    _ride_along_bytes = 12e9  # device budget for the k_pX rows of one predict_in_batches sweep (per sample)
 
     def __init__(
         self,
@@ -438,8 +441,20 @@ class ExactGP:
         sample instead of once per sample and slice (identical values: every slice's posterior and draws are what
         predict() on that slice alone returns)."""
         if predict_fn is None and type(self).predict is ExactGP.predict:
-            return self.predict(rng_key, X_new, samples, n, filter_nans, noiseless, device,
-                                _m_slice=int(batch_size), **kwargs)
+            X_new = self._set_data(X_new)
+            bs = max(1, int(batch_size))
+            # all slices of one call ride along in the factorisation: (N + M) x N doubles per sample on the device.
+            # Very large grids go in groups of slices sized to ~12 GB of ride-along rows (same values either way).
+            rows_max = max(bs, int(self._ride_along_bytes / (8.0 * (self.X_train.shape[0] + 256))) // bs * bs)
+            if X_new.shape[0] <= rows_max:
+                return self.predict(rng_key, X_new, samples, n, filter_nans, noiseless, device, _m_slice=bs, **kwargs)
+            outs = [self.predict(rng_key, X_new[i:i + rows_max], samples, n, False, noiseless, device, _m_slice=bs,
+                                 **kwargs) for i in range(0, X_new.shape[0], rows_max)]
+            y_pred = np.concatenate([o[0] for o in outs], 0)
+            y_sampled = np.concatenate([o[1] for o in outs], -1)
+            if filter_nans:
+                y_sampled = y_sampled[~np.isnan(y_sampled).any(axis=(1, 2))]
+            return y_pred, y_sampled
         y_pred, y_sampled = self._predict_in_batches(rng_key, X_new, batch_size, 0, samples, n, filter_nans,
                                                      predict_fn, noiseless, device, **kwargs)
         return np.concatenate(y_pred, 0), np.concatenate(y_sampled, -1)

@@ -311,3 +311,18 @@ def test_predict_in_batches_equals_slice_by_slice_predict():
     fn = lambda xi: (calls.append(len(xi)) or m.predict(key, xi, samples, n=1))
     m.predict_in_batches(key, Xn, batch_size=10, samples=samples, predict_fn=fn)
     assert calls == [10, 10, 3]
+
+
+def test_predict_in_batches_groups_of_slices_give_the_same_values(monkeypatch):
+    X, y, Xn, p = ref.synthetic_problem(30, 1, 47, seed=5)
+    rng = np.random.default_rng(1)
+    samples = {"k_length": np.exp(0.2 * rng.standard_normal((4, 1))), "k_scale": np.exp(0.2 * rng.standard_normal(4)),
+               "noise": 0.1 * np.exp(0.2 * rng.standard_normal(4))}
+    m = ExactGP(1, "RBF")
+    m.X_train, m.y_train = m._set_data(X, y)
+    key = get_keys()[1]
+    a = m.predict_in_batches(key, Xn, batch_size=10, samples=samples, n=2)
+    monkeypatch.setattr(ExactGP, "_ride_along_bytes", 8.0 * (30 + 256) * 20)  # two slices per sweep
+    b = m.predict_in_batches(key, Xn, batch_size=10, samples=samples, n=2)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
