@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--kernel", default="Matern")
     ap.add_argument("--inflight", type=int, default=3, help="theta samples in flight per GPU (libgpx contexts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
+                    "exercise the multi-rank control flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses GPU 0")
     ap.add_argument("--cpu-baseline-N", type=int, default=0, help="override the CPU sample size")
     return ap.parse_args()
 
@@ -119,8 +122,13 @@ def main():
         # torch first: its bundled HIP runtime must be the one libgpx binds to (same SONAME)
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
+        if a.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=a.dist_backend)
 
     from gpax_amd import _lib
     from oracle import cpu_ref as ref  # synthetic inputs only
@@ -185,7 +193,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
