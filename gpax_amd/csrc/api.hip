@@ -45,10 +45,13 @@ double kdiag_value(const KernelParams& kp) {
 struct CovSplit {
   int splits, kchunk;
 };
-// Samples per launch the sweep aims for at this N (before the memory / S caps): ~2 (16384 / Np)^2.
+// Samples per launch the sweep aims for at this N (before the memory / S caps), r = 16384 / Np:
+// 1 at N = 16384 (one sample's trailing update fills the chip), ~2 r^2 up to N ~ 4700 (7 at 8192: with 3 contexts
+// in flight B = 15 measured 2 % slower), ~4 r^2 below (60 at 4096, 226 at 2048, 256 = cap from ~1900 down;
+// N = 2048: 3 360 -> 3 520 posteriors/s, N = 4096 on one context: 916 -> 956 against 2 r^2).
 int nominal_batch(const gpx_ctx* ctx) {
   const double r = 16384.0 / (double)ctx->Np;
-  int B = (int)(2.0 * r * r);
+  int B = (int)((r >= 3.5 ? 4.0 : 2.0) * r * r);
   return B < 1 ? 1 : (B > 256 ? 256 : B);
 }
 
@@ -399,8 +402,7 @@ struct SweepIO {
 int pick_batch(gpx_ctx* ctx, int S, int n_pad, bool want_cov) {
   int forced = 0;
   if (const char* e = getenv("GPX_SWEEP_BATCH")) forced = atoi(e);
-  // auto: ~2 * (16384 / Np)^2 — 1 at N = 16384 (the trailing SYRK alone fills the chip), 7 at 8192,
-  // 30 at 4096, 256 (cap) from N ~ 1400 down; measured in tools/small_n_sweep.py / multi_ctx.py
+  // auto: nominal_batch() — measured in tools/small_n_sweep.py / multi_ctx.py / c4_sweep.py
   int B = forced > 0 ? forced : nominal_batch(ctx);
   if (B > 256) B = 256;
   const BatchPlan p = make_plan(ctx, 1, n_pad, true, true);

@@ -163,7 +163,7 @@ def test_batched_sweep_is_independent_of_batch_size(engine, kind, name, strided,
         outs[B] = engine.predict_sweep(kind, th["k_length"], th["k_scale"], th["noise"], yres, Xnew, False, 1e-6, eps)
         nb, ns, last = engine.sweep_stats()
         assert ns - before[1] == S
-        assert last == (int(B) if B != "0" else S)  # auto: 2 (16384/Np)^2 >> S at this size
+        assert last == (int(B) if B != "0" else S)  # auto: 4 (16384/Np)^2 >> S at this size
         assert nb - before[0] == -(-S // last)
     for B in ("4", "11", "0"):
         for a, b in zip(outs["1"], outs[B]):
