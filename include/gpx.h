@@ -135,7 +135,7 @@ int gpx_mvn_draw(gpx_ctx* ctx, const double* eps, int n, double* out, int* info)
 /* ---- predictive sweep: ExactGP.predict, gpax/models/gp.py:351-399 -------------------------
  * The jax.vmap over S posterior samples, run as a device-resident loop over batches of B
  * samples: the batch is a grid dimension of every launch (B is picked from N and free HBM,
- * B = 1 at N = 16384, 256 at N <= 1024; GPX_SWEEP_BATCH forces it), so at most B*N*N is
+ * B = 1 at N = 16384, 60 at 4096, 256 below N ~ 1900; GPX_SWEEP_BATCH forces it), so at most B*N*N is
  * materialised and small-N sweeps are not launch-bound.  Results do not depend on B.
  * For sample s:
  *   theta_s = (ells[s*d .. s*d+d), scales[s], noises[s]);
