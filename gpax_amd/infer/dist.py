@@ -101,9 +101,10 @@ class LogNormal(Distribution):
         self.loc, self.scale = float(loc), float(scale)
 
     def log_prob(self, x):
-        lx = np.log(x)
-        z = (lx - self.loc) / self.scale
-        return -0.5 * z * z - math.log(self.scale) - 0.5 * math.log(2 * math.pi) - lx
+        with np.errstate(divide="ignore", invalid="ignore"):  # x = exp(u) can underflow to 0 far out in the tails
+            lx = np.log(x)
+            z = (lx - self.loc) / self.scale
+            return -0.5 * z * z - math.log(self.scale) - 0.5 * math.log(2 * math.pi) - lx
 
     def grad_log_prob(self, x):
         with np.errstate(divide="ignore", invalid="ignore"):  # x = exp(u) can underflow to 0 far out in the tails
