@@ -25,6 +25,7 @@ from .. import _lib
 from ..infer import dist
 from ..infer.nuts import run_nuts
 from ..kernels.kernels import kernel_name
+from ..utils import threefry as _threefry
 from ..utils.utils import rng_from_key, split_in_batches
 
 kernel_fn_type = Callable[[np.ndarray, np.ndarray, Dict[str, np.ndarray], np.ndarray], np.ndarray]
@@ -504,11 +505,13 @@ class ExactGP:
             mean_shift = np.stack([self._mean(X_new, p) for p in per])
         else:
             yres = self.y_train
+        # a threefry key reproduces the reference's stream: split over the S samples, normal(key_s, (n, M)) each
+        draw = (lambda m: _threefry.predict_normals(rng_key, S, n, m)) if isinstance(rng_key, _threefry.ThreefryKey) \
+            else (lambda m: rng_from_key(rng_key).standard_normal((S, n, m)))
         if 0 < m_slice < M:  # the same key for every slice, as predict_in_batches passes it (gp.py:344-347)
-            eps = np.concatenate([rng_from_key(rng_key).standard_normal((S, n, min(m_slice, M - m0)))
-                                  for m0 in range(0, M, m_slice)], axis=-1)
+            eps = np.concatenate([draw(min(m_slice, M - m0)) for m0 in range(0, M, m_slice)], axis=-1)
         else:
-            eps = rng_from_key(rng_key).standard_normal((S, n, M))
+            eps = draw(M)
         return ells, scales, noises, yres, eps, mean_shift
 
     @staticmethod

@@ -26,6 +26,9 @@ def get_keys(seed: int = 0):
 def rng_from_key(rng_key) -> np.random.Generator:
     if isinstance(rng_key, np.random.Generator):
         return rng_key
+    if hasattr(rng_key, "k") and type(rng_key).__name__ == "ThreefryKey":
+        # host-side consumers other than predict's normals (NUTS, SVI, init): a Generator seeded from the key words
+        return np.random.default_rng([int(rng_key.k[0]), int(rng_key.k[1])])
     if rng_key is None:
         return np.random.default_rng()
     arr = np.asarray(rng_key)
