@@ -151,6 +151,12 @@ class ExactGP:
                                       "(or a callable returning one)")
         return pri
 
+    def model(self, X, y=None, **kwargs) -> None:
+        """The reference's NumPyro program (gp.py:137-164).  There is no NumPyro here: the same log joint —
+        priors of `_sites()` plus the MVN log-likelihood — is evaluated by `_log_joint` on the device."""
+        raise NotImplementedError("ExactGP.model is a NumPyro program in the reference; gpax_amd evaluates the same "
+                                  "log joint on the MI355X through _log_joint (host NUTS / SVI drive it)")
+
     def _sites(self):
         length_dist = self.lengthscale_prior_dist if self.lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
         noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
