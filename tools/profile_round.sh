@@ -2,6 +2,9 @@
 # Regenerate the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
 #   kernel-trace + stats of the default bench command, and separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*),
 #   summarised on the box (the rocpd sqlite databases stay in /tmp; only .md / .json summaries come back).
+# NOTE (round 1): a single pass with five TCC_* derived counters (TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+# TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum) on `bench.py --steps 1` did not finish within 10 minutes on this pool —
+# keep L2 counters out of this script, or collect one per pass on a much shorter workload with its own timeout.
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/prof
