@@ -101,14 +101,12 @@ class LogNormal(Distribution):
         self.loc, self.scale = float(loc), float(scale)
 
     def log_prob(self, x):
-        with np.errstate(divide="ignore", invalid="ignore"):  # x = exp(u) can underflow to 0 far out in the tails
-            lx = np.log(x)
-            z = (lx - self.loc) / self.scale
-            return -0.5 * z * z - math.log(self.scale) - 0.5 * math.log(2 * math.pi) - lx
+        lx = np.log(x)  # callers on the sampling path wrap this in np.errstate (x = exp(u) can underflow to 0)
+        z = (lx - self.loc) / self.scale
+        return -0.5 * z * z - math.log(self.scale) - 0.5 * math.log(2 * math.pi) - lx
 
     def grad_log_prob(self, x):
-        with np.errstate(divide="ignore", invalid="ignore"):  # x = exp(u) can underflow to 0 far out in the tails
-            return (-(np.log(x) - self.loc) / self.scale ** 2 - 1.0) / x
+        return (-(np.log(x) - self.loc) / self.scale ** 2 - 1.0) / x
 
     def sample(self, rng, shape=()):
         return np.exp(self.loc + self.scale * rng.standard_normal(shape))
