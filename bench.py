@@ -11,7 +11,9 @@ value = posteriors per second over all ranks (weak scaling: every rank runs K st
 theta samples; the sweep has no data-path collective, only the final gather of results).
 
     python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).
+N > 1: one rank per GPU under torch.distributed.run (RCCL).  The driver launches the ranks itself; when bench.py
+is started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) it re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` and relays the ranks' output.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -43,23 +45,42 @@ def parse():
                     "exercise the multi-rank control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses GPU 0")
     ap.add_argument("--cpu-baseline-N", type=int, default=0, help="override the CPU sample size")
+    ap.add_argument("--cpu-budget-s", type=float, default=150.0,
+                    help="budget of the CPU leg; the same-workload sample (one posterior at the bench N) runs when its "
+                         "estimate fits, else N is halved")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="print the torch.distributed.run command --gpus N would re-execute under, and exit")
     return ap.parse_args()
 
 
-def cpu_baseline(N, d, M, kernel, budget_s=25.0):
-    """The oracle (CPU restatement of the reference algorithm, Cholesky route) timed on the host
-    cores of this box on a bounded sample of the same workload: ONE posterior + draw at the
-    largest N (halving from the bench N) whose estimated time fits the budget."""
+def self_launch_command(a, argv):
+    """The command line `bench.py --gpus N` (N > 1, started without a launcher) re-executes itself under: one rank
+    per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def cpu_baseline(N, d, M, kernel, budget_s=150.0):
+    """The oracle (CPU restatement of the reference algorithm) timed on the host cores of this box on a bounded
+    sample of the SAME workload: ONE posterior + draw at the bench N (Cholesky route — the algorithm the GPU runs),
+    halving N only if the estimate exceeds the budget.  Beside it: the reference-faithful explicit-inverse route
+    (gpax/models/gp.py:271-273) at the largest N whose estimate fits ~30 s, and the Cholesky route on ONE core."""
+    from bench_inputs import synthetic_problem
     from oracle import cpu_ref as ref
     try:
         from threadpoolctl import threadpool_info
         pools = threadpool_info()
         threads = max([p.get("num_threads", 1) for p in pools] or [1])
-        blas = ",".join(sorted({str(p.get("internal_api")) for p in pools}))
+        blas = ";".join(sorted({f"{p.get('internal_api')} {p.get('version')} ({p.get('threading_layer', 'n/a')}, "
+                                f"{p.get('num_threads')} threads)" for p in pools}))
     except Exception:
         threads, blas = os.cpu_count() or 1, "unknown"
     # calibrate on a small case (N^3 scaling), then pick the sample size
-    Xc, yc, Xn, p = ref.synthetic_problem(2048, d, M, seed=0)
+    Xc, yc, Xn, p = synthetic_problem(2048, d, M, seed=0)
     eps = np.zeros((1, M))
     t0 = time.perf_counter()
     ref.predict_one(Xc, yc, Xn, p, eps, False, kernel=kernel, jitter=1e-6, route="chol")
@@ -67,28 +88,24 @@ def cpu_baseline(N, d, M, kernel, budget_s=25.0):
     Ns = N
     while Ns > 2048 and t_small * (Ns / 2048.0) ** 3 * 0.5 > budget_s:
         Ns //= 2
-    X, y, Xnew, p = ref.synthetic_problem(Ns, d, M, seed=0)
+    X, y, Xnew, p = synthetic_problem(Ns, d, M, seed=0)
     t0 = time.perf_counter()
     ref.predict_one(X, y, Xnew, p, eps, False, kernel=kernel, jitter=1e-6, route="chol")
     dt = time.perf_counter() - t0
-    # the reference-faithful route (explicit inverse, gp.py:271-273) costs ~6x the Cholesky route: time it
-    # at the largest N (halving) whose estimate fits what is left of the budget
-    inv = None
     Ni = Ns
-    while Ni > 1024 and 6.0 * dt * (Ni / float(Ns)) ** 3 > max(budget_s - dt, 5.0):
+    while Ni > 1024 and 6.0 * dt * (Ni / float(Ns)) ** 3 > 30.0:
         Ni //= 2
-    Xi, yi, Xni, pi_ = ref.synthetic_problem(Ni, d, M, seed=0)
+    Xi, yi, Xni, pi_ = synthetic_problem(Ni, d, M, seed=0)
     t0 = time.perf_counter()
     ref.predict_one(Xi, yi, Xni, pi_, eps, False, kernel=kernel, jitter=1e-6, route="inv")
     dti = time.perf_counter() - t0
     inv = {"value": 1.0 / dti, "unit": f"posteriors/s at N={Ni}", "seconds": dti, "N": Ni,
            "route": "explicit inverse, as gpax/models/gp.py:271-273"}
-    # and the Cholesky route on ONE core (SURVEY.md 8d asks for both ends), at a size that stays within a few seconds
     one = None
     try:
         from threadpoolctl import threadpool_limits
         N1 = 2048
-        X1, y1, Xn1, p1 = ref.synthetic_problem(N1, d, M, seed=0)
+        X1, y1, Xn1, p1 = synthetic_problem(N1, d, M, seed=0)
         with threadpool_limits(limits=1):
             t0 = time.perf_counter()
             ref.predict_one(X1, y1, Xn1, p1, eps, False, kernel=kernel, jitter=1e-6, route="chol")
@@ -99,20 +116,45 @@ def cpu_baseline(N, d, M, kernel, budget_s=25.0):
         pass
     return {
         "value": 1.0 / dt,
-        "unit": f"posteriors/s at N={Ns}",
+        "unit": "posteriors/s" if Ns == N else f"posteriors/s at N={Ns}",
         "cores": int(threads),
         "kind": "port",
-        "sample": (f"1 posterior+draw (oracle/cpu_ref.py predict_one, Cholesky route, NumPy/SciPy {blas}) "
-                   f"at N={Ns}, d={d}, M={M}: {dt:.2f} s; os.cpu_count()={os.cpu_count()}"),
+        "sample": (f"1 posterior+draw (oracle/cpu_ref.py predict_one, Cholesky route) at N={Ns}, d={d}, M={M}"
+                   f"{' = the bench workload' if Ns == N else ' (bench N halved to fit the CPU budget)'}: {dt:.2f} s; "
+                   f"BLAS: {blas}; os.cpu_count()={os.cpu_count()}"),
         "seconds": dt,
         "N": Ns,
+        "same_workload_as_value": Ns == N,
+        "blas": blas,
         "inv_route": inv,
         "one_core": one,
     }
 
 
+def gram_bytes_written(N, Np):
+    """Bytes one lower-tile Gram build actually stores (32 x 512 tiles with j0 <= i0 + 31, gram.hip:49), next to the
+    8 N^2 the algorithmic figure credits (the symmetric build may claim the full matrix)."""
+    total = 0
+    for i0 in range(0, N, 32):
+        rows = min(32, N - i0)
+        ntiles = min((i0 + 31) // 512 + 1, (Np + 511) // 512)
+        total += rows * min(ntiles * 512, Np) * 8
+    return total
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: launch the N ranks ourselves (one process per GPU over RCCL) and relay their output
+        import subprocess
+        argv = [x for x in sys.argv[1:] if x != "--dry-launch"]
+        cmd = self_launch_command(a, argv)
+        if a.dry_launch:
+            print(json.dumps({"launch": cmd}))
+            return
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -130,16 +172,18 @@ def main():
         else:
             dist.init_process_group(backend=a.dist_backend)
 
+    from bench_inputs import synthetic_problem, synthetic_theta_samples  # BASELINE.md §3 workloads
     from gpax_amd import _lib
-    from oracle import cpu_ref as ref  # synthetic inputs only
 
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     eng = _lib.Engine(local_rank)
     kind = _lib.kernel_kind(a.kernel)
     N, d, M = a.N, a.d, a.M
-    X, y, Xnew, p = ref.synthetic_problem(N, d, M, seed=0)
+    X, y, Xnew, p = synthetic_problem(N, d, M, seed=0)
     K, W = a.steps, a.warmup
     # every rank sweeps its own block of theta samples (contiguous shard of the global table)
-    thetas = ref.synthetic_theta_samples(world * (K + W), d, seed=1)
+    thetas = synthetic_theta_samples(world * (K + W), d, seed=1)
     lo = rank * (K + W)
     sl_w = slice(lo, lo + W)
     sl_k = slice(lo + W, lo + W + K)
@@ -218,12 +262,15 @@ def main():
         # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
         # (profiles/r01/traffic.json; FETCH_SIZE doubled per the gfx950 correction, MI355X_MICROARCH.md §HBM)
         traffic, traffic_note = None, None
-        tj = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-        if os.path.exists(tj) and (N, d, M) == (16384, 2, 1024):
-            t = json.load(open(tj))
-            if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
-                traffic = (2.0 * t["FETCH_SIZE"]["avg_per_launch"] + t["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
-                traffic_note = "bytes per launch, profiles/r01/{fetch,write}.md: (2*FETCH_SIZE + WRITE_SIZE) KB"
+        for rnd in ("r02", "r01"):
+            tj = os.path.join(ROOT, "profiles", rnd, "traffic.json")
+            if os.path.exists(tj) and (N, d, M) == (16384, 2, 1024):
+                t = json.load(open(tj))
+                if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+                    traffic = (2.0 * t["FETCH_SIZE"]["avg_per_launch"] + t["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
+                    traffic_note = (f"bytes per launch, profiles/{rnd}/{{fetch,write}}.md: (2*FETCH_SIZE + WRITE_SIZE) KB"
+                                    + ("" if rnd == "r02" else " (previous round's kernel)"))
+                    break
         post_flops = N ** 3 / 3 + N * N * M + N * M * M + 2 * N * N + 2 * N * M + M ** 3 / 3 + M * M
         out = {
             "metric": f"exactgp_posteriors_per_sec_N{N}_d{d}",
@@ -243,7 +290,7 @@ def main():
                        "parallelism": f"sample-sharded x{world}, {n_fl} samples in flight per GPU"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "gpx::gemm_nt_kernel (Cholesky trailing SYRK, K=512, lower tiles)",
+                "kernel": "gpx::gemm_nt128_kernel<1,1> (Cholesky trailing SYRK, K=512, lower tiles, LDS-direct staging)",
                 "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
@@ -264,11 +311,14 @@ def main():
             "potrf_tflops": (N ** 3 / 3) / (stages["potrf_ms"] * 1e-3) / 1e12,
             "kernel_classes_ms_per_predict": {"gemm_trailing": ms, "gemm_other": ms_o, "potf2": ms_p, "gram": ms_g},
             "gram_alg_GBps": bytes_g / (ms_g * 1e-3) / 1e9 if ms_g > 0 else None,
+            "gram_written_GBps": (gram_bytes_written(N, (N + 1 + 127) // 128 * 128) / (stages["gram_ms"] * 1e-3) / 1e9),
+            "gram_note": "alg = 8 N^2 credited to the symmetric build (SURVEY 8d); written = bytes the lower 32x512 "
+                         "tiles actually store, over the stand-alone Gram stage",
             "mfma_f64_microbench_tflops": eng.mfma_f64_peak(),
             "lml_check": lml,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_N or N, d, M, a.kernel)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_N or N, d, M, a.kernel, a.cpu_budget_s)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

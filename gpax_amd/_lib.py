@@ -166,6 +166,8 @@ class Engine:
         self.M = 0
         self.T = 1
         self._diag_key = None
+        self._train_owner = None
+        self._train_version = None
 
     # -- plumbing -----------------------------------------------------------------------------
     def _check(self, rc: int, what: str):
@@ -213,6 +215,10 @@ class Engine:
         treat entry b as task b % T."""
         X = _f64(X)
         self._diag_key = None  # gpx_set_train clears the per-point diagonal
+        # whoever calls set_train replaces the resident training set: no model may go on believing it owns it
+        # (the owner re-registers itself right after its own set_train, models/gp.py:_engine)
+        self._train_owner = None
+        self._train_version = None
         if X.ndim == 3:
             self.T, self.N, self.d = X.shape
             self._check(self._lib.gpx_set_train_tasks(self._ctx, _ptr(X), self.T, self.N, self.d),

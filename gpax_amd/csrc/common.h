@@ -144,6 +144,7 @@ struct gpx_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   hipDeviceProp_t prop;
+  unsigned func_attr_mask = 0; // kernels whose dynamic-LDS attribute this context has set on ITS device (bit per variant)
 
   // ---- training state -------------------------------------------------------------------
   int N = 0, d = 0;

@@ -1,21 +1,31 @@
-// gemm_f64.hip — fp64 MFMA "NT" GEMM tile kernel for gfx950:
+// gemm_f64.hip — fp64 MFMA "NT" GEMM tile kernels for gfx950:
 //     C[i][j] = beta * C[i][j] + alpha * sum_k A[i][k] * B[j][k]        (row-major everywhere)
 //
-// This one kernel carries every dense contraction on the exact-GP path (the work JAX hands to
+// These kernels carry every dense contraction on the exact-GP path (the work JAX hands to
 // LAPACK/cuSOLVER underneath gpax/models/gp.py:160-164,271-273,292): the Cholesky trailing
 // update (SYRK form, lower tiles only), the panel TRSM (multiplication by the inverted 128x128
 // diagonal block), the right-looking TRSM sweeps of the posterior, the split-K SYRK of the
 // posterior covariance, L^-T L^-1 for the gradient, and the MVN draw.
 //
-// Design (CDNA4): 128x128 block tile, BK = 16, 256 threads = 4 waves in a 2x2 grid, each wave
-// owns a 64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 accumulator VGPRs).
-// A and B tiles are both "row x k" with k contiguous (that is what NT means in row-major), so
-// both fragments are read from LDS with the same pattern: lane l reads row (l & 15), k (l >> 4).
-// LDS rows are padded to 17 doubles (odd): the compiler fuses fragment reads into ds_read2_b64,
-// whose 16-lane groups then hit 16 distinct bank pairs (an even pad measured 2-way conflicts:
-// 42 -> 66 TF in tools/exp/gemm_variants.hip); the price is 8-byte instead of 16-byte LDS stores.  Global -> register -> LDS staging,
-// double-buffered in LDS with the next tile's global loads in flight during the MFMAs: one
-// barrier per k-step.  69.6 KB LDS + <256 VGPRs => 2 workgroups (8 waves) per CU.
+// Two kernels, one arithmetic:
+//   gemm_nt128_kernel  THROUGHPUT shape, 128x128 block tile, BK = 16, 256 threads = 2x2 waves, each wave a
+//       64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators.  LDS-direct staging: every wave issues
+//       eight `buffer_load_dwordx4 ... lds` per k-step (1 KiB = 8 rows x 128 B each; loop-invariant 32-bit
+//       voffsets, the k advance in an SGPR soffset, destination in M0 — no VALU in the loop), SPREAD over the
+//       first three of the four 16-MFMA blocks of the step (3 + 3 + 2, pinned with sched_group_barrier):
+//       bunched at the top of the step the same loads cost 6 % of the loop (r02 harness, tools/exp/gemm_r2.hip:
+//       68.2 -> 75.1 TFLOP/s on zero operands at K = 2048 = 95 % of the MFMA peak).  LDS rows are unpadded
+//       128-B lines with an XOR swizzle on the 16-B chunk index, chunk' = chunk ^ ((row >> 1) & 7), applied to
+//       the SOURCE address (LDS-DMA writes lane-linearly) and to the fragment reads: each fragment is ONE
+//       conflict-free ds_read_b64.  2 buffers x 32 KB = 64 KB + < 256 VGPRs => 2 workgroups / CU.
+//   gemm_nt_kernel     LATENCY shapes (64x64, 64x128) for grids too small to fill the chip; register staging,
+//       LDS rows padded to 17 doubles (round 1).
+// Both accumulate every C element over its k range in ascending k, from the same start value, with the same
+// epilogue — so the choice of shape never changes a result bit (batched == single-sample launches):
+//   beta == 0               acc starts at 0,  C = alpha * acc
+//   alpha == -1, beta == 1  acc starts at -C (the tile is read in the prologue, while the first k-tile is in
+//                           flight, instead of read-modify-written in the epilogue), C = -acc
+//   otherwise               acc starts at 0,  C = fma(beta, C, alpha * acc)
 //
 // f64 MFMA fragment layout (differs from the f32 forms!):
 //   A: lane l holds A[i = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][j = l & 15];
@@ -90,11 +100,24 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
   double* sA1 = DBUF ? smem + TA + TB : sA0;
   double* sB1 = DBUF ? smem + 2 * TA + TB : sB0;
 
+  // epilogue form (uniform over the launch) — the same three forms as gemm_nt128_kernel, see the file header
+  const double alpha = g.alpha, beta = g.beta;
+  const bool cacc = (alpha == -1.0 && beta == 1.0);
+  double* Cw = C + ((int64_t)by * BM + wr * 16 * MT + fk) * g.ldc + (int64_t)bx * BN + wc * 16 * NT + fr;
   d4_t acc[MT][NT];
+  if (cacc) {
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = d4_t{0.0, 0.0, 0.0, 0.0};
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n][r] = -Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16];
+  } else {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = d4_t{0.0, 0.0, 0.0, 0.0};
+  }
 
   const int a_frag_off = (wr * 16 * MT + fr) * LDT + fk;
   const int b_frag_off = (wc * 16 * NT + fr) * LDT + fk;
@@ -158,11 +181,16 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
   }
 
   // epilogue: D[row = (lane >> 4) + 4 r][col = lane & 15] per 16x16 accumulator.  A wave
-  // store covers 4 rows x 16 contiguous doubles (full 128-B lines).  The beta path batches the
+  // store covers 4 rows x 16 contiguous doubles (full 128-B lines).  The generic beta path batches the
   // C loads of one accumulator row-block ahead of their use (one latency, not sixteen).
-  const double alpha = g.alpha, beta = g.beta;
-  double* Cw = C + ((int64_t)by * BM + wr * 16 * MT + fk) * g.ldc + (int64_t)bx * BN + wc * 16 * NT + fr;
-  if (beta != 0.0) {
+  if (cacc) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = -acc[m][n][r];
+  } else if (beta != 0.0) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       double cv[4][NT];
@@ -187,17 +215,178 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
   }
 }
 
+// ---- throughput shape -------------------------------------------------------------------------------
+typedef void __attribute__((address_space(3)))* lds_ptr_t;
+
+// EPI: 0 beta == 0 | 1 alpha == -1, beta == 1 (accumulators start from -C) | 2 generic read-modify-write
+// TAG only gives the Cholesky trailing update (TAG = 1) its own symbol, so that rocprofv3 kernel statistics
+// separate the dominant kernel from the other GEMM launches (TAG = 0).
+template <int TAG, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
+  constexpr int BK = 16, BM = 128, BN = 128, TD = (BM + BN) * BK, GPW = 8;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (TAG == 0) __builtin_amdgcn_s_setprio(2); // non-trailing launches sit on the critical path of the look-ahead
+  const int bx = blockIdx.x, by = blockIdx.y;
+  const int bb = (g.batch > 1) ? blockIdx.z / g.nsplit : 0;
+  const int bz = blockIdx.z - bb * g.nsplit;
+  const int row0 = g.ti_off * 128 + by * BM, col0 = g.tj_off * 128 + bx * BN;
+  if (g.lower && col0 > row0 + BM - 1) return; // entirely above the diagonal
+
+  int kb = 0, ke = g.K;
+  if (g.ktri) kb = row0 & ~(BK - 1);
+  if (g.kupper) ke = min(ke, col0 + BN);
+  double* C = g.C + (int64_t)bb * g.c_bs;
+  if (g.kchunk > 0) {
+    kb = max(kb, bz * g.kchunk);
+    ke = min(ke, (bz + 1) * g.kchunk);
+    C += (int64_t)bz * g.c_split_stride;
+  }
+  const int nk = (ke > kb) ? (ke - kb) / BK : 0;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  // staging: waves 0, 1 bring in the A rows, waves 2, 3 the B rows (64 rows = 8 groups of 8 rows per wave).
+  // One wave-instruction = 64 lanes x 16 B = 1 KiB = 8 LDS rows; lane -> row (lane >> 3), LDS chunk (lane & 7),
+  // which holds source chunk (lane & 7) ^ ((row >> 1) & 7) of that row.
+  const bool isA = wave < 2;
+  const double* src = isA ? g.A + (int64_t)bb * g.a_bs + (int64_t)by * BM * g.lda
+                          : g.B + (int64_t)bb * g.b_bs + (int64_t)bx * BN * g.ldb;
+  const int64_t ldx = isA ? g.lda : g.ldb;
+  // 2 GiB window from the tile's first row: offsets stay below 128 rows x ld x 8 B + K x 8 B
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
+  int voff[GPW];
+#pragma unroll
+  for (int j = 0; j < GPW; ++j) {
+    const int row = (wave & 1) * 64 + j * 8 + (lane >> 3);
+    const int lrow = (isA ? 0 : BM) + row;
+    const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);
+    voff[j] = (int)((row * ldx + chunk * 2) * 8);
+  }
+  const int lds_wave = ((isA ? 0 : BM) + (wave & 1) * 64) * BK;
+
+  double* Cw = C + ((int64_t)by * BM + wr * 64 + fk) * g.ldc + (int64_t)bx * BN + wc * 64 + fr;
+  d4_t acc[4][4];
+  if (EPI == 1) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n][r] = -Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16];
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = d4_t{0.0, 0.0, 0.0, 0.0};
+  }
+
+  // fragment offsets (doubles) in a buffer: row * 16 + ((k >> 1) ^ ((row >> 1) & 7)) * 2 + (k & 1), k = 4 kk + fk;
+  // 2 kk only touches bits 1..2 of the chunk index, so block kk is `offset ^ (4 kk)`
+  int aoff[4], boff[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int ra = wr * 64 + m * 16 + fr, rb = BM + wc * 64 + m * 16 + fr;
+    aoff[m] = ra * BK + (((fk >> 1) ^ ((ra >> 1) & 7)) * 2) + (fk & 1);
+    boff[m] = rb * BK + (((fk >> 1) ^ ((rb >> 1) & 7)) * 2) + (fk & 1);
+  }
+
+#define GPX_GLOAD(j, buf, soff)                                                                                    \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + (buf) * TD + lds_wave + (j) * 8 * BK), 16, voff[j], \
+                                           (soff), 0, 0)
+  if (nk > 0) {
+#pragma unroll
+    for (int j = 0; j < GPW; ++j) GPX_GLOAD(j, 0, kb * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1, nxt = cur ^ 1;
+      // the last step re-reads its own k-tile into the idle buffer (in bounds, unused): no branch in the body
+      const int soff = (kb + ((kt + 1 < nk) ? kt + 1 : kt) * BK) * 8;
+      const double* cb = smem + cur * TD;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          af[m] = cb[aoff[m] ^ (4 * kk)];
+          bf[m] = cb[boff[m] ^ (4 * kk)];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+          // next k-tile: 3 + 3 + 2 loads behind the MFMAs of blocks 0, 1, 2; block 3 gives them time to land
+          if (kk < 2 && m < 3) GPX_GLOAD(3 * kk + m, nxt, soff);
+          if (kk == 2 && m < 2) GPX_GLOAD(6 + m, nxt, soff);
+        }
+        if (kk < 3) {
+#pragma unroll
+          for (int q = 0; q < (kk < 2 ? 3 : 2); ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);  // 4 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); // 1 VMEM read
+          }
+          if (kk < 2) __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+#undef GPX_GLOAD
+
+  const double alpha = g.alpha, beta = g.beta;
+  if (EPI == 1) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = -acc[m][n][r];
+  } else if (EPI == 2) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      double cv[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) cv[r][n] = Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = fma(beta, cv[r][n], alpha * acc[m][n][r]);
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = alpha * acc[m][n][r];
+  }
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a function: every context sets it once
+// for each variant it launches (a process may hold contexts on several GPUs; contexts are also driven from
+// different host threads, so the "done" bits live in the context, not in a function-local static).
+enum : unsigned { ATTR_SMALL_22 = 0, ATTR_SMALL_24 = 1, ATTR_BIG_BASE = 2 /* + 3 * TAG + EPI */ };
+
 template <int TAG, int MT, int NT, int BK, bool DBUF>
 static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int tiles_n, int splits) {
   GemmArgs g = g0;
   g.nsplit = splits > 0 ? splits : 1;
   if (g.batch < 1) g.batch = 1;
-  static bool attr_set = false;
   constexpr size_t lds = gemm_lds_bytes<MT, NT, BK, DBUF>();
-  if (!attr_set) {
+  constexpr unsigned bit = 1u << ((NT == 2) ? ATTR_SMALL_22 : ATTR_SMALL_24);
+  if (!(ctx->func_attr_mask & bit)) {
     GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<TAG, MT, NT, BK, DBUF>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    ctx->func_attr_mask |= bit;
   }
   // tiles_m / tiles_n are given in 128-tiles
   dim3 grid(tiles_n * (4 / NT), tiles_m * (4 / MT), g.nsplit * g.batch);
@@ -206,11 +395,36 @@ static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int til
   return 0;
 }
 
+template <int TAG, int EPI>
+static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n) {
+  constexpr size_t lds = (size_t)2 * 256 * 16 * sizeof(double); // 2 buffers x (128 A rows + 128 B rows) x 128 B
+  constexpr unsigned bit = 1u << (ATTR_BIG_BASE + 3 * TAG + EPI);
+  if (!(ctx->func_attr_mask & bit)) {
+    GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_kernel<TAG, EPI>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ctx->func_attr_mask |= bit;
+  }
+  dim3 grid(tiles_n, tiles_m, g.nsplit * g.batch);
+  gemm_nt128_kernel<TAG, EPI><<<grid, 256, lds, ctx->s>>>(g);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+template <int TAG>
+static int launch_big(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int tiles_n, int splits) {
+  GemmArgs g = g0;
+  g.nsplit = splits > 0 ? splits : 1;
+  if (g.batch < 1) g.batch = 1;
+  if (g.beta == 0.0) return launch_big_epi<TAG, 0>(ctx, g, tiles_m, tiles_n);
+  if (g.alpha == -1.0 && g.beta == 1.0) return launch_big_epi<TAG, 1>(ctx, g, tiles_m, tiles_n);
+  return launch_big_epi<TAG, 2>(ctx, g, tiles_m, tiles_n);
+}
+
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
                    int prof_cls, double work) {
   if (tiles_m <= 0 || tiles_n <= 0) return 0;
   ProfScope ps(ctx, prof_cls, work * (g.batch > 1 ? g.batch : 1));
-  if (prof_cls == GPX_PROF_GEMM_TRAILING) return launch_variant<1, 4, 4, 16, true>(ctx, g, tiles_m, tiles_n, splits);
+  if (prof_cls == GPX_PROF_GEMM_TRAILING) return launch_big<1>(ctx, g, tiles_m, tiles_n, splits);
   // latency-bound launches (too few 128x128 tiles to fill 256 CUs x 2): smaller workgroup tiles
   // Workgroups the launch would have with 128x128 tiles (batch entries included).  The choice of shape does
   // not change results: every C element accumulates its k range in the same order in all shapes (the k ranges
@@ -234,7 +448,7 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
       return launch_variant<0, 2, 2, 16, false>(ctx, g, tiles_m, tiles_n, splits);
     }
   }
-  return launch_variant<0, 4, 4, 16, true>(ctx, g, tiles_m, tiles_n, splits);
+  return launch_big<0>(ctx, g, tiles_m, tiles_n, splits);
 }
 
 // ---- raw MFMA issue-rate microbenchmark ----------------------------------------------------

@@ -409,12 +409,15 @@ namespace gpx {
 int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo, int info_base,
                      int batch, int64_t a_bs, int64_t linv_bs) {
   const int nb = batch > 1 ? batch : 1;
-  static int use_tile = -1;
-  if (use_tile < 0) {
-    const char* e = getenv("GPX_POTF2");
-    use_tile = (e && e[0] == 'c') ? 0 : 1; // GPX_POTF2=column selects the column-by-column kernel
+  // GPX_POTF2=column selects the column-by-column kernel (its > 64 KB of dynamic LDS is a per-device function
+  // attribute: set once per context, i.e. on every device a process opens)
+  constexpr unsigned ATTR_POTF2_COLUMN = 1u << 31;
+  const char* e = getenv("GPX_POTF2");
+  const bool use_tile = !(e && e[0] == 'c');
+  if (!use_tile && !(ctx->func_attr_mask & ATTR_POTF2_COLUMN)) {
     GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS_BYTES));
+    ctx->func_attr_mask |= ATTR_POTF2_COLUMN;
   }
   // algorithmic flops: factor n^3/3 + triangular inverse n^3/3
   ProfScope ps(ctx, GPX_PROF_POTF2, nb * 2.0 * PB * (double)PB * PB / 3.0);

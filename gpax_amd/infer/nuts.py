@@ -7,7 +7,7 @@ NUTS defaults target_accept_prob=0.8, max_tree_depth=10, diagonal mass matrix, S
 warm-up windows.  Every leapfrog calls `potential_and_grad(u)`, which for the exact GP is one
 Gram + Cholesky + K^-1 + gradient-contraction pass on the GPU (gpx_factor + gpx_lml_grad).
 JAX's threefry streams cannot be reproduced, so chains are not bit-comparable with NumPyro's;
-the sampler is validated on distributional properties (tests/test_nuts.py).
+the sampler is validated on distributional properties (tests/test_samplers.py).
 """
 from __future__ import annotations
 

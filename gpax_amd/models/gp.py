@@ -138,6 +138,7 @@ class ExactGP:
         self._samples = None
         self._chain_shape = None
         self._device = None
+        self._data_version = 0
 
     # ------------------------------------------------------------------------------------------
     # model definition: sites, transforms, log-joint  (gp.py:137-164, 222-247)
@@ -170,11 +171,15 @@ class ExactGP:
         return sites
 
     def _engine(self) -> _lib.Engine:
+        """The shared context of this model's device with X_train resident.  Residency is keyed on (model, data
+        version): `_data_version` is bumped by every fit() / _set_training_data(), so an X array mutated in place
+        or a recycled buffer is uploaded again; Engine.set_train itself drops the previous owner."""
         eng = _lib.get_engine(self._device)
-        if getattr(eng, "_train_owner", None) is not self or getattr(eng, "_train_version", None) is not self.X_train:
+        key = (self._data_version, id(self.X_train))
+        if getattr(eng, "_train_owner", None) is not self or getattr(eng, "_train_version", None) != key:
             eng.set_train(self.X_train)
             eng._train_owner = self
-            eng._train_version = self.X_train
+            eng._train_version = key
         return eng
 
     def _ell(self, params) -> np.ndarray:
@@ -247,7 +252,9 @@ class ExactGP:
 
     def _lognormal_plan(self, sites):
         """(loc, scale, log(scale) + log(2 pi)/2) per element of u when every site has a LogNormal prior, else None."""
-        key = tuple((s.name, s.size, id(s.dist)) for s in sites)
+        key = tuple((s.name, s.size, type(s.dist).__name__, float(getattr(s.dist, "loc", np.nan)),
+                     float(getattr(s.dist, "scale", np.nan))) if type(s.dist) is dist.LogNormal
+                    else (s.name, s.size, type(s.dist).__name__, id(s.dist)) for s in sites)
         cached = getattr(self, "_ln_plan", None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -345,6 +352,8 @@ class ExactGP:
         self._device = device if isinstance(device, int) else None
         self.X_train = X
         self.y_train = y
+        self._data_version += 1  # re-upload X even when the caller reuses (or mutated) the same array object
+        self._ln_plan = None     # prior plan rebuilt once per fit
         jitter = float(kwargs.get("jitter", 1e-6))
         rng = rng_from_key(rng_key)
         sites = self._sites()
@@ -519,11 +528,7 @@ class ExactGP:
         m_slice = int(kwargs.pop("_m_slice", 0))  # predict_in_batches: covariance blocks of this many test points
         ells, scales, noises, yres, eps, mean_shift = self._sweep_inputs(rng_key, X_new, samples, n, m_slice)
         # several samples in flight per GPU: independent libgpx contexts on the same device
-        engines = _lib.get_sweep_engines(self._device)
-        for e in engines[1:]:
-            e._train_owner = None
-        if len(engines) > 1:
-            engines[0]._train_owner = None
+        engines = _lib.get_sweep_engines(self._device)  # concurrent_sweep re-uploads X (set_train drops ownership)
         means, y_sampled, infos = _lib.concurrent_sweep(engines, self.X_train, self._kind, ells, scales, noises, yres,
                                                         X_new, noiseless, jitter, eps, m_slice=m_slice)
         return self._sweep_outputs(means, y_sampled, mean_shift, filter_nans)
@@ -588,8 +593,6 @@ class ExactGP:
         else:
             args = (None, None, None, None, None)
         engines = _lib.get_sweep_engines(self._device)
-        for e in engines:
-            e._train_owner = None
         res = predict_sharded(engines, self._kind, *args, noiseless, jitter, comm)
         if res is None:
             return None
@@ -627,6 +630,7 @@ class ExactGP:
             self.y_train = np.ascontiguousarray(np.asarray(y_train_new, dtype=np.float64).squeeze())
         if isinstance(device, int):
             self._device = device
+        self._data_version += 1
 
     def _print_summary(self):
         samples = self.get_samples(chain_dim=True)

@@ -105,16 +105,17 @@ class VarNoiseGP(ExactGP):
         # main GP: y | theta, v   (hskgp.py:146-153)
         yres = self.y_train - self._mean(self.X_train, theta)
         eng.set_diag(v)
-        lml1, info1 = eng.factor(self._kind, self._ell(theta), theta["k_scale"], 0.0, jitter, yres)
-        if info1 != 0 or not np.isfinite(lml1):
+        try:  # the per-point diagonal must never outlive this block on the shared context, whatever happens inside
+            lml1, info1 = eng.factor(self._kind, self._ell(theta), theta["k_scale"], 0.0, jitter, yres)
+            if info1 != 0 or not np.isfinite(lml1):
+                return bad
+            g1 = a1 = gdiag = None
+            if want_grad:
+                g_ell, g_scale, _, a1 = eng.lml_grad()
+                gdiag = eng.lml_grad_diag()
+                g1 = np.concatenate([g_ell, [g_scale, 0.0]])
+        finally:
             eng.set_diag(None)
-            return bad
-        g1 = a1 = gdiag = None
-        if want_grad:
-            g_ell, g_scale, _, a1 = eng.lml_grad()
-            gdiag = eng.lml_grad_diag()
-            g1 = np.concatenate([g_ell, [g_scale, 0.0]])
-        eng.set_diag(None)
         # noise GP: log_var | theta_n ~ MVN(noise_loc, k_noise)   (hskgp.py:129-134)
         lv_res = lv - self._noise_loc(self.X_train, theta)
         lml2, info2 = eng.factor(self._noise_kind, self._noise_ell(theta), self._scalar(theta["k_noise_scale"]), 0.0,

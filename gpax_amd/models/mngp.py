@@ -37,6 +37,7 @@ class MeasuredNoiseGP(ExactGP):
         self.measured_noise = None
         self.noise_predicted = None
         self._use_measured = False
+        self._noise_version = 0
 
     # -- model (mngp.py:74-98): no noise site; noise is the deterministic 0 --------------------------------
     def _sites(self):
@@ -51,7 +52,9 @@ class MeasuredNoiseGP(ExactGP):
         eng = super()._engine()
         want = self.measured_noise if self._use_measured else None
         # (re)assert the per-point diagonal of this model's current phase on the shared context
-        key = (id(self), id(self.X_train), want is not None)
+        # keyed on the fit counter, not on object identities: a second fit() on the same X array with other
+        # measured noise must upload the new vector (Engine.set_train also clears the key)
+        key = (id(self), self._data_version, self._noise_version, want is not None)
         if getattr(eng, "_diag_key", None) != key:
             eng.set_diag(want)
             eng._diag_key = key
@@ -65,6 +68,7 @@ class MeasuredNoiseGP(ExactGP):
         if self.measured_noise.shape[0] != self._set_data(X).shape[0]:
             raise ValueError("measured_noise must have one value per training point")
         self.noise_predicted = None
+        self._noise_version += 1
         self._use_measured = True
         try:
             super().fit(rng_key, X, y, num_warmup, num_samples, num_chains, chain_method, progress_bar, False, device,

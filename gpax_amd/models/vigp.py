@@ -89,15 +89,19 @@ class viGP(ExactGP):
         if samples is None:
             samples = self.get_samples()
         jitter = float(kwargs.get("jitter", 1e-6))
+        info = 0
         if predict_fn is None:
-            self._factor_at(samples, jitter)
+            _, info = self._factor_at(samples, jitter)
             predict_fn = lambda xi: self._posterior_mean_var(xi, samples, noiseless, jitter)
         y_pred, y_var = [], []
         for Xi in split_in_batches(X_new, batch_size, dim=0):
             m, v = predict_fn(Xi)
             y_pred.append(m)
             y_var.append(v)
-        return np.concatenate(y_pred, 0), np.concatenate(y_var, 0)
+        y_pred, y_var = np.concatenate(y_pred, 0), np.concatenate(y_var, 0)
+        if info != 0:  # K(theta) not positive definite: NaN like predict() and the reference's inverse route
+            y_pred, y_var = np.full_like(y_pred, np.nan), np.full_like(y_var, np.nan)
+        return y_pred, y_var
 
     def _factor_at(self, params, jitter):
         noise = self._scalar(params["noise"])

@@ -283,6 +283,30 @@ def predict_one(X_train, y_train, X_new, params, eps, noiseless=False, kernel="R
     return y_mean, mvn_sample(y_mean, K, eps)
 
 
+def exactgp_full_pass(X_train, y_train, X_new, params, eps, noiseless=False, kernel="RBF", jitter=1e-6):
+    """lml (gp.py:137-164), posterior mean / cov (gp.py:253-277, Cholesky route) and the MVN draw (gp.py:279-293)
+    of ONE theta from ONE factorisation of k_XX — the same arithmetic as exactgp_log_likelihood +
+    get_mvn_posterior(route='chol') + mvn_sample (tests/test_oracle.py asserts equality), for the full-size
+    parity tests where three separate N = 16384 factorisations on the host would take minutes."""
+    X_train, y_train = _set_data(X_train, y_train)
+    X_new = _set_data(X_new)
+    kfn = get_kernel(kernel)
+    noise = params["noise"]
+    noise_p = noise * (1 - int(bool(noiseless)))
+    k_XX = kfn(X_train, X_train, params, noise, jitter=jitter)
+    L = np.linalg.cholesky(k_XX)
+    del k_XX
+    w = sla.solve_triangular(L, y_train, lower=True)
+    lml = float(-0.5 * (w @ w) - np.log(np.diag(L)).sum() - 0.5 * y_train.shape[0] * LOG_2PI)
+    k_pX = kfn(X_new, X_train, params, jitter=0.0)
+    V = sla.solve_triangular(L, k_pX.T, lower=True)
+    k_pp = kfn(X_new, X_new, params, noise_p, jitter=jitter)
+    cov = k_pp - V.T @ V
+    mean = V.T @ w
+    alpha = sla.solve_triangular(L, w, lower=True, trans="T")
+    return lml, mean, cov, mvn_sample(mean, cov, eps), alpha
+
+
 def predict(X_train, y_train, X_new, samples: Dict[str, np.ndarray], eps, noiseless=False, kernel="RBF",
             jitter=1e-6, **kw):
     """ExactGP.predict, gpax/models/gp.py:351-399: the vmap over S samples as a loop.
@@ -416,24 +440,7 @@ def preprocess_sparse_image(sparse_image):
 
 
 # ------------------------------------------------------------------------------------------
-# synthetic workloads of BASELINE.md §3 (shared by tests and bench.py)
+# synthetic workloads of BASELINE.md §3: defined in bench_inputs.py (shared by bench.py and the tests; the
+# workload generator is not part of the checker).  Re-exported here for the tests that grew up calling ref.*.
 # ------------------------------------------------------------------------------------------
-def synthetic_problem(N: int, d: int, M: int, seed: int = 0, noise: float = 0.1):
-    rng = np.random.default_rng(seed)
-    X = rng.uniform(0.0, 10.0, size=(N, d))
-    f = np.prod(np.sin(X + 0.3 * np.arange(d)[None, :]), axis=1)
-    y = f + math.sqrt(noise) * rng.standard_normal(N)
-    Xnew = rng.uniform(0.0, 10.0, size=(M, d))
-    params = {"k_length": 1.0 + 0.25 * np.arange(d), "k_scale": 1.3, "noise": noise}
-    return X, y, Xnew, params
-
-
-def synthetic_theta_samples(S: int, d: int, seed: int = 1, noise: float = 0.1):
-    """C4 of BASELINE.md: lengthscales / scale ~ LogNormal(0, 0.1) * base, noise ~ LogNormal(log .1, .1)."""
-    rng = np.random.default_rng(seed)
-    base_l = 1.0 + 0.25 * np.arange(d)
-    return {
-        "k_length": base_l[None, :] * np.exp(0.1 * rng.standard_normal((S, d))),
-        "k_scale": 1.3 * np.exp(0.1 * rng.standard_normal(S)),
-        "noise": noise * np.exp(0.1 * rng.standard_normal(S)),
-    }
+from bench_inputs import synthetic_problem, synthetic_theta_samples  # noqa: E402,F401

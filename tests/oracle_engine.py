@@ -36,6 +36,8 @@ class OracleEngine:
         self.N, self.d = self.X.shape
         self._diag = None
         self._diag_key = None
+        self._train_owner = None  # as _lib.Engine.set_train: the previous owner's residency claim ends here
+        self._train_version = None
 
     def set_diag(self, v):
         self._diag = None if v is None else np.asarray(v, dtype=np.float64).reshape(-1)

@@ -1,0 +1,139 @@
+"""GPU: DIRECT HIP-vs-oracle parity at BASELINE.json's sizes — the oracle
+(oracle/cpu_ref.py, restating gpax/models/gp.py:137-164,253-293,351-399) run on the host beside the device path:
+
+    C2  RBF     N =  4096, d = 2, M = 1024   lml, gradient, posterior (reference's explicit-inverse route), draws
+    C4  RBF     N =  8192, d = 3, M = 1024   one theta as C2; the S = 1000 sweep once (determinism + 4 spot samples)
+    C3  Matern  N = 16384, d = 2, M = 1024   lml, alpha, posterior, draws (one host factorisation, ~1-2 min)
+    C5  Matern  512 x 512 image, N ~ 16384   exact viGP: SVI steps + predict_in_batches over all 262 144 pixels
+
+Tolerances are SURVEY.md §8c's: |d lml| <= 1e-10 |lml|, |d mean| <= 1e-8 |mean|, |d cov|_F <= 1e-8 |k_pp|_F,
+draws 1e-8 — two orders inside the north-star bar (1e-6)."""
+import numpy as np
+import pytest
+
+from bench_inputs import synthetic_problem, synthetic_sparse_image, synthetic_theta_samples
+from oracle import cpu_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+JIT = 1e-6
+
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def check_one_theta(engine, kind, name, X, y, Xn, p, eps, route, want_grad):
+    engine.set_train(X)
+    lml, info = engine.factor(kind, p["k_length"], p["k_scale"], p["noise"], JIT, y)
+    assert info == 0
+    mean, cov, var = engine.posterior(Xn, p["noise"], JIT, want_cov=True, want_var=True)
+    draws, dinfo = engine.mvn_draw(eps)
+    assert dinfo == 0
+    kpp = ref.get_kernel(name)(Xn, Xn, p, p["noise"], jitter=JIT)
+    if route == "inv":  # the reference's own route (gp.py:271-273)
+        e_lml = ref.exactgp_log_likelihood(X, y, p, kernel=name, jitter=JIT)
+        e_mean, e_cov = ref.get_mvn_posterior(X, y, Xn, p, False, kernel=name, jitter=JIT, route="inv")
+        e_draws = ref.mvn_sample(e_mean, e_cov, eps)
+        e_alpha = None
+    else:
+        e_lml, e_mean, e_cov, e_draws, e_alpha = ref.exactgp_full_pass(X, y, Xn, p, eps, False, kernel=name, jitter=JIT)
+    assert abs(lml - e_lml) <= 1e-10 * abs(e_lml), (lml, e_lml)
+    assert relerr(mean, e_mean) < 1e-8
+    assert np.linalg.norm(cov - e_cov) / np.linalg.norm(kpp) < 1e-8
+    assert np.linalg.norm(var - np.diag(e_cov)) / np.linalg.norm(np.diag(kpp)) < 1e-8
+    assert relerr(draws, e_draws) < 1e-8
+    if want_grad or e_alpha is not None:
+        engine.factor(kind, p["k_length"], p["k_scale"], p["noise"], JIT, y)
+        g_ell, g_scale, g_noise, alpha = engine.lml_grad()
+        if want_grad:
+            e_ell, e_scale, e_noise, e_alpha = ref.exactgp_log_likelihood_grad(X, y, p, kernel=name, jitter=JIT)
+            sc = max(np.abs(e_ell).max(), abs(e_scale), abs(e_noise))
+            np.testing.assert_allclose(g_ell, e_ell, rtol=1e-8, atol=1e-8 * sc)
+            assert abs(g_scale - e_scale) <= 1e-8 * sc and abs(g_noise - e_noise) <= 1e-8 * sc
+        assert relerr(alpha, e_alpha) < 1e-8
+
+
+def test_c2_rbf_n4096_vs_oracle(engine):
+    N, d, M = 4096, 2, 1024
+    X, y, Xn, p = synthetic_problem(N, d, M, seed=0)
+    eps = np.random.default_rng(2).standard_normal((2, M))
+    check_one_theta(engine, 0, "RBF", X, y, Xn, p, eps, route="inv", want_grad=True)
+
+
+def test_c4_shape_n8192_d3_one_theta_vs_oracle(engine):
+    N, d, M = 8192, 3, 1024
+    X, y, Xn, p = synthetic_problem(N, d, M, seed=0)
+    eps = np.random.default_rng(2).standard_normal((1, M))
+    check_one_theta(engine, 0, "RBF", X, y, Xn, p, eps, route="inv", want_grad=True)
+
+
+def test_c4_sweep_s1000_n8192_d3(engine):
+    """BASELINE.json configs[3] on one GPU: the full 1000-sample sweep once (contexts in flight as predict() runs
+    it), bit-reproducible, 4 spot samples against the oracle, y_means.mean(0) as gp.py:399."""
+    from gpax_amd import _lib
+
+    N, d, M, S = 8192, 3, 1024, 1000
+    X, y, Xn, _ = synthetic_problem(N, d, M, seed=0)
+    th = synthetic_theta_samples(S, d, seed=1)
+    eps = np.random.default_rng(2).standard_normal((S, 1, M))
+    engines = _lib.get_sweep_engines(0)
+    m1, d1, i1 = _lib.concurrent_sweep(engines, X, 0, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, JIT, eps)
+    assert m1.shape == (S, M) and d1.shape == (S, 1, M) and np.all(i1 == 0)
+    assert np.isfinite(m1).all() and np.isfinite(d1).all()
+    # the same table through ONE context (other batch boundaries, no threads): identical sample by sample
+    engine.set_train(X)
+    sub = np.r_[0:40, 960:1000]
+    m2, d2, i2 = engine.predict_sweep(0, th["k_length"][sub], th["k_scale"][sub], th["noise"][sub], y, Xn, False, JIT,
+                                      eps[sub])
+    np.testing.assert_array_equal(m1[sub], m2)
+    np.testing.assert_array_equal(d1[sub], d2)
+    for s in (0, 333, 666, 999):
+        q = {k: v[s] for k, v in th.items()}
+        e_mean, e_draw = ref.predict_one(X, y, Xn, q, eps[s], False, kernel="RBF", jitter=JIT, route="chol")
+        assert relerr(m1[s], e_mean) < 1e-8
+        assert relerr(d1[s], e_draw) < 1e-8
+    assert relerr(m1.mean(0), m1.astype(np.longdouble).mean(0).astype(np.float64)) < 1e-14
+
+
+def test_c3_matern_n16384_vs_oracle(engine):
+    N, d, M = 16384, 2, 1024
+    X, y, Xn, p = synthetic_problem(N, d, M, seed=0)
+    eps = np.random.default_rng(2).standard_normal((1, M))
+    check_one_theta(engine, 1, "Matern", X, y, Xn, p, eps, route="chol", want_grad=False)
+
+
+def test_c5_exact_vigp_on_the_512x512_image():
+    """BASELINE.json configs[4], the exact viGP leg (gpax/models/vigp.py:77-185): N ~ 16384 training pixels, a few
+    SVI steps (each = one device fit step), predict_in_batches over the 262 144 pixels in slices of 1000 with ONE
+    factorisation, compared with the oracle's vigp_predict on a pixel subset."""
+    from gpax_amd import _lib, viGP
+    from gpax_amd.utils import preprocess_sparse_image
+
+    _lib.set_engine(None)
+    img, sparse = synthetic_sparse_image(512, 512, 0.0625, seed=3)
+    X, y, X_full = preprocess_sparse_image(sparse)
+    assert 15000 < X.shape[0] < 18000 and X_full.shape == (512 * 512, 2)
+    m = viGP(2, "Matern", lengthscale_prior_dist=None)
+    m.fit(0, X, y, num_steps=6, step_size=5e-2, progress_bar=False, print_summary=False)
+    assert len(m.loss) == 6 and np.all(np.isfinite(m.loss)) and m.loss[-1] < m.loss[0]
+    theta = m.get_samples()
+    assert set(theta) == {"k_length", "k_scale", "noise"}
+    # a well-conditioned theta for the reconstruction (6 SVI steps from the prior median are not a converged fit)
+    theta = {"k_length": np.array([25.0, 25.0]), "k_scale": np.float64(1.0), "noise": np.float64(1e-2)}
+    mean, var = m.predict_in_batches(0, X_full, batch_size=1000, samples=theta, noiseless=True)
+    assert mean.shape == (512 * 512,) and var.shape == (512 * 512,)
+    assert np.isfinite(mean).all() and np.all(var > 0)
+    rmse = np.sqrt(np.mean((mean.reshape(512, 512) - img) ** 2))
+    assert rmse < 0.05, rmse
+    # slices of one factorisation == predict() on the slice alone (vigp.py:129-151 re-inverts per slice)
+    sl = slice(100_000, 101_000)
+    m1, v1 = m.predict(0, X_full[sl], samples=theta, noiseless=True)
+    np.testing.assert_array_equal(mean[sl], m1)
+    np.testing.assert_array_equal(var[sl], v1)
+    # oracle: viGP.predict = (mean, diag cov) of get_mvn_posterior at the guide median (vigp.py:184-185)
+    idx = np.random.default_rng(5).choice(512 * 512, 256, replace=False)
+    p = {"k_length": theta["k_length"], "k_scale": float(theta["k_scale"]), "noise": float(theta["noise"])}
+    e_mean, e_var = ref.vigp_predict(X, y, X_full[idx], p, noiseless=True, kernel="Matern", jitter=JIT, route="chol")
+    assert relerr(mean[idx], e_mean) < 1e-8
+    assert np.linalg.norm(var[idx] - e_var) / np.linalg.norm(e_var) < 1e-6  # k_ss - |V|^2 cancels ~1e3 : 1 here

@@ -326,3 +326,35 @@ def test_predict_in_batches_groups_of_slices_give_the_same_values(monkeypatch):
     b = m.predict_in_batches(key, Xn, batch_size=10, samples=samples, n=2)
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_predict_of_one_model_does_not_leave_another_model_stale_training_inputs():
+    """ADVICE r1: with a single context, A.predict() re-uploaded X while the engine still recorded B as owner;
+    B's next posterior then ran on A's training inputs.  Engine.set_train now drops the owner itself."""
+    from gpax_amd import ExactGP
+    rng = np.random.default_rng(0)
+    XA, XB = rng.uniform(0, 3, (12, 1)), rng.uniform(0, 3, (12, 1))
+    yA, yB = np.sin(XA[:, 0]), np.cos(2 * XB[:, 0])
+    Xn = np.linspace(0, 3, 7)[:, None]
+    p = {"k_length": np.array([0.7]), "k_scale": 1.1, "noise": 0.05}
+    A, B = ExactGP(1, "RBF"), ExactGP(1, "RBF")
+    A.X_train, A.y_train = A._set_data(XA, yA)
+    B.X_train, B.y_train = B._set_data(XB, yB)
+    mB0, _ = B.get_mvn_posterior(Xn, p)
+    samples = {k: np.asarray([v, v]) for k, v in p.items()}
+    A.predict(0, Xn, samples=samples, n=1)
+    mB1, _ = B.get_mvn_posterior(Xn, p)
+    np.testing.assert_array_equal(mB0, mB1)
+
+
+def test_refit_with_a_mutated_X_array_reuploads_the_training_inputs():
+    from gpax_amd import viGP
+    rng = np.random.default_rng(1)
+    X = np.ascontiguousarray(rng.uniform(0, 3, (10, 1)))
+    y = np.sin(X[:, 0])
+    m = viGP(1, "RBF")
+    m.fit(0, X, y, num_steps=2, progress_bar=False, print_summary=False)
+    eng = _lib.get_engine()
+    X[:] = X + 1.0  # same object, new contents
+    m.fit(0, X, y, num_steps=2, progress_bar=False, print_summary=False)
+    np.testing.assert_array_equal(eng.X, X)

@@ -136,3 +136,21 @@ def test_linreg_recovers_a_line():  # gpax/models/linreg.py:18-56
     p = lr.get_params()
     assert abs(p["alpha"] - 0.7) < 0.1 and abs(p["beta"][0] - 1.9) < 0.1 and 0.01 < p["sigma"] < 0.3
     np.testing.assert_allclose(lr.predict(np.array([[1.0], [2.0]])), [2.6, 4.5], atol=0.15)
+
+
+def test_second_fit_on_the_same_X_uploads_the_new_measured_noise():
+    """the diagonal cache was keyed on object identities, so fit(noise=a); fit(noise=b) on the same X
+    array left `a` on the device.  The key now carries a per-fit counter."""
+    X, y, _ = get_dummy_data()
+    X2 = np.ascontiguousarray(X[:, None], dtype=np.float64)  # _set_data returns this very object
+    eng = _lib.get_engine()
+    seen = []
+    real = eng.set_diag
+    eng.set_diag = lambda v: (seen.append(None if v is None else np.array(v)), real(v))[1]
+    m = MeasuredNoiseGP(1, "RBF")
+    kw = dict(num_warmup=3, num_samples=3, progress_bar=False, print_summary=False)
+    m.fit(get_keys()[0], X2, y, np.full(8, 0.01), **kw)
+    m.fit(get_keys()[0], X2, y, np.full(8, 5.0), **kw)
+    vals = [v[0] for v in seen if v is not None]
+    assert 0.01 in vals and 5.0 in vals
+    assert vals.index(5.0) > vals.index(0.01)

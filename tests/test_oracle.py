@@ -158,3 +158,19 @@ def test_utils_restatement():
         ref.split_in_batches(np.arange(3), 4)  # the reference's bug (utils.py:48), restated
     chunks = ref.split_dict({"a": np.arange(10), "b": np.arange(20).reshape(10, 2)}, 4)
     assert [len(q["a"]) for q in chunks] == [4, 4, 2] and chunks[1]["b"].shape == (4, 2)
+
+
+def test_full_pass_equals_the_separate_restatements():
+    """exactgp_full_pass (one factorisation; used by the full-size GPU parity tests) is the arithmetic of
+    exactgp_log_likelihood + get_mvn_posterior(route='chol') + mvn_sample, bit for bit."""
+    X, y, Xn, p = ref.synthetic_problem(150, 2, 40, seed=11)
+    eps = np.random.default_rng(0).standard_normal((3, 40))
+    for name in ("RBF", "Matern"):
+        lml, mean, cov, draws, alpha = ref.exactgp_full_pass(X, y, Xn, p, eps, False, kernel=name)
+        assert lml == ref.exactgp_log_likelihood(X, y, p, kernel=name)
+        m2, c2 = ref.get_mvn_posterior(X, y, Xn, p, False, kernel=name, route="chol")
+        np.testing.assert_array_equal(mean, m2)
+        np.testing.assert_array_equal(cov, c2)
+        np.testing.assert_array_equal(draws, ref.mvn_sample(m2, c2, eps))
+        K = ref.get_kernel(name)(X, X, p, p["noise"])
+        np.testing.assert_allclose(K @ alpha, y, rtol=1e-9, atol=1e-9)
