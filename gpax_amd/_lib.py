@@ -20,7 +20,8 @@ MAX_DIM = 16
 PROF_GEMM_TRAILING, PROF_GEMM_OTHER, PROF_POTF2, PROF_GRAM = 0, 1, 2, 3
 STAGE_GRAM, STAGE_POTRF, STAGE_FITSTEP, STAGE_POSTERIOR, STAGE_PREDICT = 0, 1, 2, 3, 4
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgpx.so")
+# GPX_LIB: another build of the same ABI (e.g. the AddressSanitizer build, `make -C gpax_amd/csrc asan`)
+_LIB_PATH = os.environ.get("GPX_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgpx.so")
 _lib = None
 
 _dp = C.POINTER(C.c_double)
@@ -49,6 +50,7 @@ def load_library() -> C.CDLL:
     vp = C.c_void_p
     sig = {
         "gpx_init": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "gpx_device_count": (C.c_int, []),
         "gpx_destroy": (None, [vp]),
         "gpx_last_error": (C.c_char_p, [vp]),
         "gpx_device_info": (C.c_int, [vp, C.c_char_p, C.c_int, _ip, C.POINTER(C.c_int64), _ip]),
@@ -80,6 +82,13 @@ def load_library() -> C.CDLL:
         "gpx_mfma_f64_peak": (C.c_int, [vp, _dp]),
         "gpx_gemm_nt": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_double, _dp]),
         "gpx_potrf": (C.c_int, [vp, C.c_int, _dp, _dp, _ip]),
+        "gpx_node_init": (C.c_int, [C.c_int, _ip, C.c_int, C.POINTER(vp)]),
+        "gpx_node_destroy": (None, [vp]),
+        "gpx_node_last_error": (C.c_char_p, [vp]),
+        "gpx_node_info": (C.c_int, [vp, _ip, _ip, _ip, _ip]),
+        "gpx_predict_sweep_multi": (C.c_int, [vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
+                                              _dp, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip, _dp,
+                                              C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
@@ -90,11 +99,11 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "gpx_init gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
+    "gpx_init gpx_device_count gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
     "gpx_factor gpx_lml_grad gpx_lml_grad_diag gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
     "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
-    "gpx_potrf"
+    "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_predict_sweep_multi"
 ).split()
 
 
@@ -445,6 +454,101 @@ class Engine:
         info = C.c_int()
         self._check(self._lib.gpx_potrf(self._ctx, n, _ptr(A), _ptr(L), C.byref(info)), "gpx_potrf")
         return L, info.value
+
+
+class Node:
+    """The GPUs of one node behind ONE process (include/gpx.h gpx_node_*): `inflight` libgpx contexts on each of
+    `devices` plus one RCCL communicator per device.  predict_sweep = Engine.predict_sweep with the posterior
+    samples split in contiguous blocks over the GPUs: ncclBroadcast of the inputs, ncclSend / ncclRecv gather of the
+    results, over xGMI — the vmap axis of ExactGP.predict (gpax/models/gp.py:392-395), SURVEY.md 8e."""
+
+    def __init__(self, devices=None, inflight: Optional[int] = None):
+        self._lib = load_library()
+        self._node = C.c_void_p()
+        if devices is None:
+            devices = list(range(visible_device_count()))
+        elif isinstance(devices, int):
+            devices = list(range(devices))
+        self.devices = [int(v) for v in devices]
+        if not self.devices:
+            raise GpxError("Node: no GPU visible")
+        self.inflight = sweep_inflight() if inflight is None else max(1, int(inflight))
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        rc = self._lib.gpx_node_init(len(self.devices), arr, self.inflight, C.byref(self._node))
+        if rc != 0:
+            msg = self._lib.gpx_node_last_error(self._node).decode() if self._node else "gpx_node_init failed"
+            if self._node:
+                self._lib.gpx_node_destroy(self._node)
+                self._node = C.c_void_p()
+            raise GpxError(f"gpx_node_init(devices={self.devices}) failed ({rc}): {msg}")
+
+    def close(self):
+        if getattr(self, "_node", None):
+            self._lib.gpx_node_destroy(self._node)
+            self._node = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> dict:
+        g, f, t, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        rc = self._lib.gpx_node_info(self._node, C.byref(g), C.byref(f), C.byref(t), C.byref(v))
+        if rc != 0:
+            raise GpxError("gpx_node_info failed")
+        return {"ngpu": g.value, "inflight": f.value, "transport": "rccl" if t.value else "memcpy",
+                "rccl_version": v.value}
+
+    def predict_sweep(self, X, kind: int, ells, scales, noises, yres, Xnew, noiseless: bool, jitter: float,
+                      eps: Optional[np.ndarray], want_var: bool = False, m_slice: int = 0):
+        X = _f64(X)
+        N, d = X.shape
+        ells = _f64(ells)
+        S = ells.shape[0]
+        ells = _f64(ells, (S, n_ell(kind, d)))
+        scales, noises = _f64(scales, (S,)), _f64(noises, (S,))
+        yres = _f64(yres)
+        rows = 1 if yres.ndim == 1 else yres.shape[0]
+        yres = _f64(yres, (rows, N))
+        Xnew = _f64(Xnew)
+        if Xnew.ndim != 2 or Xnew.shape[1] != d:
+            raise ValueError(f"X_new has shape {Xnew.shape}; expected (M, d={d})")
+        M = Xnew.shape[0]
+        n = 0 if eps is None else int(np.asarray(eps).shape[1])
+        eps_c = None if n == 0 else _f64(eps, (S, n, M))
+        means = np.empty((S, M))
+        samples = np.empty((S, n, M))
+        infos = np.zeros(S, dtype=np.int32)
+        vars_ = np.empty((S, M)) if want_var else None
+        rc = self._lib.gpx_predict_sweep_multi(
+            self._node, kind, _ptr(X), N, d, S, _ptr(ells), _ptr(scales), _ptr(noises), _ptr(yres), rows, _ptr(Xnew), M,
+            int(bool(noiseless)), float(jitter), _ptr(eps_c), n, _ptr(means), _ptr(samples) if n else None,
+            infos.ctypes.data_as(_ip), _ptr(vars_), int(m_slice))
+        if rc != 0:
+            raise GpxError(f"gpx_predict_sweep_multi failed ({rc}): {self._lib.gpx_node_last_error(self._node).decode()}")
+        if want_var:
+            return means, samples, infos, vars_
+        return means, samples, infos
+
+
+def visible_device_count() -> int:
+    """HIP devices visible to this process (gpx_device_count)."""
+    return int(load_library().gpx_device_count())
+
+
+_default_node: Optional[Node] = None
+
+
+def get_node(devices=None) -> Node:
+    """Process-wide Node over `devices` (default: every visible GPU), rebuilt when the device list changes."""
+    global _default_node
+    want = None if devices is None else ([int(v) for v in devices] if not isinstance(devices, int)
+                                         else list(range(devices)))
+    if _default_node is None or (want is not None and _default_node.devices != want):
+        _default_node = Node(want)
+    return _default_node
 
 
 _default_engine: Optional[Engine] = None

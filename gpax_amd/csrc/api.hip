@@ -191,8 +191,9 @@ int dev_grad(gpx_ctx* ctx, const BatchPlan& bp) {
 }
 int dev_grad(gpx_ctx* ctx) { return dev_grad(ctx, make_plan(ctx, 1, 0, false)); }
 
-// Xnew: (T, M, d) — T = ctx->T task-specific test sets (T = 1: the usual (M, d))
-int set_xnew(gpx_ctx* ctx, const double* Xnew, int M) {
+// Xnew: (T, M, d) — T = ctx->T task-specific test sets (T = 1: the usual (M, d)).
+// on_device: Xnew already lives on this context's GPU (node-level sweep: it arrived by RCCL broadcast).
+int set_xnew(gpx_ctx* ctx, const double* Xnew, int M, bool on_device = false) {
   if (M < 1) return bad_arg(ctx, "M must be >= 1");
   ctx->M = M;
   ctx->Mp = round_up(M, TILE);
@@ -204,7 +205,9 @@ int set_xnew(gpx_ctx* ctx, const double* Xnew, int M) {
   GPX_TRY(ensure(ctx, ctx->mean, (size_t)ctx->Mp * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->var, (size_t)ctx->Mp * sizeof(double)));
   const size_t xb = (size_t)ctx->T * M * ctx->d * sizeof(double);
-  if (xb > (64u << 10)) { // large X_new (predict_in_batches grids): through page-locked staging, see DESIGN.md 10
+  if (on_device) {
+    GPX_HIP(ctx, hipMemcpyAsync(ctx->Xnew.d(), Xnew, xb, hipMemcpyDeviceToDevice, ctx->stream));
+  } else if (xb > (64u << 10)) { // large X_new (predict_in_batches grids): through page-locked staging, see DESIGN.md 10
     GPX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the previous use of the staging buffer has been consumed
     GPX_HIP(ctx, ctx->pin_x.ensure(xb));
     std::memcpy(ctx->pin_x.p, Xnew, xb);
@@ -582,7 +585,38 @@ int gpx_init(int device, gpx_ctx** out) {
   {
     int lo = 0, hi = 0; // numerically lower = higher priority
     GPX_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, lo));
+    // CU reservation: mask bit i is CU (i / 8) of XCD (i % 8) on gfx950 (tools/exp/cumask_probe.hip: bits 0..7 =
+    // CU 0 of each of the 8 XCDs), so reserving a multiple of 8 bits keeps the XCDs balanced.
+    // MEASURED AND REJECTED as a default (profiles/r02/cu_reserve.md): with 8 CUs reserved the potf2 launches drop
+    // from 171 to 50 us each inside the pipeline, but a masked queue still gets its workgroups balanced over the 32
+    // shader engines, so the engines that lost a CU (7 of 8 left) set the pace of the trailing update: 28.7 -> 32.4 ms
+    // per factorisation (roofline 0.69 -> 0.61), potrf 31.4 -> 32.5 ms.  Kept behind GPX_CU_RESERVE for experiments.
+    int reserve = 0;
+    if (const char* e = getenv("GPX_CU_RESERVE")) reserve = atoi(e);
+    const int ncu = ctx->prop.multiProcessorCount;
+    reserve = (reserve / 8) * 8;
+    if (reserve < 0 || reserve > ncu / 4 || ncu % 32 != 0) reserve = 0;
+    if (reserve > 0) {
+      const int words = ncu / 32;
+      std::vector<uint32_t> m_main((size_t)words, 0xffffffffu), m_res((size_t)words, 0u);
+      for (int b = 0; b < reserve; ++b) {
+        m_main[(size_t)(b / 32)] &= ~(1u << (b % 32));
+        m_res[(size_t)(b / 32)] |= (1u << (b % 32));
+      }
+      if (hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)words, m_main.data()) != hipSuccess ||
+          hipExtStreamCreateWithCUMask(&ctx->rstream, (uint32_t)words, m_res.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
+        ctx->stream = ctx->rstream = nullptr;
+        reserve = 0;
+      } else {
+        GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evR0, hipEventDisableTiming));
+        GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evR1, hipEventDisableTiming));
+      }
+    }
+    ctx->cu_reserved = reserve;
+    if (!ctx->stream) GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, lo));
     GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->pstream, hipStreamNonBlocking, hi));
     ctx->s = ctx->stream;
   }
@@ -591,6 +625,11 @@ int gpx_init(int device, gpx_ctx** out) {
   GPX_TRY(ensure(ctx, ctx->scal, 8192));
   GPX_HIP(ctx, hipMemsetAsync(ctx->scal.p, 0, 8192, ctx->stream));
   return 0;
+}
+
+int gpx_device_count(void) {
+  int count = 0;
+  return (hipGetDeviceCount(&count) == hipSuccess) ? count : 0;
 }
 
 void gpx_destroy(gpx_ctx* ctx) {
@@ -613,6 +652,9 @@ void gpx_destroy(gpx_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->evP) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->evU) (void)hipEventDestroy(e);
+    if (ctx->evR0) (void)hipEventDestroy(ctx->evR0);
+    if (ctx->evR1) (void)hipEventDestroy(ctx->evR1);
+    if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
     if (ctx->pstream) (void)hipStreamDestroy(ctx->pstream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   }
@@ -669,7 +711,7 @@ int gpx_gram(gpx_ctx* ctx, int kind, const double* X, int n, const double* Z, in
   return 0;
 }
 
-int gpx_set_train_tasks(gpx_ctx* ctx, const double* X, int T, int N, int d) {
+static int set_train_impl(gpx_ctx* ctx, const double* X, int T, int N, int d, bool on_device) {
   if (!ctx || ctx->device < 0) return -1;
   if (!X) return bad_arg(ctx, "null X");
   if (N < 1) return bad_arg(ctx, "N must be >= 1");
@@ -687,12 +729,16 @@ int gpx_set_train_tasks(gpx_ctx* ctx, const double* X, int T, int N, int d) {
   GPX_TRY(ensure(ctx, ctx->K, (size_t)ctx->Np * ctx->ldk * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->Linv, (size_t)(ctx->Np / TILE) * TILE * TILE * sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->yres, (size_t)N * sizeof(double)));
-  GPX_HIP(ctx, hipMemcpyAsync(ctx->X.d(), X, (size_t)T * N * d * sizeof(double), hipMemcpyHostToDevice,
-                              ctx->stream));
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->X.d(), X, (size_t)T * N * d * sizeof(double),
+                              on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->factored = false;
   ctx->have_post = false;
   return 0;
+}
+
+int gpx_set_train_tasks(gpx_ctx* ctx, const double* X, int T, int N, int d) {
+  return set_train_impl(ctx, X, T, N, d, false);
 }
 
 int gpx_set_train(gpx_ctx* ctx, const double* X, int N, int d) { return gpx_set_train_tasks(ctx, X, 1, N, d); }
@@ -1211,3 +1257,45 @@ int gpx_potrf(gpx_ctx* ctx, int n, const double* A, double* L, int* info) {
 }
 
 } // extern "C"
+
+// ---- device-resident I/O variant of gpx_predict_sweep (node-level sweep, multi.hip) -----------------------------
+// Every d_* pointer lives on ctx's device (inputs arrived by RCCL broadcast, outputs are gathered by RCCL); the
+// theta tables are host arrays.  Enqueues on ctx->stream and returns; the caller synchronises.  d_infos receives
+// 2 ints per sample (train pivot, cov pivot) exactly as gpx_predict_sweep decodes them.
+namespace gpx {
+int sweep_device_io(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales, const double* noises,
+                    const double* d_X, int N, int d, const double* d_yres, int yres_rows, const double* d_Xnew, int M,
+                    int noiseless, double jitter, const double* d_eps, int n, double* d_means, double* d_samples,
+                    int* d_infos, double* d_vars, int m_slice) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (S < 1 || n < 0 || !ells || !scales || !noises || !d_yres || !d_Xnew || !d_means || !d_infos)
+    return bad_arg(ctx, "sweep_device_io arguments");
+  if (yres_rows != 1 && yres_rows != S) return bad_arg(ctx, "yres_rows must be 1 or S");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  if (d_X != nullptr) GPX_TRY(set_train_impl(ctx, d_X, 1, N, d, true));
+  if (ctx->N != N || ctx->d != d) return bad_arg(ctx, "training set mismatch");
+  GPX_TRY(set_xnew(ctx, d_Xnew, M, true));
+  if (yres_rows == 1)
+    GPX_HIP(ctx, hipMemcpyAsync(ctx->yres.d(), d_yres, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  GPX_HIP(ctx, hipMemsetAsync(d_infos, 0, (size_t)2 * S * sizeof(int), ctx->stream));
+  SweepIO io;
+  io.kind = kind;
+  io.S = S;
+  io.n = n;
+  io.noiseless = noiseless;
+  io.jitter = jitter;
+  io.ells = ells;
+  io.scales = scales;
+  io.noises = noises;
+  io.dYres = (yres_rows == 1) ? nullptr : d_yres;
+  io.dEps = n > 0 ? d_eps : nullptr;
+  io.dMeans = d_means;
+  io.dSamples = n > 0 ? d_samples : nullptr;
+  io.dInfos = d_infos;
+  io.dVars = d_vars;
+  io.m_slice = m_slice;
+  return sweep_core(ctx, io);
+}
+int ctx_cov_block(const gpx_ctx* ctx) { return ctx->cM; }
+} // namespace gpx
+

@@ -140,6 +140,12 @@ struct gpx_ctx {
   hipStream_t stream = nullptr;  // main stream (API copies, trailing updates)
   hipStream_t pstream = nullptr; // high-priority panel stream (lookahead)
   hipStream_t s = nullptr;       // stream the launch helpers currently target
+  // CU reservation (GPX_CU_RESERVE = multiple of 8, default 0 = off; see gpx_init): the main stream's CU mask leaves
+  // these CUs out and `rstream` may ONLY use them, so the single-workgroup diagonal-block factorisations of the panel
+  // chain do not share a CU (MFMA pipe, LDS) with two resident trailing-update workgroups
+  hipStream_t rstream = nullptr;
+  int cu_reserved = 0;
+  hipEvent_t evR0 = nullptr, evR1 = nullptr;
   std::vector<hipEvent_t> evP, evU; // per-outer-block panel / next-panel-update events
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
@@ -328,6 +334,12 @@ int launch_grad_contract(gpx_ctx* ctx, const KernelParams& kp, const double* dX,
 int launch_grad_reduce(gpx_ctx* ctx, const double* dpart, int nblocks, int nvals, double* dout,
                        int batch = 1, int64_t out_bs = 0);
 void sgp_release(gpx_ctx* ctx);
+// api.hip: gpx_predict_sweep with device-resident inputs / outputs (node-level sweep, multi.hip)
+int sweep_device_io(gpx_ctx* ctx, int kind, int S, const double* ells, const double* scales, const double* noises,
+                    const double* d_X, int N, int d, const double* d_yres, int yres_rows, const double* d_Xnew, int M,
+                    int noiseless, double jitter, const double* d_eps, int n, double* d_means, double* d_samples,
+                    int* d_infos, double* d_vars, int m_slice);
+int ctx_cov_block(const gpx_ctx* ctx);
 int launch_add_mean(gpx_ctx* ctx, double* ddraws, int64_t ld, int n, int M, const double* dmean,
                     int batch = 1, int64_t d_bs = 0, int64_t mean_bs = 0);
 

@@ -1,0 +1,395 @@
+// multi.hip — the predictive sweep over the GPUs of ONE node from ONE process (include/gpx.h: gpx_node_*,
+// gpx_predict_sweep_multi).
+//
+// Reference seam: the vmap over posterior samples in ExactGP.predict (gpax/models/gp.py:392-395) is the only axis
+// of the exact-GP path that shards: the S per-theta pipelines are independent given
+// (X_train, y_res, X_new), and y_means.mean(0) (gp.py:399) is the only cross-sample reduction.
+//
+//   root GPU   : one H2D upload of [X | X_new | y_res | eps] (page-locked staging)
+//   RCCL / xGMI: ncclBroadcast of that payload to every GPU of the node            (KBs .. a few MB)
+//   every GPU  : its contiguous block of the S samples through the batched device pipeline (sweep_core, api.hip),
+//                split again over the contexts in flight on that GPU; one host thread per context
+//   RCCL / xGMI: ncclSend / ncclRecv (one group) of every GPU's [means | draws | vars | pivots] block to the root
+//   root GPU   : one D2H download
+// No collective sits inside the sweep.  The theta tables stay on the host: every context builds the device table of
+// its own samples from them (they are host data of this very process).
+//
+// RCCL is bound at run time (dlopen of librccl.so.1: whichever copy the process already holds — e.g. PyTorch's —
+// or ROCm's), so libgpx has no link-time dependency on it and a 1-GPU user never loads it ... except through this
+// entry.  GPX_NODE_TRANSPORT=memcpy replaces the two RCCL steps by hipMemcpyPeerAsync; it exists so that the
+// sharding / threading logic can be exercised on a box with a single GPU (the same device listed twice, which RCCL
+// refuses) and is never selected implicitly.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <thread>
+
+#include "common.h"
+
+using namespace gpx;
+
+namespace {
+
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+};
+
+bool load_rccl(RcclApi& r, std::string& err) {
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (r.handle) break;
+  }
+  if (!r.handle) {
+    err = std::string("cannot load RCCL (librccl.so.1): ") + dlerror();
+    return false;
+  }
+#define GPX_SYM(field, name)                                              \
+  r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name));   \
+  if (!r.field) {                                                         \
+    err = std::string("RCCL symbol missing: ") + name;                    \
+    return false;                                                         \
+  }
+  GPX_SYM(CommInitAll, "ncclCommInitAll")
+  GPX_SYM(CommDestroy, "ncclCommDestroy")
+  GPX_SYM(GetErrorString, "ncclGetErrorString")
+  GPX_SYM(Broadcast, "ncclBroadcast")
+  GPX_SYM(Send, "ncclSend")
+  GPX_SYM(Recv, "ncclRecv")
+  GPX_SYM(GroupStart, "ncclGroupStart")
+  GPX_SYM(GroupEnd, "ncclGroupEnd")
+  GPX_SYM(GetVersion, "ncclGetVersion")
+#undef GPX_SYM
+  return true;
+}
+
+struct NodeDev {
+  int device = -1;
+  std::vector<gpx_ctx*> ctxs; // contexts in flight on this GPU
+  hipStream_t cs = nullptr;   // communication / staging stream
+  DevBuf payload;             // [X | X_new | y_res | eps] as broadcast
+  DevBuf out;                 // this GPU's result block (the root's holds every block: the gather target)
+};
+
+// contiguous block [start, stop) of part `r` out of `parts` over S items, sizes differing by at most 1
+inline void shard_range(int S, int r, int parts, int* lo, int* hi) {
+  const int base = S / parts, rem = S % parts;
+  *lo = r * base + (r < rem ? r : rem);
+  *hi = *lo + base + (r < rem ? 1 : 0);
+}
+
+// result block of c samples, in doubles: [means c*M | draws c*n*M | vars c*M | pivots: 2c ints in c doubles]
+struct BlockLayout {
+  int64_t means, draws, vars, infos, total;
+  BlockLayout(int c, int n, int M) {
+    means = 0;
+    draws = (int64_t)c * M;
+    vars = draws + (int64_t)c * n * M;
+    infos = vars + (int64_t)c * M;
+    total = infos + c;
+  }
+};
+
+} // namespace
+
+struct gpx_node {
+  std::vector<NodeDev> devs;
+  std::vector<ncclComm_t> comms;
+  RcclApi rccl;
+  bool use_rccl = true;
+  int rccl_version = 0;
+  std::string err;
+  PinBuf pin_in, pin_out;
+  int64_t sweeps = 0;
+};
+
+namespace {
+
+int node_fail(gpx_node* nd, const std::string& msg) {
+  nd->err = msg;
+  return -2;
+}
+
+#define NODE_HIP(nd, expr)                                                                        \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) return node_fail((nd), std::string(#expr ": ") + hipGetErrorString(_e)); \
+  } while (0)
+#define NODE_NCCL(nd, expr)                                                                              \
+  do {                                                                                                   \
+    ncclResult_t _r = (expr);                                                                            \
+    if (_r != ncclSuccess) return node_fail((nd), std::string(#expr ": ") + (nd)->rccl.GetErrorString(_r)); \
+  } while (0)
+
+} // namespace
+
+extern "C" {
+
+int gpx_node_init(int ngpu, const int* devices, int inflight, gpx_node** out) {
+  if (!out) return -1;
+  gpx_node* nd = new gpx_node();
+  *out = nd; // returned even on failure so the caller can read gpx_node_last_error
+  if (ngpu < 1) {
+    nd->err = "bad argument: ngpu must be >= 1";
+    return -1;
+  }
+  if (inflight < 1) inflight = 1;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return node_fail(nd, "no HIP device available");
+  const char* tr = getenv("GPX_NODE_TRANSPORT");
+  nd->use_rccl = !(tr && std::string(tr) == "memcpy");
+  nd->devs.resize((size_t)ngpu);
+  std::vector<int> devlist((size_t)ngpu);
+  for (int r = 0; r < ngpu; ++r) {
+    const int dev = devices ? devices[r] : r;
+    if (dev < 0 || dev >= count) {
+      nd->err = "bad argument: device ordinal out of range";
+      return -1;
+    }
+    devlist[(size_t)r] = dev;
+    NodeDev& D = nd->devs[(size_t)r];
+    D.device = dev;
+    for (int c = 0; c < inflight; ++c) {
+      gpx_ctx* ctx = nullptr;
+      const int rc = gpx_init(dev, &ctx);
+      if (rc != 0) {
+        nd->err = std::string("gpx_init failed: ") + gpx_last_error(ctx);
+        gpx_destroy(ctx);
+        return rc;
+      }
+      D.ctxs.push_back(ctx);
+    }
+    NODE_HIP(nd, hipSetDevice(dev));
+    NODE_HIP(nd, hipStreamCreateWithFlags(&D.cs, hipStreamNonBlocking));
+  }
+  if (nd->use_rccl) {
+    if (!load_rccl(nd->rccl, nd->err)) return -3;
+    (void)nd->rccl.GetVersion(&nd->rccl_version);
+    nd->comms.resize((size_t)ngpu);
+    NODE_NCCL(nd, nd->rccl.CommInitAll(nd->comms.data(), ngpu, devlist.data()));
+  } else {
+    // peer copies between distinct devices: enable direct access where the topology allows it (xGMI)
+    for (int a = 0; a < ngpu; ++a)
+      for (int b = 0; b < ngpu; ++b)
+        if (devlist[(size_t)a] != devlist[(size_t)b]) {
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, devlist[(size_t)a], devlist[(size_t)b]) == hipSuccess && can) {
+            (void)hipSetDevice(devlist[(size_t)a]);
+            (void)hipDeviceEnablePeerAccess(devlist[(size_t)b], 0); // "already enabled" is fine
+            (void)hipGetLastError();
+          }
+        }
+  }
+  return 0;
+}
+
+void gpx_node_destroy(gpx_node* nd) {
+  if (!nd) return;
+  for (size_t r = 0; r < nd->devs.size(); ++r) {
+    NodeDev& D = nd->devs[r];
+    if (D.device < 0) continue;
+    (void)hipSetDevice(D.device);
+    if (D.cs) (void)hipStreamSynchronize(D.cs);
+    if (nd->use_rccl && r < nd->comms.size() && nd->comms[r]) (void)nd->rccl.CommDestroy(nd->comms[r]);
+    for (gpx_ctx* c : D.ctxs) gpx_destroy(c);
+    D.payload.release();
+    D.out.release();
+    if (D.cs) (void)hipStreamDestroy(D.cs);
+  }
+  nd->pin_in.release();
+  nd->pin_out.release();
+  delete nd; // the RCCL handle stays loaded for the life of the process (other users may share it)
+}
+
+const char* gpx_node_last_error(const gpx_node* nd) { return nd ? nd->err.c_str() : "null node"; }
+
+int gpx_node_info(const gpx_node* nd, int* ngpu, int* inflight, int* transport_rccl, int* rccl_version) {
+  if (!nd || nd->devs.empty()) return -1;
+  if (ngpu) *ngpu = (int)nd->devs.size();
+  if (inflight) *inflight = (int)nd->devs[0].ctxs.size();
+  if (transport_rccl) *transport_rccl = nd->use_rccl ? 1 : 0;
+  if (rccl_version) *rccl_version = nd->rccl_version;
+  return 0;
+}
+
+int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int d, int S, const double* ells,
+                            const double* scales, const double* noises, const double* yres, int yres_rows,
+                            const double* Xnew, int M, int noiseless, double jitter, const double* eps, int n,
+                            double* means, double* samples, int* infos, double* vars, int m_slice) {
+  if (!nd || nd->devs.empty()) return -1;
+  if (S < 0 || n < 0) return node_fail(nd, "bad argument: negative count"), -1;
+  if (S == 0) return 0;
+  if (!X || !ells || !scales || !noises || !yres || !Xnew || !means) return node_fail(nd, "bad argument: null pointer"), -1;
+  if (N < 1 || M < 1 || d < 1 || d > GPX_MAX_DIM) return node_fail(nd, "bad argument: sizes"), -1;
+  if (n > 0 && (!eps || !samples)) return node_fail(nd, "bad argument: eps/samples required when n > 0"), -1;
+  if (yres_rows != 1 && yres_rows != S) return node_fail(nd, "bad argument: yres_rows must be 1 or S"), -1;
+  const int G = (int)nd->devs.size();
+  const int ne = d + (kind == GPX_KERNEL_PERIODIC ? 1 : 0);
+
+  // ---- 1. payload: one upload to the root GPU, one broadcast over xGMI ----------------------------------------
+  const int64_t o_X = 0, o_Xn = o_X + (int64_t)N * d, o_y = o_Xn + (int64_t)M * d,
+                o_eps = o_y + (int64_t)yres_rows * N, p_total = o_eps + (int64_t)S * n * M;
+  const size_t p_bytes = (size_t)p_total * sizeof(double);
+  NodeDev& root = nd->devs[0];
+  NODE_HIP(nd, hipSetDevice(root.device));
+  NODE_HIP(nd, hipStreamSynchronize(root.cs)); // previous use of the staging buffers is over
+  NODE_HIP(nd, nd->pin_in.ensure(p_bytes));
+  double* hp = nd->pin_in.d();
+  std::memcpy(hp + o_X, X, (size_t)N * d * sizeof(double));
+  std::memcpy(hp + o_Xn, Xnew, (size_t)M * d * sizeof(double));
+  std::memcpy(hp + o_y, yres, (size_t)yres_rows * N * sizeof(double));
+  if (n > 0) std::memcpy(hp + o_eps, eps, (size_t)S * n * M * sizeof(double));
+  for (int r = 0; r < G; ++r) {
+    NODE_HIP(nd, hipSetDevice(nd->devs[(size_t)r].device));
+    NODE_HIP(nd, nd->devs[(size_t)r].payload.ensure(p_bytes));
+  }
+  NODE_HIP(nd, hipSetDevice(root.device));
+  NODE_HIP(nd, hipMemcpyAsync(root.payload.p, hp, p_bytes, hipMemcpyHostToDevice, root.cs));
+  if (nd->use_rccl) {
+    NODE_NCCL(nd, nd->rccl.GroupStart());
+    for (int r = 0; r < G; ++r) {
+      NodeDev& D = nd->devs[(size_t)r];
+      NODE_NCCL(nd, nd->rccl.Broadcast(D.payload.p, D.payload.p, (size_t)p_total, ncclDouble, 0, nd->comms[(size_t)r], D.cs));
+    }
+    NODE_NCCL(nd, nd->rccl.GroupEnd());
+  } else {
+    for (int r = 1; r < G; ++r) {
+      NodeDev& D = nd->devs[(size_t)r];
+      NODE_HIP(nd, hipMemcpyPeerAsync(D.payload.p, D.device, root.payload.p, root.device, p_bytes, root.cs));
+    }
+  }
+  for (int r = 0; r < G; ++r) {
+    NODE_HIP(nd, hipSetDevice(nd->devs[(size_t)r].device));
+    NODE_HIP(nd, hipStreamSynchronize(nd->devs[(size_t)r].cs));
+  }
+  NODE_HIP(nd, hipSetDevice(root.device));
+  NODE_HIP(nd, hipStreamSynchronize(root.cs));
+
+  // ---- 2. every GPU sweeps its block of samples; contexts in flight split it again -------------------------------
+  std::vector<int> lo((size_t)G), hi((size_t)G);
+  std::vector<int64_t> boff((size_t)G + 1, 0); // block offsets (doubles) inside the root's gather buffer
+  for (int r = 0; r < G; ++r) {
+    shard_range(S, r, G, &lo[(size_t)r], &hi[(size_t)r]);
+    boff[(size_t)r + 1] = boff[(size_t)r] + BlockLayout(hi[(size_t)r] - lo[(size_t)r], n, M).total;
+  }
+  for (int r = 0; r < G; ++r) {
+    NodeDev& D = nd->devs[(size_t)r];
+    NODE_HIP(nd, hipSetDevice(D.device));
+    const int64_t need = (r == 0) ? boff[(size_t)G] : BlockLayout(hi[(size_t)r] - lo[(size_t)r], n, M).total;
+    NODE_HIP(nd, D.out.ensure((size_t)(need > 0 ? need : 1) * sizeof(double)));
+  }
+  // below N ~ 3000 one context's batched sweep already fills a GPU: one context per GPU there
+  const int per_gpu = (N < 3000) ? 1 : (int)root.ctxs.size();
+  std::vector<std::thread> threads;
+  std::vector<int> rcs((size_t)G * per_gpu, 0);
+  std::vector<int> cblock((size_t)G * per_gpu, M);
+  for (int r = 0; r < G; ++r) {
+    const int c_r = hi[(size_t)r] - lo[(size_t)r];
+    if (c_r <= 0) continue;
+    const BlockLayout bl(c_r, n, M);
+    NodeDev& D = nd->devs[(size_t)r];
+    const int parts = per_gpu < c_r ? per_gpu : c_r;
+    for (int c = 0; c < parts; ++c) {
+      int slo, shi;
+      shard_range(c_r, c, parts, &slo, &shi);
+      gpx_ctx* ctx = D.ctxs[(size_t)c];
+      double* blk = D.out.d(); // block r starts at offset 0 of its own buffer (the root's block is block 0 of the gather buffer)
+      const double* pl = D.payload.d();
+      const int g0 = lo[(size_t)r] + slo; // first global sample of this context
+      const int cnt = shi - slo;
+      int* rc_slot = &rcs[(size_t)r * per_gpu + c];
+      int* cb_slot = &cblock[(size_t)r * per_gpu + c];
+      threads.emplace_back([=]() {
+        int rc = sweep_device_io(ctx, kind, cnt, ells + (int64_t)g0 * ne, scales + g0, noises + g0, pl + o_X, N, d,
+                                 pl + o_y + (yres_rows == 1 ? 0 : (int64_t)g0 * N), yres_rows == 1 ? 1 : cnt, pl + o_Xn,
+                                 M, noiseless, jitter, n > 0 ? pl + o_eps + (int64_t)g0 * n * M : nullptr, n,
+                                 blk + bl.means + (int64_t)slo * M, n > 0 ? blk + bl.draws + (int64_t)slo * n * M : nullptr,
+                                 reinterpret_cast<int*>(blk + bl.infos) + 2 * slo, vars ? blk + bl.vars + (int64_t)slo * M : nullptr,
+                                 m_slice);
+        if (rc == 0) rc = gpx_synchronize(ctx);
+        *rc_slot = rc;
+        *cb_slot = ctx_cov_block(ctx);
+      });
+    }
+  }
+  for (std::thread& t : threads) t.join();
+  for (int r = 0; r < G; ++r)
+    for (int c = 0; c < per_gpu; ++c)
+      if (rcs[(size_t)r * per_gpu + c] != 0) {
+        nd->err = std::string("sweep failed on device ") + std::to_string(nd->devs[(size_t)r].device) + ": " +
+                  gpx_last_error(nd->devs[(size_t)r].ctxs[(size_t)c]);
+        return rcs[(size_t)r * per_gpu + c];
+      }
+
+  // ---- 3. gather every block on the root GPU (one RCCL group), one download ---------------------------------------
+  if (nd->use_rccl) {
+    NODE_NCCL(nd, nd->rccl.GroupStart());
+    for (int r = 1; r < G; ++r) {
+      const int64_t cnt = boff[(size_t)r + 1] - boff[(size_t)r];
+      if (cnt <= 0) continue;
+      NodeDev& D = nd->devs[(size_t)r];
+      NODE_NCCL(nd, nd->rccl.Recv(root.out.d() + boff[(size_t)r], (size_t)cnt, ncclDouble, r, nd->comms[0], root.cs));
+      NODE_NCCL(nd, nd->rccl.Send(D.out.p, (size_t)cnt, ncclDouble, 0, nd->comms[(size_t)r], D.cs));
+    }
+    NODE_NCCL(nd, nd->rccl.GroupEnd());
+    for (int r = 1; r < G; ++r) {
+      NODE_HIP(nd, hipSetDevice(nd->devs[(size_t)r].device));
+      NODE_HIP(nd, hipStreamSynchronize(nd->devs[(size_t)r].cs));
+    }
+  } else {
+    for (int r = 1; r < G; ++r) {
+      const int64_t cnt = boff[(size_t)r + 1] - boff[(size_t)r];
+      if (cnt <= 0) continue;
+      NodeDev& D = nd->devs[(size_t)r];
+      NODE_HIP(nd, hipMemcpyPeerAsync(root.out.d() + boff[(size_t)r], root.device, D.out.p, D.device,
+                                      (size_t)cnt * sizeof(double), root.cs));
+    }
+  }
+  NODE_HIP(nd, hipSetDevice(root.device));
+  const size_t o_bytes = (size_t)boff[(size_t)G] * sizeof(double);
+  NODE_HIP(nd, nd->pin_out.ensure(o_bytes));
+  NODE_HIP(nd, hipMemcpyAsync(nd->pin_out.p, root.out.p, o_bytes, hipMemcpyDeviceToHost, root.cs));
+  NODE_HIP(nd, hipStreamSynchronize(root.cs));
+  const double* ho = nd->pin_out.d();
+  const int cM = cblock[0];
+  for (int r = 0; r < G; ++r) {
+    const int c_r = hi[(size_t)r] - lo[(size_t)r];
+    if (c_r <= 0) continue;
+    const BlockLayout bl(c_r, n, M);
+    const double* blk = ho + boff[(size_t)r];
+    const int g0 = lo[(size_t)r];
+    std::memcpy(means + (int64_t)g0 * M, blk + bl.means, (size_t)c_r * M * sizeof(double));
+    if (n > 0) std::memcpy(samples + (int64_t)g0 * n * M, blk + bl.draws, (size_t)c_r * n * M * sizeof(double));
+    if (vars) std::memcpy(vars + (int64_t)g0 * M, blk + bl.vars, (size_t)c_r * M * sizeof(double));
+    const int* hin = reinterpret_cast<const int*>(blk + bl.infos);
+    for (int s = 0; s < c_r; ++s) { // decode the pivots exactly as gpx_predict_sweep does
+      int it = hin[2 * s], ic = hin[2 * s + 1];
+      if (it > N) it = 0;
+      if (ic > cM) ic = 0;
+      const int code = it != 0 ? it : (ic != 0 ? -ic : 0);
+      const int gs = g0 + s;
+      if (infos) infos[gs] = code;
+      if (it != 0)
+        for (int a = 0; a < M; ++a) {
+          means[(int64_t)gs * M + a] = NAN;
+          if (vars) vars[(int64_t)gs * M + a] = NAN;
+        }
+      if (code != 0 && n > 0)
+        for (int64_t t = 0; t < (int64_t)n * M; ++t) samples[(int64_t)gs * n * M + t] = NAN;
+    }
+  }
+  nd->sweeps += 1;
+  return 0;
+}
+
+} // extern "C"

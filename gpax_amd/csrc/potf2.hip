@@ -419,13 +419,29 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS_BYTES));
     ctx->func_attr_mask |= ATTR_POTF2_COLUMN;
   }
-  // algorithmic flops: factor n^3/3 + triangular inverse n^3/3
-  ProfScope ps(ctx, GPX_PROF_POTF2, nb * 2.0 * PB * (double)PB * PB / 3.0);
-  if (use_tile)
-    potf2_tile_kernel<<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
-  else
-    potf2_inv_kernel<<<nb, 256, POTF2_LDS_BYTES, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
+  // Few workgroups (the single-theta pipeline, small batches): run on the reserved CUs through `rstream`, fenced
+  // by events into the stream the chain lives on, so the block factorisation has a CU to itself.
+  hipStream_t chain = ctx->s;
+  const bool reserved = ctx->rstream != nullptr && nb <= ctx->cu_reserved;
+  if (reserved) {
+    GPX_HIP(ctx, hipEventRecord(ctx->evR0, chain));
+    GPX_HIP(ctx, hipStreamWaitEvent(ctx->rstream, ctx->evR0, 0));
+    ctx->s = ctx->rstream;
+  }
+  {
+    // algorithmic flops: factor n^3/3 + triangular inverse n^3/3
+    ProfScope ps(ctx, GPX_PROF_POTF2, nb * 2.0 * PB * (double)PB * PB / 3.0);
+    if (use_tile)
+      potf2_tile_kernel<<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
+    else
+      potf2_inv_kernel<<<nb, 256, POTF2_LDS_BYTES, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
+  }
+  ctx->s = chain;
   GPX_HIP(ctx, hipGetLastError());
+  if (reserved) {
+    GPX_HIP(ctx, hipEventRecord(ctx->evR1, ctx->rstream));
+    GPX_HIP(ctx, hipStreamWaitEvent(chain, ctx->evR1, 0));
+  }
   return 0;
 }
 } // namespace gpx

@@ -9,8 +9,9 @@ What changed underneath:
   * get_mvn_posterior (gp.py:253-277) uses POTRF + TRSM instead of the explicit inverse;
   * predict (gp.py:351-399) runs the vmap over posterior samples as the device-resident sweep
     gpx_predict_sweep (one theta in flight, nothing S*N*N is materialised);
-  * priors are gpax_amd.infer.dist objects (NumPyro is not a dependency); `kernel_prior` /
-    `noise_prior` (callables that run numpyro.sample) are not supported;
+  * priors are gpax_amd.infer.dist objects (NumPyro is not a dependency); `kernel_prior` / `noise_prior` /
+    `mean_fn_prior` callables are written with gpax_amd.sample / plate instead of numpyro.sample / plate and are
+    traced once for their sites (infer/primitives.py) — or given declaratively as a dict name -> distribution;
   * rng_key is an opaque seed (utils.rng_from_key); JAX threefry streams are not reproduced.
 """
 from __future__ import annotations
@@ -24,6 +25,7 @@ import numpy as np
 from .. import _lib
 from ..infer import dist
 from ..infer.nuts import run_nuts
+from ..infer.primitives import trace_sites
 from ..kernels.kernels import kernel_name
 from ..utils import threefry as _threefry
 from ..utils.utils import rng_from_key, split_in_batches
@@ -94,12 +96,16 @@ class ExactGP:
         input_dim: number of input (feature) dimensions
         kernel: 'RBF' or 'Matern' (or gpax_amd.kernels.RBFKernel / MaternKernel)
         mean_fn: optional deterministic mean function  mean_fn(X) or mean_fn(X, params)
-        kernel_prior: not supported on this path (NumPyro-program callable in the reference)
-        mean_fn_prior: dict name -> distribution (or a callable returning one) for the mean-function
-            parameters; the reference takes a callable that runs numpyro.sample
-        noise_prior: not supported (deprecated in the reference)
+        kernel_prior: custom priors over the kernel parameters: a function that calls gpax_amd.sample(name, dist)
+            (inside gpax_amd.plate for vector sites) and returns {"k_length": ..., "k_scale": ...} — the reference's
+            numpyro.sample callables with the import swapped — or a dict name -> distribution
+        mean_fn_prior: the same for the parameters of mean_fn
+        noise_prior: the same for the noise variance (deprecated in the reference in favour of noise_prior_dist)
         noise_prior_dist: prior on the noise variance (default LogNormal(0, 1))
         lengthscale_prior_dist: prior on the lengthscales (default LogNormal(0, 1))
+        mean_fn_grad: optional mean_fn_grad(X, params) -> {name: d mean / d name (N,)}; without it the derivative
+            of the mean function w.r.t. its parameters is taken by complex-step differentiation (exact to rounding
+            for the analytic NumPy expressions mean functions are made of), falling back to central differences
     """
 
     _ride_along_bytes = 12e9  # device budget for the k_pX rows of one predict_in_batches sweep (per sample)
@@ -114,22 +120,24 @@ class ExactGP:
         noise_prior: Optional[Callable] = None,
         noise_prior_dist: Optional[dist.Distribution] = None,
         lengthscale_prior_dist: Optional[dist.Distribution] = None,
+        mean_fn_grad: Optional[Callable] = None,
     ) -> None:
-        if noise_prior is not None:
-            warnings.warn("`noise_prior` is deprecated in gpax; use `noise_prior_dist`.", FutureWarning)
-            raise NotImplementedError("`noise_prior` callables run numpyro.sample and have no MI355X path; "
-                                      "pass `noise_prior_dist` (gpax_amd.dist.*) instead")
-        if kernel_prior is not None:
-            raise NotImplementedError("`kernel_prior` callables run numpyro.sample and have no MI355X path; "
-                                      "pass `lengthscale_prior_dist` (gpax_amd.dist.*) instead")
+        if noise_prior is not None:  # gp.py:108-115
+            warnings.warn("`noise_prior` is deprecated and will be removed in a future version. Please use "
+                          "`noise_prior_dist` instead, which accepts a gpax_amd.dist distribution, e.g. "
+                          "`dist.HalfNormal(scale=0.1)`, rather than a function that calls `sample`.", FutureWarning)
+        if kernel_prior is not None:  # gp.py:116-123
+            warnings.warn("`kernel_prior` will remain available for complex priors. However, for modifying only the "
+                          "lengthscales, it is recommended to use `lengthscale_prior_dist` instead.", UserWarning)
         self.kernel_dim = input_dim
         self.kernel_name = kernel_name(kernel)
         self.kernel = kernel
         self._kind = _lib.kernel_kind(self.kernel_name)
         self.mean_fn = mean_fn
-        self.kernel_prior = None
+        self.kernel_prior = kernel_prior
         self.mean_fn_prior = mean_fn_prior
-        self.noise_prior = None
+        self.noise_prior = noise_prior
+        self.mean_fn_grad = mean_fn_grad
         self.noise_prior_dist = noise_prior_dist
         self.lengthscale_prior_dist = lengthscale_prior_dist
         self.X_train = None
@@ -143,32 +151,85 @@ class ExactGP:
     # ------------------------------------------------------------------------------------------
     # model definition: sites, transforms, log-joint  (gp.py:137-164, 222-247)
     # ------------------------------------------------------------------------------------------
-    def _mean_prior_dict(self) -> Dict[str, dist.Distribution]:
+    def _traced(self, fn, what):
+        """Sites of a prior given as callable (gpax_amd.sample program) or dict name -> distribution."""
+        sites, returned, det = trace_sites(fn, what)
+        return [_Site(n, shp, dd) for n, shp, dd in sites], returned, det
+
+    def _mean_prior_sites(self):
         if self.mean_fn_prior is None:
-            return {}
-        pri = self.mean_fn_prior() if callable(self.mean_fn_prior) else self.mean_fn_prior
-        if not isinstance(pri, dict) or not all(isinstance(v, dist.Distribution) for v in pri.values()):
-            raise NotImplementedError("mean_fn_prior must be a dict name -> gpax_amd.dist distribution "
-                                      "(or a callable returning one)")
-        return pri
+            return []
+        return self._traced(self.mean_fn_prior, "mean_fn_prior")[0]
 
-    def model(self, X, y=None, **kwargs) -> None:
-        """The reference's NumPyro program (gp.py:137-164).  There is no NumPyro here: the same log joint —
-        priors of `_sites()` plus the MVN log-likelihood — is evaluated by `_log_joint` on the device."""
-        raise NotImplementedError("ExactGP.model is a NumPyro program in the reference; gpax_amd evaluates the same "
-                                  "log joint on the MI355X through _log_joint (host NUTS / SVI drive it)")
+    def _mean_prior_dict(self) -> Dict[str, dist.Distribution]:
+        return {s.name: s.dist for s in self._mean_prior_sites()}
 
-    def _sites(self):
+    def model(self, X, y=None, params: Optional[Dict[str, np.ndarray]] = None, **kwargs) -> float:
+        """The reference's NumPyro program (gp.py:137-164) registers the prior sites and the MVN likelihood with a
+        tracer; there is no tracer here, so `model` evaluates what that program defines: the log joint
+            log p(y | theta) + sum_sites log p(theta_site)
+        at `params` (constrained values, site name -> value; default: the prior medians), the likelihood on the
+        device (gpx_factor).  y = None: the log prior alone.  NaN when K(theta) is not positive definite."""
+        X = self._set_data(X)
+        sites = self._sites()
+        theta = {s.name: (np.full(s.shape, float(s.dist.median())) if s.shape else float(s.dist.median()))
+                 for s in sites}
+        if params is not None:
+            theta.update({k: v for k, v in params.items() if k in theta})
+        theta = self._with_deterministic(theta)
+        val = 0.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for s_ in sites:
+                val += float(np.sum(s_.dist.log_prob(np.asarray(theta[s_.name], dtype=np.float64).reshape(-1))))
+        if y is None:
+            return val
+        y = np.asarray(y, dtype=np.float64).squeeze()
+        jitter = float(kwargs.get("jitter", 1e-6))
+        eng = _lib.get_engine(self._device)
+        eng.set_train(X)
+        lml, info = eng.factor(self._kind, self._ell(theta), self._scalar(theta["k_scale"]),
+                               self._scalar(theta["noise"]), jitter, y - self._mean(X, theta))
+        return val + lml if info == 0 else float("nan")
+
+    def _kernel_sites(self):
+        """k_length (plate 'ard'), k_scale, period — default priors (gp.py:229-247) or the traced kernel_prior."""
+        self._det = {}
+        if self.kernel_prior is not None:
+            sites, returned, det = self._traced(self.kernel_prior, "kernel_prior")
+            have = set(returned) if isinstance(returned, dict) else set()
+            if not {"k_length", "k_scale"} <= have:
+                raise ValueError("kernel_prior must return at least 'k_length' and 'k_scale' (kernels.py:44-91)")
+            if self.kernel_name == "Periodic" and "period" not in have:
+                raise ValueError("kernel_prior of a Periodic kernel must return 'period' (kernels.py:94-117)")
+            for sx in sites:
+                if sx.name == "k_length" and sx.size not in (1, self.kernel_dim):
+                    raise ValueError(f"k_length site has {sx.size} entries for input_dim {self.kernel_dim}")
+            self._det.update({k: v for k, v in det.items() if k in ("k_length", "k_scale", "period")})
+            return sites
         length_dist = self.lengthscale_prior_dist if self.lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
-        noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
         sites = [_Site("k_length", (self.kernel_dim,), length_dist),  # plate "ard", gp.py:238-239
                  _Site("k_scale", (), dist.LogNormal(0.0, 1.0))]     # gp.py:241
         if self.kernel_name == "Periodic":
             sites.append(_Site("period", (), dist.LogNormal(0.0, 1.0)))  # gp.py:243-244
-        sites.append(_Site("noise", (), noise_dist))                     # gp.py:222-227
-        for name, d in self._mean_prior_dict().items():
-            sites.append(_Site(name, (), d))
         return sites
+
+    def _noise_sites(self):
+        if self.noise_prior is not None:  # gp.py:146-147 (deprecated there)
+            sites, returned, det = self._traced(self.noise_prior, "noise_prior")
+            if len(sites) != 1 or sites[0].name != "noise" or sites[0].size != 1:
+                raise ValueError("noise_prior must sample exactly one scalar site named 'noise'")
+            return sites
+        noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
+        return [_Site("noise", (), noise_dist)]  # gp.py:222-227
+
+    def _sites(self):
+        return self._kernel_sites() + self._noise_sites() + self._mean_prior_sites()
+
+    def _with_deterministic(self, theta):
+        """numpyro.deterministic values registered by a kernel_prior (e.g. a fixed k_scale)."""
+        for k, v in getattr(self, "_det", {}).items():
+            theta.setdefault(k, v)
+        return theta
 
     def _engine(self) -> _lib.Engine:
         """The shared context of this model's device with X_train resident.  Residency is keyed on (model, data
@@ -192,6 +253,29 @@ class ExactGP:
         args = [X, params] if self.mean_fn_prior is not None else [X]
         return np.asarray(self.mean_fn(*args), dtype=np.float64).squeeze()
 
+    def _dmean(self, X, theta, name) -> np.ndarray:
+        """d mean_fn(X, theta) / d theta[name] (N,): the user's mean_fn_grad, else complex-step differentiation
+        (f(x + ih).imag / h, h = 1e-30: no subtractive cancellation, exact to rounding for analytic NumPy
+        expressions), else central differences."""
+        if self.mean_fn_grad is not None:
+            return np.asarray(self.mean_fn_grad(X, theta)[name], dtype=np.float64).reshape(-1)
+        x0 = float(np.asarray(theta[name]).reshape(-1)[0])
+        try:
+            tc = dict(theta)
+            tc[name] = complex(x0, 1e-30)
+            with np.errstate(all="ignore"):
+                out = np.asarray(self.mean_fn(X.astype(np.complex128), tc))
+            if np.iscomplexobj(out):
+                dm = out.imag.squeeze() / 1e-30
+                if dm.shape == (X.shape[0],) and np.all(np.isfinite(dm)):
+                    return dm
+        except Exception:
+            pass
+        h = 1e-6 * max(1.0, abs(x0))
+        tp, tm = dict(theta), dict(theta)
+        tp[name], tm[name] = x0 + h, x0 - h
+        return (self._mean(X, tp) - self._mean(X, tm)) / (2 * h)
+
     def _unpack(self, sites, u):
         theta, off = {}, 0
         for s in sites:
@@ -199,7 +283,7 @@ class ExactGP:
             x = s.dist.transform(ui)
             theta[s.name] = x.reshape(s.shape) if s.shape else float(x[0])
             off += s.size
-        return theta
+        return self._with_deterministic(theta)
 
     def _log_joint(self, sites, u, jitter: float, jacobian: bool, want_grad: bool = True, eng=None):
         """log p(y | theta) + log p(theta) [+ log |dtheta/du|] at theta = T(u) and its gradient
@@ -270,7 +354,7 @@ class ExactGP:
         """Add the log-priors (and log-Jacobians) to the device log-likelihood and map its gradient
         (glik: site name -> d lml / d site, any shape matching the site) to the unconstrained vector u."""
         plan = self._lognormal_plan(sites)
-        if plan is not None and (glik is None or all(s.name in glik for s in sites)):
+        if plan is not None and (glik is None or all(s.name in glik and np.size(glik[s.name]) == s.size for s in sites)):
             # every site LogNormal (the default priors): the whole pass as a handful of vector operations, element
             # for element the arithmetic of the generic loop below (this runs once per leapfrog)
             loc, scale, const = plan
@@ -307,13 +391,10 @@ class ExactGP:
                     gl = glik.get(s.name)
                     if gl is not None:
                         gx = np.asarray(gl, dtype=np.float64).reshape(-1)
+                        if gx.size != s.size:  # one lengthscale shared by all input dimensions (custom kernel_prior)
+                            gx = np.array([gx.sum()])
                     else:  # mean-function parameter: d lml / d phi = sum_i alpha_i d m_i / d phi
-                        h = 1e-6 * max(1.0, abs(float(x[0])))
-                        tp, tm = dict(theta), dict(theta)
-                        tp[s.name] = float(x[0]) + h
-                        tm[s.name] = float(x[0]) - h
-                        dm = (self._mean(self.X_train, tp) - self._mean(self.X_train, tm)) / (2 * h)
-                        gx = np.array([float(np.sum(alpha * dm))])
+                        gx = np.array([float(np.sum(alpha * self._dmean(self.X_train, theta, s.name)))])
                     gu = (gx + d_.grad_log_prob(x)) * d_.dx_du(ui)
                     if jacobian:
                         gu = gu + dlj
@@ -518,6 +599,8 @@ class ExactGP:
         Make prediction at X_new points using posterior samples for GP parameters (gp.py:351-399).
 
         Returns the centre of mass of the sampled means (M,) and all sampled predictions (S, n, M).
+        `device`: a GPU ordinal, or "all" / a list of ordinals to shard the posterior samples over the GPUs of
+        this node (one process, RCCL over xGMI; the reference's `device` is a jax.Device for device_put).
         """
         X_new = self._set_data(X_new)
         if samples is None:
@@ -527,6 +610,13 @@ class ExactGP:
         jitter = float(kwargs.get("jitter", 1e-6))
         m_slice = int(kwargs.pop("_m_slice", 0))  # predict_in_batches: covariance blocks of this many test points
         ells, scales, noises, yres, eps, mean_shift = self._sweep_inputs(rng_key, X_new, samples, n, m_slice)
+        if device == "all" or isinstance(device, (list, tuple)):
+            # the vmap axis sharded over the GPUs of this node from this one process: RCCL broadcast of the inputs,
+            # RCCL gather of the results (gpx_predict_sweep_multi); same values as the single-GPU sweep
+            node = _lib.get_node(None if device == "all" else list(device))
+            means, y_sampled, infos = node.predict_sweep(self.X_train, self._kind, ells, scales, noises, yres, X_new,
+                                                         noiseless, jitter, eps, m_slice=m_slice)
+            return self._sweep_outputs(means, y_sampled, mean_shift, filter_nans)
         # several samples in flight per GPU: independent libgpx contexts on the same device
         engines = _lib.get_sweep_engines(self._device)  # concurrent_sweep re-uploads X (set_train drops ownership)
         means, y_sampled, infos = _lib.concurrent_sweep(engines, self.X_train, self._kind, ells, scales, noises, yres,
@@ -599,17 +689,25 @@ class ExactGP:
         means, y_sampled, infos = res
         return self._sweep_outputs(means, y_sampled, mean_shift, filter_nans)
 
-    def sample_from_prior(self, rng_key, X: np.ndarray, num_samples: int = 10):
-        """Samples from the prior predictive distribution at X (gp.py:401-408)."""
+    def sample_from_prior(self, rng_key, X: np.ndarray, num_samples: int = 10, **kwargs: float):
+        """Samples from the prior predictive distribution at X (gp.py:401-408: Predictive(self.model, num_samples)):
+        theta ~ priors, y ~ MVN(mean_fn(X), kernel(X, X, theta, noise, jitter)).  Randomness is consumed per draw as
+        [one draw of every site, in site order; then N standard normals] from rng_from_key(rng_key); the Gram matrix
+        and its Cholesky factor come from the device."""
         X = self._set_data(X)
         rng = rng_from_key(rng_key)
+        jitter = float(kwargs.get("jitter", 1e-6))
         eng = _lib.get_engine(self._device)
+        sites = self._sites()
         out = np.empty((num_samples, X.shape[0]))
         for i in range(num_samples):
-            theta = {s.name: (s.dist.sample(rng, s.shape) if s.shape else float(s.dist.sample(rng))) for s in self._sites()}
-            K = eng.gram(self._kind, X, X, self._ell(theta), theta["k_scale"], theta["noise"] + 1e-6, True)
+            theta = self._with_deterministic(
+                {s.name: (s.dist.sample(rng, s.shape) if s.shape else float(s.dist.sample(rng))) for s in sites})
+            eps = rng.standard_normal(X.shape[0])
+            K = eng.gram(self._kind, X, X, self._ell(theta), self._scalar(theta["k_scale"]),
+                         self._scalar(theta["noise"]) + jitter, True)
             L, info = eng.potrf(K)
-            out[i] = self._mean(X, theta) + L @ rng.standard_normal(X.shape[0]) if info == 0 else np.nan
+            out[i] = self._mean(X, theta) + L @ eps if info == 0 else np.nan
         return out
 
     # ------------------------------------------------------------------------------------------

@@ -51,6 +51,7 @@ typedef struct gpx_ctx gpx_ctx;
 /* Replaces JAX device selection (`device=` kwarg -> jax.device_put, gpax/models/gp.py:201-203).
  * Fails (<0) when no gfx950-capable HIP device `device` exists. */
 int gpx_init(int device, gpx_ctx** out);
+int gpx_device_count(void); /* HIP devices visible to this process (0 when there is none / no driver) */
 void gpx_destroy(gpx_ctx* ctx);
 const char* gpx_last_error(const gpx_ctx* ctx);
 int gpx_device_info(gpx_ctx* ctx, char* name, int name_len, int* num_cu, int64_t* hbm_bytes,
@@ -177,6 +178,28 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
 int gpx_sgp_posterior(gpx_ctx* ctx, int kind, const double* ell, double scale, double noise, double jitter,
                       const double* Xu, int Mi, const double* yres, const double* Xnew, int Ms, double noise_p,
                       double* mean, double* cov, double* var, int* info);
+
+/* ---- node-level predictive sweep: the vmap axis of ExactGP.predict (gpax/models/gp.py:392-395) sharded over the
+ * GPUs of ONE node from ONE process.  A gpx_node owns `inflight` contexts on each of `ngpu`
+ * devices (devices == NULL: ordinals 0 .. ngpu-1) and one RCCL communicator per device (ncclCommInitAll; RCCL is
+ * bound at run time with dlopen, libgpx does not link it).  gpx_predict_sweep_multi = gpx_predict_sweep (T = 1,
+ * no pred_diag) with the S samples split in contiguous blocks over the GPUs:
+ *   root GPU <- one H2D of [X | X_new | y_res | eps];  ncclBroadcast of that payload over xGMI;
+ *   every GPU sweeps its block (contexts in flight split it again, one host thread each);
+ *   ncclSend / ncclRecv (one group) of the [means | draws | vars | pivots] blocks to the root;  one D2H.
+ * Results equal gpx_predict_sweep's sample by sample (same kernels, same per-sample arithmetic).
+ * Environment: GPX_NODE_TRANSPORT=memcpy replaces the two RCCL steps by hipMemcpyPeerAsync (testing on a box
+ * with one GPU listed twice, which RCCL refuses); never selected implicitly. */
+typedef struct gpx_node gpx_node;
+int gpx_node_init(int ngpu, const int* devices, int inflight, gpx_node** out);
+void gpx_node_destroy(gpx_node* node);
+const char* gpx_node_last_error(const gpx_node* node);
+/* transport_rccl: 1 = RCCL, 0 = memcpy test transport; rccl_version as ncclGetVersion reports it (0 without RCCL) */
+int gpx_node_info(const gpx_node* node, int* ngpu, int* inflight, int* transport_rccl, int* rccl_version);
+int gpx_predict_sweep_multi(gpx_node* node, int kind, const double* X, int N, int d, int S, const double* ells,
+                            const double* scales, const double* noises, const double* yres, int yres_rows,
+                            const double* Xnew, int M, int noiseless, double jitter, const double* eps, int n,
+                            double* means, double* samples, int* infos, double* vars, int m_slice);
 
 /* Sweep statistics since gpx_init: batches launched, samples processed, and the batch size B
  * chosen by the most recent sweep. */

@@ -150,3 +150,49 @@ def test_predict_with_threefry_keys_on_gpu():
         m_ref, c_ref = ref.get_mvn_posterior(X, y, Xn, {"k_length": p["k_length"], "k_scale": float(p["k_scale"]),
                                                         "noise": float(p["noise"])}, False, kernel="Matern", route="inv")
         np.testing.assert_allclose(ys[i], ref.mvn_sample(m_ref, c_ref, eps[i]), rtol=1e-6, atol=1e-8)
+
+
+def test_sample_from_prior_on_gpu_matches_the_oracle_mvn_sample():
+    """A15 (gp.py:401-408): theta ~ priors, y ~ MVN(mean, K(theta)); device Gram + device Cholesky per draw against
+    ref.mvn_sample given the same generator (sites in order, then N standard normals per draw)."""
+    from gpax_amd.utils.utils import rng_from_key
+    for kernel, kfn in [("RBF", ref.RBFKernel), ("Matern", ref.MaternKernel)]:
+        X = np.random.default_rng(1).uniform(0, 4, (150, 2))
+        m = ExactGP(2, kernel, noise_prior_dist=dist.HalfNormal(0.3))
+        out = m.sample_from_prior(11, X, num_samples=4)
+        assert out.shape == (4, 150) and np.isfinite(out).all()
+        rng = rng_from_key(11)
+        for i in range(4):
+            theta = {s.name: (s.dist.sample(rng, s.shape) if s.shape else float(s.dist.sample(rng))) for s in m._sites()}
+            eps = rng.standard_normal(150)
+            K = kfn(X, X, theta, theta["noise"], jitter=1e-6)
+            expect = ref.mvn_sample(np.zeros(150), K, eps[None])[0]
+            assert np.linalg.norm(out[i] - expect) <= 1e-8 * np.linalg.norm(expect)
+
+
+def test_model_log_joint_on_gpu():
+    X, y, _, p = ref.synthetic_problem(700, 2, 4, seed=4)
+    m = ExactGP(2, "Matern")
+    params = {"k_length": p["k_length"], "k_scale": p["k_scale"], "noise": p["noise"]}
+    prior = m.model(X, None, params=params)
+    full = m.model(X, y, params=params)
+    expect = ref.exactgp_log_likelihood(X, y, p, kernel="Matern")
+    assert abs((full - prior) - expect) <= 1e-10 * abs(expect)
+
+
+def test_custom_kernel_prior_fit_on_gpu():  # gpax/tests/test_gp.py:129-134
+    import gpax_amd
+
+    def prior():
+        length = gpax_amd.sample("k_length", dist.Uniform(0, 1))
+        scale = gpax_amd.sample("k_scale", dist.LogNormal(0, 1))
+        return {"k_length": length, "k_scale": scale}
+
+    rng = np.random.default_rng(0)
+    X = np.linspace(1, 2, 8) + 0.01 * rng.standard_normal(8)
+    y = 10 * X ** 2
+    with pytest.warns(UserWarning):
+        m = ExactGP(1, "RBF", kernel_prior=prior)
+    m.fit(get_keys()[0], X, y, num_warmup=30, num_samples=30, progress_bar=False, print_summary=False)
+    s = m.get_samples()
+    assert s["k_length"].shape == (30,) and np.all((s["k_length"] > 0) & (s["k_length"] < 1))

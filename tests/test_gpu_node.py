@@ -1,0 +1,108 @@
+"""GPU: the node-level sweep (gpx_node_* / gpx_predict_sweep_multi) — one process, the posterior
+samples of ExactGP.predict (gpax/models/gp.py:392-395) sharded over GPUs with RCCL broadcast / gather.
+On the 1-GPU test box: RCCL with one rank (dlopen, ncclCommInitAll, broadcast), and the sharding / threading logic
+with the same device listed twice over the memcpy test transport; with more GPUs visible, RCCL over all of them."""
+import os
+
+import numpy as np
+import pytest
+
+from bench_inputs import synthetic_problem, synthetic_theta_samples
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(N, d, M, S, n, seed=0):
+    X, y, Xn, _ = synthetic_problem(N, d, M, seed=seed)
+    th = synthetic_theta_samples(S, d, seed=seed + 1)
+    eps = np.random.default_rng(seed + 2).standard_normal((S, n, M))
+    return X, y, Xn, th, eps
+
+
+def _reference(engine, X, y, Xn, th, eps, kind=1, want_var=False, m_slice=0):
+    engine.set_train(X)
+    return engine.predict_sweep(kind, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps,
+                                want_var=want_var, m_slice=m_slice)
+
+
+def test_one_rank_rccl_equals_the_single_gpu_sweep(engine):
+    from gpax_amd import _lib
+    X, y, Xn, th, eps = _case(700, 2, 130, 9, 2)
+    node = _lib.Node([0], inflight=2)
+    info = node.info()
+    assert info["ngpu"] == 1 and info["transport"] == "rccl" and info["rccl_version"] > 0
+    m, s, i, v = node.predict_sweep(X, 1, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps,
+                                    want_var=True)
+    m0, s0, i0, v0 = _reference(engine, X, y, Xn, th, eps, want_var=True)
+    np.testing.assert_array_equal(m, m0)
+    np.testing.assert_array_equal(s, s0)
+    np.testing.assert_array_equal(v, v0)
+    np.testing.assert_array_equal(i, i0)
+    node.close()
+
+
+@pytest.mark.parametrize("N,S,ranks,inflight", [(300, 7, 2, 1), (3100, 11, 3, 2), (300, 2, 3, 2)])
+def test_sharding_logic_with_one_gpu_listed_several_times(engine, N, S, ranks, inflight, monkeypatch):
+    """Blocks of unequal size, an empty block (S < ranks), contexts in flight splitting a block again, per-sample
+    y residuals, predict_in_batches blocks and a non-PD theta — over the memcpy test transport."""
+    from gpax_amd import _lib
+    monkeypatch.setenv("GPX_NODE_TRANSPORT", "memcpy")
+    X, y, Xn, th, eps = _case(N, 3, 70, S, 1, seed=5)
+    th["k_scale"][S // 2] = -1.0  # not positive definite: NaN rows + info, never an abort (gp.py:396-398)
+    yres = np.stack([y + 0.01 * k for k in range(S)])
+    node = _lib.Node([0] * ranks, inflight=inflight)
+    assert node.info()["transport"] == "memcpy"
+    got = node.predict_sweep(X, 0, th["k_length"], th["k_scale"], th["noise"], yres, Xn, False, 1e-6, eps, m_slice=32)
+    engine.set_train(X)
+    want = engine.predict_sweep(0, th["k_length"], th["k_scale"], th["noise"], yres, Xn, False, 1e-6, eps, m_slice=32)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    assert want[2][S // 2] != 0 and np.isnan(got[0][S // 2]).all()
+    node.close()
+
+
+def test_exactgp_predict_device_all(engine):
+    from gpax_amd import ExactGP, _lib
+    _lib.set_engine(None)
+    X, y, Xn, th, _ = _case(400, 2, 50, 6, 1, seed=9)
+    m = ExactGP(2, "Matern")
+    m.X_train, m.y_train = m._set_data(X, y)
+    samples = {k: v for k, v in th.items()}
+    a_mean, a_draws = m.predict(3, Xn, samples=samples, n=2)
+    b_mean, b_draws = m.predict(3, Xn, samples=samples, n=2, device="all")
+    np.testing.assert_array_equal(a_mean, b_mean)
+    np.testing.assert_array_equal(a_draws, b_draws)
+    assert _lib.get_node().info()["transport"] == "rccl"
+
+
+def test_contexts_on_every_visible_gpu_launch_the_big_gemm(engine):
+    """Per-device kernel attributes (a process-wide static set the > 64 KB dynamic-LDS attribute on the
+    first device only): a factorisation with trailing updates on a context of EVERY visible device."""
+    from gpax_amd import _lib
+    n_dev = _lib.visible_device_count()
+    assert n_dev >= 1
+    X, y, _, p = synthetic_problem(1500, 2, 8, seed=3)
+    engine.set_train(X)
+    want, _ = engine.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+    for dev in range(n_dev):
+        for _ in range(2):  # two contexts per device: the attribute bit lives in the context
+            e = _lib.Engine(dev)
+            e.set_train(X)
+            lml, info = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+            assert info == 0 and lml == want
+            e.close()
+
+
+@pytest.mark.skipif(int(os.environ.get("GPX_TEST_MULTI_GPU", "1")) == 0, reason="disabled")
+def test_all_visible_gpus_over_rccl(engine):
+    from gpax_amd import _lib
+    n_dev = _lib.visible_device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU visible: the multi-rank RCCL path needs >= 2")
+    X, y, Xn, th, eps = _case(2000, 3, 200, 4 * n_dev + 1, 1, seed=21)
+    node = _lib.Node(list(range(n_dev)), inflight=2)
+    got = node.predict_sweep(X, 0, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps)
+    want = _reference(engine, X, y, Xn, th, eps, kind=0)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    node.close()

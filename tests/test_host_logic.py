@@ -72,8 +72,10 @@ def test_unsupported_inputs_raise_clearly():
         ExactGP(1, "NNGP")
     with pytest.raises(NotImplementedError):
         ExactGP(1, lambda a, b, c: None)
-    with pytest.raises(NotImplementedError):
-        ExactGP(1, "RBF", kernel_prior=lambda: {})
+    with pytest.warns(UserWarning):
+        m = ExactGP(1, "RBF", kernel_prior=lambda: {})
+    with pytest.raises(NotImplementedError):  # a prior callable that registers no gpax_amd.sample site
+        m._sites()
 
 
 @pytest.mark.parametrize("noiseless", [False, True])
@@ -358,3 +360,144 @@ def test_refit_with_a_mutated_X_array_reuploads_the_training_inputs():
     X[:] = X + 1.0  # same object, new contents
     m.fit(0, X, y, num_steps=2, progress_bar=False, print_summary=False)
     np.testing.assert_array_equal(eng.X, X)
+
+
+# ---- prior callables: the reference's numpyro.sample programs with the import swapped (gp.py:96-135) ----------
+
+def dummy_mean_fn(x, params):  # gpax/tests/test_gp.py:25-26
+    return params["a"] * x[:, 0] ** params["b"]
+
+
+def dummy_mean_fn_priors():  # gpax/tests/test_gp.py:29-32
+    import gpax_amd
+    a = gpax_amd.sample("a", dist.LogNormal(0, 1))
+    b = gpax_amd.sample("b", dist.Normal(3, 1))
+    return {"a": a, "b": b}
+
+
+def gp_kernel_custom_prior():  # gpax/tests/test_gp.py:35-38
+    import gpax_amd
+    length = gpax_amd.sample("k_length", dist.Uniform(0, 1))
+    scale = gpax_amd.sample("k_scale", dist.LogNormal(0, 1))
+    return {"k_length": length, "k_scale": scale}
+
+
+def _dummy(n=8, seed=0):
+    rng = np.random.default_rng(seed)
+    X = np.linspace(1, 2, n) + 0.01 * rng.standard_normal(n)
+    return X, 10 * X ** 2
+
+
+@pytest.mark.parametrize("kernel", ["RBF", "Matern"])
+def test_fit_with_custom_kernel_priors(kernel):  # gpax/tests/test_gp.py:129-134
+    X, y = _dummy()
+    with pytest.warns(UserWarning):
+        m = ExactGP(1, kernel, kernel_prior=gp_kernel_custom_prior)
+    m.fit(0, X, y, num_warmup=20, num_samples=20, progress_bar=False, print_summary=False)
+    s = m.get_samples()
+    assert m.mcmc is not None and s["k_length"].shape == (20,)  # scalar site: no ARD plate in this prior
+    assert np.all((s["k_length"] > 0) & (s["k_length"] < 1))    # Uniform(0, 1) support
+    mean, draws = m.predict(1, np.linspace(1, 2, 5), n=2)
+    assert mean.shape == (5,) and draws.shape == (20, 2, 5)
+
+
+def test_kernel_prior_with_plate_and_deterministic_scale():
+    import gpax_amd
+
+    def prior():
+        with gpax_amd.plate("ard", 2):
+            length = gpax_amd.sample("k_length", dist.Gamma(2.0, 5.0))
+        scale = gpax_amd.deterministic("k_scale", 1.0)
+        return {"k_length": length, "k_scale": scale}
+
+    with pytest.warns(UserWarning):
+        m = ExactGP(2, "RBF", kernel_prior=prior)
+    sites = m._sites()
+    assert [(s.name, s.shape) for s in sites] == [("k_length", (2,)), ("noise", ())]
+    theta = m._unpack(sites, np.zeros(3))
+    assert theta["k_scale"] == 1.0 and theta["k_length"].shape == (2,)
+
+
+def test_noise_prior_callable_is_accepted_with_the_deprecation_warning():  # gp.py:108-115
+    import gpax_amd
+    with pytest.warns(FutureWarning):
+        m = ExactGP(1, "RBF", noise_prior=lambda: gpax_amd.sample("noise", dist.HalfNormal(0.1)))
+    sites = {s.name: s for s in m._sites()}
+    assert isinstance(sites["noise"].dist, dist.HalfNormal)
+
+
+def test_post_processed_prior_draws_are_rejected():
+    import gpax_amd
+
+    def prior():
+        length = gpax_amd.sample("k_length", dist.LogNormal(0, 1))
+        return {"k_length": 2.0 * length, "k_scale": gpax_amd.sample("k_scale", dist.LogNormal(0, 1))}
+
+    with pytest.warns(UserWarning):
+        m = ExactGP(1, "RBF", kernel_prior=prior)
+    with pytest.raises(NotImplementedError, match="post-processed"):
+        m._sites()
+    with pytest.raises(RuntimeError):
+        gpax_amd.sample("x", dist.Normal())  # outside of a prior callable
+
+
+def test_mean_fn_prior_callable_and_exact_mean_gradient():
+    """gpax/tests/test_gp.py:244-262 (fit with mean_fn + mean_fn_prior); the derivative of the mean function w.r.t.
+    its parameters is complex-step (was central differences, O(1e-9) noise): checked to 1e-10 against the
+    closed form d/da = x^b, d/db = a x^b log x through the log joint's gradient."""
+    X, y = _dummy(12)
+    m = ExactGP(1, "RBF", mean_fn=dummy_mean_fn, mean_fn_prior=dummy_mean_fn_priors)
+    m.X_train, m.y_train = m._set_data(X, y)
+    sites = m._sites()
+    names = [s.name for s in sites]
+    assert names == ["k_length", "k_scale", "noise", "a", "b"]
+    u = np.array([0.1, 0.2, -1.0, 0.3, 2.5])
+    val, grad = m._log_joint(sites, u, 1e-6, jacobian=False)
+    theta = m._unpack(sites, u)
+    x = m.X_train[:, 0]
+    p = {"k_length": theta["k_length"], "k_scale": theta["k_scale"], "noise": theta["noise"]}
+    yres = y - theta["a"] * x ** theta["b"]
+    _, _, _, alpha = ref.exactgp_log_likelihood_grad(m.X_train, y, p, kernel="RBF", yres=yres)
+    dm = {"a": x ** theta["b"], "b": theta["a"] * x ** theta["b"] * np.log(x)}
+    for name in ("a", "b"):
+        i = names.index(name)
+        s_ = sites[i]
+        xv = np.array([theta[name]])
+        expect = (float(alpha @ dm[name]) + s_.dist.grad_log_prob(xv)[0]) * s_.dist.dx_du(u[i:i + 1])[0]
+        assert abs(grad[i] - expect) <= 1e-10 * abs(expect), (name, grad[i], expect)
+    # a user-supplied derivative takes precedence
+    m2 = ExactGP(1, "RBF", mean_fn=dummy_mean_fn, mean_fn_prior=dummy_mean_fn_priors,
+                 mean_fn_grad=lambda X_, th: {"a": X_[:, 0] ** th["b"], "b": th["a"] * X_[:, 0] ** th["b"] * np.log(X_[:, 0])})
+    m2.X_train, m2.y_train = m.X_train, m.y_train
+    _, grad2 = m2._log_joint(sites, u, 1e-6, jacobian=False)
+    np.testing.assert_allclose(grad2, grad, rtol=1e-12)
+    m.fit(0, X, y, num_warmup=10, num_samples=10, progress_bar=False, print_summary=False)
+    assert set(m.get_samples()) == {"k_length", "k_scale", "noise", "a", "b"}
+
+
+def test_model_returns_the_log_joint():
+    """ExactGP.model (gp.py:137-164) = priors + MVN likelihood; evaluated at given params, y = None: priors only."""
+    X, y, _, p = ref.synthetic_problem(30, 2, 4, seed=2)
+    m = ExactGP(2, "Matern", noise_prior_dist=dist.HalfNormal(0.5))
+    params = {"k_length": np.array([1.0, 1.25]), "k_scale": 1.3, "noise": 0.1}
+    lp = dist.LogNormal(0, 1).log_prob(np.array([1.0, 1.25])).sum() + dist.LogNormal(0, 1).log_prob(np.array([1.3]))[0] \
+        + dist.HalfNormal(0.5).log_prob(np.array([0.1]))[0]
+    assert abs(m.model(X, None, params=params) - lp) < 1e-12
+    full = m.model(X, y, params=params)
+    assert abs(full - (lp + ref.exactgp_log_likelihood(X, y, p, kernel="Matern"))) < 1e-9
+    assert np.isfinite(m.model(X, y))  # default: prior medians
+    assert np.isnan(m.model(X, y, params={**params, "k_scale": -1.0}))
+
+
+def test_sample_from_prior_is_mvn_sample_of_the_prior_draws():
+    """gp.py:401-408 against the oracle's mvn_sample: same generator, same consumption order (sites, then eps)."""
+    from gpax_amd.utils.utils import rng_from_key
+    X = np.linspace(0, 3, 25)[:, None]
+    m = ExactGP(1, "RBF")
+    out = m.sample_from_prior(5, X, num_samples=3, jitter=1e-5)
+    rng = rng_from_key(5)
+    for i in range(3):
+        theta = {s.name: (s.dist.sample(rng, s.shape) if s.shape else float(s.dist.sample(rng))) for s in m._sites()}
+        eps = rng.standard_normal(25)
+        K = ref.RBFKernel(X, X, theta, theta["noise"], jitter=1e-5)
+        np.testing.assert_allclose(out[i], ref.mvn_sample(np.zeros(25), K, eps[None])[0], rtol=1e-9, atol=1e-12)
