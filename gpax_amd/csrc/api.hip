@@ -616,6 +616,10 @@ int gpx_init(int device, gpx_ctx** out) {
       }
     }
     ctx->cu_reserved = reserve;
+    if (const char* e = getenv("GPX_OUTER_TILES")) {
+      const int ot = atoi(e);
+      if (ot >= 1 && ot <= 32) ctx->outer_tiles = ot;
+    }
     if (!ctx->stream) GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, lo));
     GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->pstream, hipStreamNonBlocking, hi));
     ctx->s = ctx->stream;

@@ -14,7 +14,7 @@
 namespace gpx {
 
 constexpr int TILE = 128;      // MFMA GEMM block tile and diagonal-block size
-constexpr int OUTER_TILES = 4; // outer blocking of the right-looking sweeps (4*128 = 512)
+constexpr int OUTER_TILES = 4; // default outer blocking of the right-looking sweeps (4*128 = 512); ctx->outer_tiles
 constexpr double AUG_BIG = 1e300;
 constexpr double SQRT5 = 2.23606797749978969641;
 constexpr double MATERN_EPS = 1e-12; // gpax/kernels/kernels.py:20-21
@@ -150,6 +150,7 @@ struct gpx_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   hipDeviceProp_t prop;
+  int outer_tiles = gpx::OUTER_TILES; // GPX_OUTER_TILES (experiments): K of the trailing update = 128 * outer_tiles
   unsigned func_attr_mask = 0; // kernels whose dynamic-LDS attribute this context has set on ITS device (bit per variant)
 
   // ---- training state -------------------------------------------------------------------

@@ -123,7 +123,8 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
                 int* dInfo, int batch, int64_t a_bs, int64_t linv_bs) {
   const BatchStrides bs{batch > 1 ? batch : 1, a_bs, linv_bs};
   const int nblk = np / TILE;
-  const int nouter = (nblk + OUTER_TILES - 1) / OUTER_TILES;
+  const int OT = ctx->outer_tiles;
+  const int nouter = (nblk + OT - 1) / OT;
   GPX_TRY(ensure_events(ctx, nouter));
   hipStream_t smain = ctx->stream, span = ctx->pstream;
   // the panel stream starts after everything already queued on the main stream (Gram etc.)
@@ -131,9 +132,9 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
   GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[nouter], 0));
   int rc = 0;
   for (int k = 0; k < nouter && rc >= 0; ++k) {
-    const int ob = k * OUTER_TILES;
-    const int oe = (ob + OUTER_TILES < nblk) ? ob + OUTER_TILES : nblk;
-    const int oe2 = (oe + OUTER_TILES < nblk) ? oe + OUTER_TILES : nblk;
+    const int ob = k * OT;
+    const int oe = (ob + OT < nblk) ? ob + OT : nblk;
+    const int oe2 = (oe + OT < nblk) ? oe + OT : nblk;
     // P(k) on the panel stream (it follows U1(k-1) there, in stream order)
     ctx->s = span;
     rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs);
@@ -168,7 +169,8 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
                   int64_t ldl, const double* dLinv, int nblk, int upper_rows, int batch,
                   int64_t b_bs, int64_t l_bs, int64_t linv_bs) {
   if (batch < 1) batch = 1;
-  const int nouter = (nblk + OUTER_TILES - 1) / OUTER_TILES;
+  const int OT = ctx->outer_tiles;
+  const int nouter = (nblk + OT - 1) / OT;
   GPX_TRY(ensure_events(ctx, nouter));
   hipStream_t smain = ctx->stream, span = ctx->pstream;
   GPX_HIP(ctx, hipEventRecord(ctx->evU[nouter], smain));
@@ -185,9 +187,9 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
   };
   int rc = 0;
   for (int k = 0; k < nouter && rc >= 0; ++k) {
-    const int ob = k * OUTER_TILES;
-    const int oe = (ob + OUTER_TILES < nblk) ? ob + OUTER_TILES : nblk;
-    const int oe2 = (oe + OUTER_TILES < nblk) ? oe + OUTER_TILES : nblk;
+    const int ob = k * OT;
+    const int oe = (ob + OT < nblk) ? ob + OT : nblk;
+    const int oe2 = (oe + OT < nblk) ? oe + OT : nblk;
     ctx->s = span;
     for (int i = ob; i < oe && rc >= 0; ++i) {
       const int rt = upper_rows ? (i + 1) : rows_t;

@@ -5,12 +5,18 @@ the reference would draw from the same key (gpax/utils/utils.py:24-30 get_keys; 
 `keys = jax.random.split(rng_key, S)`, per sample `MultivariateNormal(mean, K).sample(key_s, (n,))`
 = `mean + L @ jax.random.normal(key_s, (n, M))` in NumPyro).
 
-What is pinned and what is not.  The threefry2x32 block function is checked against the Random123 / JAX
-known-answer vectors (tests/test_threefry.py).  Everything derived from it — key construction, `split`,
-`random_bits`, `uniform`, `normal` — restates jax/_src/prng.py and jax/_src/random.py for
-`jax_threefry_partitionable=True`, the default since JAX 0.5.0 (the reference pins jax >= 0.6.2) [knowledge];
-JAX is not installed here, so those layers are NOT verified against a JAX run.  `normal` ends in erf_inv:
-XLA's polynomial and scipy.special.erfinv agree to a few ulp, not bit for bit.
+What is pinned (tests/test_threefry.py).  The threefry2x32 block function: the Random123 / JAX known-answer
+vectors.  The layers above it — key construction, `split`, `random_bits`, `uniform`, `normal` — restate
+jax/_src/prng.py and jax/_src/random.py [knowledge] in BOTH counter layouts JAX has shipped, and are pinned to the
+values JAX's own documentation publishes for them:
+  * `jax_threefry_partitionable=True` (default since JAX 0.5.0; the reference pins jax >= 0.6.2 — the default
+    here): "Pseudorandom numbers" tutorial, JAX >= 0.5: normal(key(42)) = -0.028304616 and the three draws
+    0.6057640314102173, -0.21089035272598267, -0.3948981463909149 of its split loop;
+  * the legacy layout (`set_partitionable(False)`): the same tutorial before 0.5 and the README / quickstart:
+    split(PRNGKey(42)) = [2465931498 3679230171], [255383827 267815257], normal = -0.18471177 / 1.3694694;
+    split(PRNGKey(0)) = [4146024105 967050713], [2718843009 1272950319], normal(PRNGKey(0)) = -0.20584226.
+The uint32 words are reproduced exactly; `normal` ends in erf_inv, where XLA's polynomial and
+scipy.special.erfinv agree to a few ulp of float32, not bit for bit (the tests allow 4 ulp).
 """
 from __future__ import annotations
 
@@ -19,6 +25,15 @@ from scipy import special
 
 _ROT = ((13, 15, 26, 6), (17, 29, 16, 24))
 _U32 = np.uint32
+_PARTITIONABLE = True
+
+
+def set_partitionable(flag: bool) -> bool:
+    """jax.config.update('jax_threefry_partitionable', flag): choose the counter layout of split / random_bits.
+    Returns the previous setting."""
+    global _PARTITIONABLE
+    old, _PARTITIONABLE = _PARTITIONABLE, bool(flag)
+    return old
 
 
 class ThreefryKey:
@@ -69,15 +84,39 @@ def _iota_2x32(shape):
     return (idx >> np.uint64(32)).astype(np.uint32), (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
 
 
+def _legacy_bits32(key: ThreefryKey, n: int) -> np.ndarray:
+    """threefry_2x32(key, iota(n)) of the non-partitionable layout: the counter vector (padded to even length) is cut
+    in two halves that feed the two input words; the output words are concatenated."""
+    cnt = np.arange(n, dtype=np.uint32)
+    if n % 2:
+        cnt = np.concatenate([cnt, np.zeros(1, dtype=np.uint32)])
+    h = cnt.size // 2
+    a, b = threefry2x32(key, cnt[:h], cnt[h:])
+    return np.concatenate([a, b])[:n]
+
+
 def split(key: ThreefryKey, num: int = 2):
-    """jax.random.split: key i = threefry2x32(key, (0, i))  (fold-like split of the partitionable scheme)."""
+    """jax.random.split.  Partitionable layout: key i = threefry2x32(key, (0, i)).  Legacy layout: the 2 num words of
+    threefry_2x32(key, iota(2 num)) reshaped to (num, 2)."""
+    if not _PARTITIONABLE:
+        w = _legacy_bits32(key, 2 * int(num)).reshape(int(num), 2)
+        return [ThreefryKey(a, b) for a, b in w]
     hi, lo = _iota_2x32((int(num),))
     b1, b2 = threefry2x32(key, hi, lo)
     return [ThreefryKey(a, b) for a, b in zip(b1, b2)]
 
 
 def random_bits(key: ThreefryKey, bit_width: int, shape):
-    hi, lo = _iota_2x32(tuple(shape))
+    shape = tuple(shape)
+    if not _PARTITIONABLE:
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        if bit_width == 32:
+            return _legacy_bits32(key, n).reshape(shape)
+        if bit_width == 64:  # two 32-bit words per element, consecutive in the stream: (hi << 32) | lo
+            w = _legacy_bits32(key, 2 * n).reshape(n, 2).astype(np.uint64)
+            return ((w[:, 0] << np.uint64(32)) | w[:, 1]).reshape(shape)
+        raise NotImplementedError("bit_width must be 32 or 64")
+    hi, lo = _iota_2x32(shape)
     b1, b2 = threefry2x32(key, hi, lo)
     if bit_width == 64:
         return (b1.astype(np.uint64) << np.uint64(32)) | b2.astype(np.uint64)

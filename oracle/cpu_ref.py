@@ -161,7 +161,14 @@ def measured_noise_predict_one(X_train, y_train, X_new, params, noise_predicted,
 
 # ------------------------------------------------------------------------------------------
 # NumPyro MultivariateNormal [knowledge]: log_prob = -1/2 |L^-1 (y-loc)|^2 - sum log L_ii
-#   - n/2 log 2 pi with L = cholesky(covariance_matrix); sample = loc + L @ eps
+#   - n/2 log 2 pi with L = cholesky(covariance_matrix); sample = loc + L @ eps.
+#   Source of the formula: numpyro/distributions/continuous.py, class MultivariateNormal — __init__ sets
+#   scale_tril = cholesky(covariance_matrix); log_prob computes M = _batch_mahalanobis(scale_tril, value - loc)
+#   (a solve_triangular followed by a sum of squares), half_log_det = sum(log(diagonal(scale_tril))),
+#   normalize_term = half_log_det + 0.5 * event_size * log(2 pi), result -0.5 * M - normalize_term; sample returns
+#   loc + squeeze(scale_tril @ eps[..., None]) with eps ~ N(0, 1) of shape sample_shape + batch_shape + event_shape.
+#   Pinned here (tests/test_oracle.py) against scipy.stats.multivariate_normal.logpdf, an independent
+#   implementation of the same textbook density (Rasmussen & Williams, GPML eq. 2.30 / A.9).
 # ------------------------------------------------------------------------------------------
 def mvn_log_prob(y, loc, cov) -> float:
     y = np.asarray(y, dtype=np.float64)
@@ -333,7 +340,13 @@ def vigp_predict(X_train, y_train, X_new, params, noiseless=False, kernel="RBF",
 # ------------------------------------------------------------------------------------------
 def lowrank_mvn_log_prob(y, loc, W, D) -> float:
     """LowRankMultivariateNormal(loc, cov_factor=W (N,M), cov_diag=D (N,)).log_prob(y):
-    Woodbury + matrix-determinant lemma with the capacitance matrix C = I + W^T D^-1 W."""
+    Woodbury + matrix-determinant lemma with the capacitance matrix C = I + W^T D^-1 W.
+    Source of the formula [knowledge]: numpyro/distributions/continuous.py, class LowRankMultivariateNormal —
+    __init__: Wt_Dinv = W^T / D, K = I + Wt_Dinv W, _capacitance_tril = cholesky(K); log_prob:
+    M = _batch_lowrank_mahalanobis(W, D, diff, capacitance_tril) = sum(diff^2 / D) - |C_tril^-1 (Wt_Dinv diff)|^2,
+    log_det = _batch_lowrank_logdet(...) = 2 sum log diag(C_tril) + sum log D, result -0.5 (n log 2 pi + log_det + M)
+    (the same decomposition as torch.distributions.LowRankMultivariateNormal, from which NumPyro's was ported).
+    Pinned (tests/test_oracle.py) against the dense MVN density of W W^T + diag(D) to 1e-11."""
     y = np.asarray(y, dtype=np.float64)
     r = y - loc
     Wt_Dinv = W.T / D
@@ -437,6 +450,66 @@ def preprocess_sparse_image(sparse_image):
     full_indices = np.array(np.meshgrid(*[np.arange(dim) for dim in sparse_image.shape])).T.reshape(
         -1, sparse_image.ndim)
     return gp_input.astype(dtype), targets.astype(dtype), full_indices.astype(dtype)
+
+
+# ------------------------------------------------------------------------------------------
+# gpax/acquisition/base_acq.py:20-155 and acquisition.py:22-35
+# NumPyro Normal(0, 1) [knowledge]: cdf(u) = (1 + erf(u / sqrt 2)) / 2, log_prob(u) = -u^2 / 2 - log sqrt(2 pi)
+# ------------------------------------------------------------------------------------------
+def _std_normal_cdf(u):
+    from scipy.special import erf
+    return 0.5 * (1.0 + erf(u / math.sqrt(2.0)))
+
+
+def _std_normal_log_prob(u):
+    return -0.5 * u * u - 0.5 * LOG_2PI
+
+
+def acq_ei(moments, best_f=None, maximize=False):
+    """base_acq.py:20-73"""
+    mean, var = moments
+    if best_f is None:
+        best_f = mean.max() if maximize else mean.min()
+    sigma = np.sqrt(var)
+    u = (mean - best_f) / sigma
+    if not maximize:
+        u = -u
+    ucdf = _std_normal_cdf(u)
+    updf = np.exp(_std_normal_log_prob(u))
+    return sigma * (updf + u * ucdf)
+
+
+def acq_ucb(moments, beta=0.25, maximize=False):
+    """base_acq.py:76-109"""
+    mean, var = moments
+    delta = np.sqrt(beta * var)
+    if maximize:
+        return mean + delta
+    return -(mean - delta)
+
+
+def acq_ue(moments):
+    """base_acq.py:112-133 (returns the standard deviation)"""
+    _, var = moments
+    return np.sqrt(var)
+
+
+def acq_poi(moments, best_f=None, xi=0.01, maximize=False):
+    """base_acq.py:136-155"""
+    mean, var = moments
+    if best_f is None:
+        best_f = mean.max() if maximize else mean.min()
+    sigma = np.sqrt(var)
+    u = (mean - best_f - xi) / sigma
+    if not maximize:
+        u = -u
+    return _std_normal_cdf(u)
+
+
+def acq_moments_from_samples(y_sampled, n):
+    """acquisition.py:28-32: pooled moments of the (S, n, M) predictive draws of an MCMC model."""
+    y_sampled = y_sampled.reshape(n * y_sampled.shape[0], -1)
+    return y_sampled.mean(0), y_sampled.var(0)
 
 
 # ------------------------------------------------------------------------------------------

@@ -80,3 +80,21 @@ def test_thompson_shapes():
     v = viGP(1, "RBF")
     v.fit(get_keys()[0], X, y, num_steps=10, progress_bar=False, print_summary=False)
     assert Thompson(get_keys()[1], v, Xn, noiseless=False).shape == (1, 9)
+
+
+def test_base_functions_match_the_oracle_restatement_of_base_acq():
+    """oracle/cpu_ref.py restates gpax/acquisition/base_acq.py:20-155 line by line (erf-based NumPyro Normal cdf);
+    the product's closed forms (scipy ndtr) must agree element-wise, incl. best_f given / derived and both senses."""
+    rng = np.random.default_rng(4)
+    mean, var = 3.0 * rng.standard_normal(200), rng.uniform(1e-6, 4.0, 200)
+    for maximize in (False, True):
+        for best_f in (None, 0.7):
+            # far in the tail sigma (phi(u) + u Phi(u)) cancels to ~1e-16 of its terms: absolute floor at 1e-14 of the scale
+            e = ref.acq_ei((mean, var), best_f, maximize)
+            np.testing.assert_allclose(ei((mean, var), best_f=best_f, maximize=maximize), e, rtol=1e-10,
+                                       atol=1e-14 * np.abs(e).max())
+            np.testing.assert_allclose(poi((mean, var), best_f=best_f, xi=0.03, maximize=maximize),
+                                       ref.acq_poi((mean, var), best_f, 0.03, maximize), rtol=1e-10, atol=1e-15)
+        np.testing.assert_allclose(ucb((mean, var), beta=0.4, maximize=maximize), ref.acq_ucb((mean, var), 0.4, maximize),
+                                   rtol=1e-15)
+    np.testing.assert_allclose(ue((mean, var)), ref.acq_ue((mean, var)), rtol=1e-15)

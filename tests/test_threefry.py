@@ -1,5 +1,6 @@
-"""gpax_amd.utils.threefry: the block function against the Random123 / JAX known-answer vectors; structural
-checks of the derived jax.random restatements (which are not verifiable against JAX here — see the module header)."""
+"""gpax_amd.utils.threefry: the block function against the Random123 / JAX known-answer vectors, and the layers above
+it (PRNGKey / split / normal) against the values JAX's documentation publishes, in both counter layouts
+(jax_threefry_partitionable True = default since JAX 0.5, and the legacy one)."""
 import numpy as np
 import pytest
 
@@ -88,3 +89,45 @@ def test_models_accept_threefry_keys():
         np.testing.assert_allclose(ysb[4][:, :4], mean0[None, :] + e0[4] @ np.linalg.cholesky(cov0).T, rtol=1e-7, atol=1e-9)
     finally:
         _lib.set_engine(None)
+
+
+def _ulps32(a, b):
+    a, b = np.float32(a), np.float32(b)
+    return abs(int(a.view(np.int32)) - int(b.view(np.int32)))
+
+
+def test_partitionable_layout_matches_the_published_jax_values():
+    """JAX >= 0.5 'Pseudorandom numbers' tutorial (jax_threefry_partitionable=True): key = random.key(42);
+    random.normal(key) -> -0.028304616; then `for i in range(3): new_key, subkey = random.split(key); ...
+    val = random.normal(subkey); key = new_key` prints 0.6057640314102173, -0.21089035272598267, -0.3948981463909149."""
+    assert tf.set_partitionable(True) is True  # the default
+    key = tf.PRNGKey(42)
+    assert _ulps32(tf.normal(key, (), np.float32), -0.028304616) <= 4
+    for expect in (0.6057640314102173, -0.21089035272598267, -0.3948981463909149):
+        key, sub = tf.split(key)
+        assert _ulps32(tf.normal(sub, (), np.float32), expect) <= 4
+
+
+def test_legacy_layout_matches_the_published_jax_values():
+    """JAX < 0.5 tutorial / README (jax_threefry_partitionable=False): split(PRNGKey(42)) ->
+    [2465931498 3679230171], [255383827 267815257]; normal(PRNGKey(42)) -> -0.18471177, normal(subkey) -> 1.3694694;
+    split(PRNGKey(0)) -> [4146024105 967050713], [2718843009 1272950319]; normal(PRNGKey(0)) -> -0.20584226."""
+    old = tf.set_partitionable(False)
+    try:
+        k = tf.PRNGKey(42)
+        new, sub = tf.split(k)
+        assert tuple(map(int, new.k)) == (2465931498, 3679230171)
+        assert tuple(map(int, sub.k)) == (255383827, 267815257)
+        assert _ulps32(tf.normal(k, (), np.float32), -0.18471177) <= 4
+        assert _ulps32(tf.normal(sub, (), np.float32), 1.3694694) <= 4
+        k0 = tf.PRNGKey(0)
+        a, b = tf.split(k0)
+        assert tuple(map(int, a.k)) == (4146024105, 967050713)
+        assert tuple(map(int, b.k)) == (2718843009, 1272950319)
+        assert _ulps32(tf.normal(k0, (), np.float32), -0.20584226) <= 4
+        # 64-bit draws consume two consecutive words per element; shapes only reshape the stream
+        z = tf.normal(k0, (3, 2))
+        assert z.shape == (3, 2) and np.all(np.isfinite(z))
+        np.testing.assert_array_equal(z.reshape(-1), tf.normal(k0, (6,)))
+    finally:
+        tf.set_partitionable(old)
