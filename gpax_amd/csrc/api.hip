@@ -1,9 +1,41 @@
 // api.hip — the C-ABI of libgpx (declared in include/gpx.h): host orchestration of the
 // device-resident exact-GP pipeline.  Each entry point cites the gpax interface it replaces in
 // gpx.h; this file only sequences kernels on the context's stream and moves data H<->D.
+#include <dlfcn.h>
+
 #include "common.h"
 
 using namespace gpx;
+
+namespace gpx {
+namespace {
+int (*g_roctx_push)(const char*) = nullptr;
+int (*g_roctx_pop)() = nullptr;
+int g_roctx_state = 0; // 0 = not looked at, 1 = bound, -1 = off / unavailable
+void roctx_bind() {
+  g_roctx_state = -1;
+  const char* e = getenv("GPX_ROCTX");
+  if (!(e && e[0] == '1')) return;
+  for (const char* n : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"}) {
+    if (void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) {
+      g_roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      g_roctx_pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (g_roctx_push && g_roctx_pop) {
+        g_roctx_state = 1;
+        return;
+      }
+    }
+  }
+}
+} // namespace
+void roctx_push(const char* name) {
+  if (g_roctx_state == 0) roctx_bind();
+  if (g_roctx_state == 1) (void)g_roctx_push(name);
+}
+void roctx_pop() {
+  if (g_roctx_state == 1) (void)g_roctx_pop();
+}
+} // namespace gpx
 
 namespace {
 
@@ -122,10 +154,14 @@ int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
                                   sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->Linv, (size_t)B * bp.linv_bs * sizeof(double)));
   double* K = ctx->K.d();
-  GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->X.d(), N, N, ctx->X.d(), N, Np,
-                             ctx->noise + ctx->jitter, 1, 1, K, ctx->ldk, B, bp.k_bs, bp.th, 1, ts_train(ctx),
-                             ctx->has_diag ? ctx->diagv.d() : nullptr));
-  GPX_TRY(launch_augment(ctx, K, ctx->ldk, N, Np, bp.yres, B, bp.k_bs, bp.y_bs, bp.y_mod));
+  {
+    RoctxRange r("gpx:gram");
+    GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->X.d(), N, N, ctx->X.d(), N, Np,
+                               ctx->noise + ctx->jitter, 1, 1, K, ctx->ldk, B, bp.k_bs, bp.th, 1, ts_train(ctx),
+                               ctx->has_diag ? ctx->diagv.d() : nullptr));
+    GPX_TRY(launch_augment(ctx, K, ctx->ldk, N, Np, bp.yres, B, bp.k_bs, bp.y_bs, bp.y_mod));
+  }
+  RoctxRange r_potrf(fused ? "gpx:potrf+trsm(k_pX ride-along)" : "gpx:potrf");
   if (fused) {
     // k_pX = kernel(X_new, X_train, params, jitter=0.0): no diagonal term (gp.py:268)
     GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->Xnew.d(), ctx->M, ctx->Mp, ctx->X.d(), N, Np, 0.0,
@@ -153,6 +189,7 @@ int dev_grad(gpx_ctx* ctx, const BatchPlan& bp) {
   GPX_TRY(ensure(ctx, ctx->alpha, (size_t)B * alpha_bs * sizeof(double)));
   double* W = ctx->W.d();
   double* K = ctx->K.d();
+  RoctxRange r_grad("gpx:lml_grad (L^-T trsm, K^-1 syrk, contraction)");
   GPX_TRY(launch_set_identity(ctx, W, ctx->ldk, n128, B, w_bs));
   GPX_TRY(trsm_right_lt(ctx, W, ctx->ldk, nt, K, ctx->ldk, ctx->Linv.d(), nt, 1, B, w_bs, bp.k_bs, bp.linv_bs));
   // alpha_i = sum_{k>=i} W[i][k] w[k], w = row N of the augmented factor (read before K is
@@ -228,6 +265,7 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov, const BatchPlan& bp, bool want_me
   const int cMp = ctx->cMp, cmt = cMp / TILE;
   const double* K = ctx->K.d();
   KernelParams kp = ctx->theta;
+  RoctxRange r_post(want_cov ? "gpx:posterior (trsm, mean, cov syrk)" : "gpx:posterior (trsm, mean, var)");
   double* Vt;
   int64_t ldv, v_bs;
   if (ctx->fused_vt) { // already solved during the factorisation
@@ -297,6 +335,7 @@ int dev_posterior(gpx_ctx* ctx, bool want_cov) {
 int dev_draw(gpx_ctx* ctx, int n_pad, int n, const BatchPlan& bp, int m0 = 0, int mc = -1) {
   const int Mp = ctx->cMp, mt = Mp / TILE, B = bp.B;
   if (mc < 0) mc = ctx->cM;
+  RoctxRange r_draw("gpx:mvn_draw (chol(cov), L eps)");
   if (!ctx->cov_factored) {
     GPX_TRY(ensure(ctx, ctx->CovLinv, (size_t)B * bp.covlinv_bs * sizeof(double)));
     // first block resets the pivot report; later blocks keep the first failure (potf2 only writes a zero slot)

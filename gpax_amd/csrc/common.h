@@ -240,6 +240,18 @@ inline int bad_arg(gpx_ctx* ctx, const char* msg) {
     if (_rc < 0) return _rc; \
   } while (0)
 
+// roctx ranges around the pipeline stages (tracing) — `rocprofv3 --marker-trace` shows them on the host
+// timeline.  The roctx library (librocprofiler-sdk-roctx.so.1, else libroctx64.so.4) is bound with dlopen the first
+// time a range is opened and only when GPX_ROCTX=1, so an untraced run pays one branch per stage.
+void roctx_push(const char* name);
+void roctx_pop();
+struct RoctxRange {
+  explicit RoctxRange(const char* name) { roctx_push(name); }
+  ~RoctxRange() { roctx_pop(); }
+  RoctxRange(const RoctxRange&) = delete;
+  RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 // Bracket a kernel launch with events when profiling is on.
 struct ProfScope {
   gpx_ctx* ctx;

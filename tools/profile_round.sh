@@ -1,30 +1,37 @@
 #!/bin/bash
 # Regenerate the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   kernel-trace + stats of the default bench command, and separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*),
-#   summarised on the box (the rocpd sqlite databases stay in /tmp; only .md / .json summaries come back).
-# NOTE (round 1): a single pass with five TCC_* derived counters (TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
-# TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum) on `bench.py --steps 1` did not finish within 10 minutes on this pool —
-# keep L2 counters out of this script, or collect one per pass on a much shorter workload with its own timeout.
+#   bash tools/profile_round.sh r02
+#   kernel-trace + stats of the default bench command, separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*), the C4
+#   sweep (S = 1000) with its own kernel trace, and the round's bench line; summarised on the box (the rocpd sqlite
+#   databases stay in /tmp; only .md / .json summaries come back under gpurun_out/prof — copy them to profiles/<round>).
+# NOTE (round 1): a single pass with five TCC_* derived counters on `bench.py --steps 1` did not finish within 10
+# minutes on this pool — keep L2 counters out of this script.  --pmc passes carry --kernel-trace only (gpurun refuses
+# --pmc together with the hip / hsa / memory trace domains).
+RND=${1:-r02}
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/prof
 rm -rf $O && mkdir -p $O
 run() {
-  name=$1; args=$2; shift 2
+  name=$1; cmd=$2; shift 2
   rm -rf /tmp/prof_$name
-  rocprofv3 "$@" -d /tmp/prof_$name -- python bench.py --no-cpu-baseline $args > $O/bench_under_$name.json 2> $O/$name.err
+  timeout 600 rocprofv3 "$@" -d /tmp/prof_$name -- $cmd > $O/under_$name.json 2> $O/$name.err
   db=$(find /tmp/prof_$name -name '*.db' | head -1)
-  echo "## rocprofv3 $name pass: rocprofv3 $* -- python bench.py --no-cpu-baseline $args" > $O/$name.md
+  echo "## rocprofv3 $name pass: rocprofv3 $* -- $cmd" > $O/$name.md
   python tools/rocpd_summary.py "$db" $O/$name.md $O/traffic.json > /dev/null 2>> $O/$name.err
-  tail -c 300 $O/bench_under_$name.json | head -c 300; echo
+  tail -c 300 $O/under_$name.json | head -c 300; echo
 }
-run trace "" --kernel-trace --stats
+B="python bench.py --no-cpu-baseline"
+run trace "$B" --kernel-trace --stats
 # one theta in flight: the dominant kernel's average duration here is the one bench.py's roofline block measures
 # (its profile pass runs on a single context); with 3 contexts in flight (pass above) concurrent kernels stretch
-run trace1 "--inflight 1" --kernel-trace --stats
-run fetch "--steps 1 --warmup 0" --pmc FETCH_SIZE
-run write "--steps 1 --warmup 0" --pmc WRITE_SIZE
-run sq "--steps 1 --warmup 0" --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
-python bench.py > $O/bench_r01.json 2> $O/bench_r01.err
-cut -c1-400 $O/bench_r01.json
+run trace1 "$B --inflight 1" --kernel-trace --stats
+run fetch "$B --steps 1 --warmup 0" --kernel-trace --pmc FETCH_SIZE
+run write "$B --steps 1 --warmup 0" --kernel-trace --pmc WRITE_SIZE
+run sq "$B --steps 1 --warmup 0" --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
+# C4: the 1000-sample sweep at N = 8192, d = 3 through ExactGP.predict, plain and under the kernel trace
+python tools/c4_sweep.py > $O/c4_sweep.json 2> $O/c4_sweep.err
+run c4trace "python tools/c4_sweep.py" --kernel-trace --stats
+python bench.py > $O/bench_$RND.json 2> $O/bench_$RND.err
+cut -c1-400 $O/bench_$RND.json
 ls -la $O

@@ -25,14 +25,16 @@ def main():
         for name, cn, n, s, a in pmc:
             short = name if len(name) < 70 else name[:67] + "..."
             lines.append(f"| `{short}` | {cn} | {n} | {s:.6g} | {a:.6g} |")
-    # the dominant kernel has its own symbol: gpx::gemm_nt_kernel<1> (Cholesky trailing SYRK)
+    # the dominant kernel has its own symbol: gpx::gemm_nt128_kernel<1, EPI> (Cholesky trailing SYRK; round 1:
+    # gemm_nt_kernel<1, ...>)
     try:
         rows = cur.execute("select counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection "
-                           "where kernel_name like '%gemm_nt_kernel<1,%' group by counter_name").fetchall()
+                           "where kernel_name like '%gemm_nt128_kernel<1,%' or kernel_name like '%gemm_nt_kernel<1,%' "
+                           "group by counter_name").fetchall()
     except Exception:
         rows = []
     for cname, n, tot, avg, dur in rows:
-        lines += ["", f"DOMINANT gemm_nt_kernel<1>: {n} dispatches, {cname} sum = {tot:.6g}, avg per launch = {avg:.6g}, "
+        lines += ["", f"DOMINANT trailing-update kernel: {n} dispatches, {cname} sum = {tot:.6g}, avg per launch = {avg:.6g}, "
                       f"avg duration under PMC = {dur / 1e3:.1f} us"]
         if len(sys.argv) > 3:
             import json
