@@ -647,6 +647,9 @@ int gpx_init(int device, gpx_ctx** out) {
         (void)hipGetLastError();
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
+    if (ctx->evD) (void)hipEventDestroy(ctx->evD);
+    if (ctx->evQ) (void)hipEventDestroy(ctx->evQ);
+    if (ctx->qstream) (void)hipStreamDestroy(ctx->qstream);
         ctx->stream = ctx->rstream = nullptr;
         reserve = 0;
       } else {
@@ -655,12 +658,20 @@ int gpx_init(int device, gpx_ctx** out) {
       }
     }
     ctx->cu_reserved = reserve;
+    if (const char* e = getenv("GPX_LAZY_GROUP")) {
+      const int lg = atoi(e);
+      if (lg >= 1 && lg <= 16) ctx->lazy_group = lg;
+    }
     if (const char* e = getenv("GPX_OUTER_TILES")) {
       const int ot = atoi(e);
       if (ot >= 1 && ot <= 32) ctx->outer_tiles = ot;
     }
     if (!ctx->stream) GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, lo));
     GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->pstream, hipStreamNonBlocking, hi));
+    GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->qstream, hipStreamNonBlocking, hi));
+    GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evD, hipEventDisableTiming));
+    GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evQ, hipEventDisableTiming));
+    if (const char* e = getenv("GPX_EARLY_DIAG")) ctx->early_diag = (e[0] != '0');
     ctx->s = ctx->stream;
   }
   GPX_HIP(ctx, hipEventCreate(&ctx->ev0));
@@ -698,6 +709,9 @@ void gpx_destroy(gpx_ctx* ctx) {
     if (ctx->evR0) (void)hipEventDestroy(ctx->evR0);
     if (ctx->evR1) (void)hipEventDestroy(ctx->evR1);
     if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
+    if (ctx->evD) (void)hipEventDestroy(ctx->evD);
+    if (ctx->evQ) (void)hipEventDestroy(ctx->evQ);
+    if (ctx->qstream) (void)hipStreamDestroy(ctx->qstream);
     if (ctx->pstream) (void)hipStreamDestroy(ctx->pstream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   }

@@ -146,10 +146,17 @@ struct gpx_ctx {
   hipStream_t rstream = nullptr;
   int cu_reserved = 0;
   hipEvent_t evR0 = nullptr, evR1 = nullptr;
+  // early diagonal (linalg.hip): the next diagonal block is factored on `qstream` while the rest of the update that
+  // produced it is still running on the panel stream
+  hipStream_t qstream = nullptr;
+  hipEvent_t evD = nullptr, evQ = nullptr;
+  int early_diag = 0; // GPX_EARLY_DIAG=1 switches it on: measured slower (profiles/r02/chain_experiments.md), default off
   std::vector<hipEvent_t> evP, evU; // per-outer-block panel / next-panel-update events
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   hipDeviceProp_t prop;
+  int lazy_group = 1; // GPX_LAZY_GROUP: outer blocks whose far (bulk) trailing update is applied in one launch (linalg.hip);
+                      // 2 is 2 % faster for one theta alone and 17 % slower with 3 contexts in flight: default 1
   int outer_tiles = gpx::OUTER_TILES; // GPX_OUTER_TILES (experiments): K of the trailing update = 128 * outer_tiles
   unsigned func_attr_mask = 0; // kernels whose dynamic-LDS attribute this context has set on ITS device (bit per variant)
 
@@ -308,6 +315,8 @@ struct GemmArgs {
   int kupper;  // k range ends at (tj_off + bx + 1) * 128 (B lower triangular, e.g. chol factor)
   int kchunk;  // split-K chunk (multiple of 16), 0 = no split
   int64_t c_split_stride;
+  int skip;    // != 0: the 128-tile (skip_ti, skip_tj) of the caller's global tile frame is left out (it was updated by
+  int skip_ti, skip_tj; // an earlier launch of its own: the "early diagonal" of the Cholesky panel chain, linalg.hip)
   int nsplit;  // grid.z = nsplit * batch (filled in by launch_gemm_nt)
   int batch;   // independent problems per launch (0 or 1 = one); element b at base + b * *_bs
   int64_t a_bs, b_bs, c_bs;

@@ -57,7 +57,7 @@ constexpr size_t gemm_lds_bytes() {
 // DBUF = false: single LDS buffer (two barriers per k-step) — 17 KB for the 64x64 shape, which fits
 // in the LDS two resident trailing-update workgroups leave free, so a chain launch is placed at once.
 template <int TAG, int MT, int NT, int BK, bool DBUF>
-__global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)) void gemm_nt_kernel(GemmArgs g) {
   constexpr int BM = 32 * MT, BN = 32 * NT, LDT = BK + 1;
   constexpr int TA = BM * LDT, TB = BN * LDT;
   constexpr int TPR = BK / 2;    // threads per staged row (one double2 each)
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : 3) void gemm_nt_kernel(G
   // element coordinates of this tile in the caller's global tile frame (offsets given in 128-tiles)
   const int row0 = g.ti_off * 128 + by * BM, col0 = g.tj_off * 128 + bx * BN;
   if (g.lower && col0 > row0 + BM - 1) return; // entirely above the diagonal
+  if (g.skip && (row0 >> 7) == g.skip_ti && (col0 >> 7) == g.skip_tj) return; // updated by its own launch
 
   int kb = 0, ke = g.K;
   if (g.ktri) kb = row0 & ~(BK - 1);            // A rows are zero left of the diagonal (upper-triangular operand)
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
   const int bz = blockIdx.z - bb * g.nsplit;
   const int row0 = g.ti_off * 128 + by * BM, col0 = g.tj_off * 128 + bx * BN;
   if (g.lower && col0 > row0 + BM - 1) return; // entirely above the diagonal
+  if (g.skip && (row0 >> 7) == g.skip_ti && (col0 >> 7) == g.skip_tj) return; // updated by its own launch
 
   int kb = 0, ke = g.K;
   if (g.ktri) kb = row0 & ~(BK - 1);
@@ -443,7 +445,10 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   }
   if (small_ok && tiles < 400.0) {
     if (g.C == g.A) { // in-place (panel TRSM): one workgroup must own the whole row width
-      if (tiles_n == 1) return launch_variant<0, 2, 4, 16, true>(ctx, g, tiles_m, tiles_n, splits);
+      // 32x128 strip, single LDS buffer: 22 KB and < 80 VGPRs, i.e. it fits in what two resident trailing-update
+      // workgroups leave free on a CU (32 KB, 80 registers per SIMD) and is placed at once; the round-1 64x128 shape
+      // (52 KB, 125 VGPRs) had to wait for a trailing workgroup to retire — half a tile time (~50 us) per panel step
+      if (tiles_n == 1) return launch_variant<0, 1, 4, 16, false>(ctx, g, tiles_m, tiles_n, splits);
     } else {
       return launch_variant<0, 2, 2, 16, false>(ctx, g, tiles_m, tiles_n, splits);
     }

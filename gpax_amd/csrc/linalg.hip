@@ -53,12 +53,46 @@ static inline void set_batch(GemmArgs& g, int batch, int64_t a_bs, int64_t b_bs,
   g.c_bs = c_bs;
 }
 
+// Factor the diagonal block kb on the q stream, after everything queued so far on the panel stream (which has just
+// brought that block up to date), and remember that the panel stream must wait for it (evQ) before it uses the result.
+static int queue_potf2(gpx_ctx* ctx, double* dA, int64_t lda, int kb, double* dLinv, int* dInfo,
+                       const BatchStrides& bs) {
+  hipStream_t span = ctx->s;
+  GPX_HIP(ctx, hipEventRecord(ctx->evD, span));
+  GPX_HIP(ctx, hipStreamWaitEvent(ctx->qstream, ctx->evD, 0));
+  ctx->s = ctx->qstream;
+  const int rc = launch_potf2_inv(ctx, dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE, lda,
+                                  dLinv + (int64_t)kb * TILE * TILE, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs);
+  ctx->s = span;
+  GPX_TRY(rc);
+  GPX_HIP(ctx, hipEventRecord(ctx->evQ, ctx->qstream));
+  return 0;
+}
+
+// One outer block (diagonal blocks ob .. oe-1).  Per diagonal block kb: potf2 (+ inverse) -> panel TRSM (GEMM with
+// the inverse) -> update of the outer block's remaining columns.
+// EARLY DIAGONAL: potf2(kb + 1) only needs the diagonal tile (kb+1, kb+1) of that update.  The tile is updated by a
+// launch of its own, its factorisation is queued on the q stream at once, and the rest of the update (that tile
+// skipped) runs meanwhile on the panel stream: per step the chain is TRSM + max(potf2, update) instead of their sum
+// (inside the pipeline a potf2 launch costs ~160 us next to resident trailing-update workgroups, the update ~50 us).
+// Every tile still receives the same updates in the same order: results do not change (tests/test_gpu_edges.py).
+// MEASURED AND LEFT OFF BY DEFAULT (GPX_EARLY_DIAG=1 enables it; profiles/r02/chain_experiments.md): the extra
+// one-tile launches (161 per C3 factorisation) cost more than the overlap saves — every dependent launch of the chain
+// pays ~40-50 us next to the saturating trailing update, whatever its size: potrf 31.4 -> 32.6 ms.
+// first_queued: potf2(ob) was queued on the q stream by the caller (the early diagonal of U1).
 static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob, int oe,
-                       double* dLinv, int* dInfo, const BatchStrides& bs) {
+                       double* dLinv, int* dInfo, const BatchStrides& bs, bool first_queued) {
+  const bool early = ctx->early_diag != 0 && ctx->qstream != nullptr;
+  bool queued = first_queued;
   for (int kb = ob; kb < oe; ++kb) {
     double* Akk = dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE;
     double* Li = dLinv + (int64_t)kb * TILE * TILE;
-    GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs));
+    if (queued) {
+      GPX_HIP(ctx, hipStreamWaitEvent(ctx->s, ctx->evQ, 0)); // L_kk and its inverse come from the q stream
+      queued = false;
+    } else {
+      GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs));
+    }
     const int below = nblk - kb - 1 + extra;
     if (below <= 0) continue;
     double* Apan = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)kb * TILE;
@@ -76,6 +110,14 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
       g.lower = 1;
       g.ti_off = kb + 1;
       g.tj_off = kb + 1;
+      if (early) { // the next diagonal tile first, its factorisation on the q stream, then everything else
+        GPX_TRY(launch_gemm_nt(ctx, g, 1, 1, 0, GPX_PROF_GEMM_OTHER, (double)TILE * (TILE + 1.0) * TILE));
+        GPX_TRY(queue_potf2(ctx, dA, lda, kb + 1, dLinv, dInfo, bs));
+        queued = true;
+        g.skip = 1;
+        g.skip_ti = kb + 1;
+        g.skip_tj = kb + 1;
+      }
       GPX_TRY(launch_gemm_nt(ctx, g, below, inner_cols, 0, GPX_PROF_GEMM_OTHER,
                              2.0 * below * inner_cols * (double)TILE * TILE * TILE));
     }
@@ -84,9 +126,15 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
 }
 
 // C[rows r0.., cols c0..c1) -= Pan[rows, ob..oe) * Pan[cols, ob..oe)^T, lower tiles only.
+// only_tile >= 0: just the diagonal tile (only_tile, only_tile); skip_tile >= 0: everything but that diagonal tile.
 static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob,
-                           int oe, int r0, int c0, int c1, int prof_cls, const BatchStrides& bs) {
-  const int rows = nblk + extra - r0, cols = c1 - c0;
+                           int oe, int r0, int c0, int c1, int prof_cls, const BatchStrides& bs,
+                           int only_tile = -1, int skip_tile = -1) {
+  int rows = nblk + extra - r0, cols = c1 - c0;
+  if (only_tile >= 0) {
+    r0 = c0 = only_tile;
+    rows = cols = 1;
+  }
   if (rows <= 0 || cols <= 0) return 0;
   const int K = (oe - ob) * TILE;
   const double* PanR = dA + (int64_t)r0 * TILE * lda + (int64_t)ob * TILE;
@@ -97,13 +145,22 @@ static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int 
   g.lower = 1;
   g.ti_off = r0;
   g.tj_off = c0;
+  if (skip_tile >= 0) {
+    g.skip = 1;
+    g.skip_ti = g.skip_tj = skip_tile;
+  }
   // algorithmic flops: 2K per updated entry with column <= row
   double entries = 0.0;
-  for (int t = 0; t < cols; ++t) {
-    const int first_row_tile = (c0 + t > r0) ? c0 + t : r0; // rows below the diagonal tile
-    const double full = (double)(nblk + extra - first_row_tile - (c0 + t >= r0 ? 1 : 0)) * TILE * TILE;
-    const double diag = (c0 + t >= r0) ? 0.5 * TILE * (TILE + 1.0) : 0.0;
-    entries += full + diag;
+  if (only_tile >= 0) {
+    entries = 0.5 * TILE * (TILE + 1.0);
+  } else {
+    for (int t = 0; t < cols; ++t) {
+      const int first_row_tile = (c0 + t > r0) ? c0 + t : r0; // rows below the diagonal tile
+      const double full = (double)(nblk + extra - first_row_tile - (c0 + t >= r0 ? 1 : 0)) * TILE * TILE;
+      const double diag = (c0 + t >= r0) ? 0.5 * TILE * (TILE + 1.0) : 0.0;
+      entries += full + diag;
+    }
+    if (skip_tile >= 0) entries -= 0.5 * TILE * (TILE + 1.0);
   }
   return launch_gemm_nt(ctx, g, rows, cols, 0, prof_cls, 2.0 * K * entries);
 }
@@ -119,41 +176,87 @@ static int ensure_events(gpx_ctx* ctx, int nouter) {
   return 0;
 }
 
+// Lazy far updates (ctx->lazy_group = G outer blocks).  With accumulators that start from -C (gemm_f64.hip) an
+// update with K = 512 followed by another with K = 512 is, bit for bit, ONE fma chain of length 1024 — a C tile
+// stored and reloaded between the two is the same double.  So how the k range of a tile's updates is cut into
+// launches is free, and the bulk of the trailing matrix can take the panels of G outer blocks in one launch
+// (K = 512 G: half / a quarter of the C read-modify-write traffic and of the per-tile prologue / epilogue, the
+// difference between 56 and 63 / 69 TFLOP/s for this kernel on random data), as long as every tile still receives
+// its panels in ascending order.  Outer blocks are grouped G at a time; ge(k) = last block of k's group.
+//   P(k)        panel stream: factor outer block k (potf2 / TRSM / inner updates)
+//   U1(k)       panel stream: K = 512 update from block k alone of the columns that cannot wait for the group's far
+//               update: outer columns k+1 .. ge(k)+1 (P(k+1) needs column k+1 next)
+//   far(g)      main stream, at k = ge(k), K = all columns of the group: first the outer columns ge+2 .. ge+G+1
+//               ("near-far": the next group's U1 launches write them, and only wait for THIS launch), then the bulk
+//               ge+G+2 .. end.
+// Column c thus receives whole groups while group_end <= c - 2, then single blocks — ascending throughout; the
+// event after the near-far launch orders the next group's singles behind it.  G = 1 is the round-1 schedule
+// (U1 = next block's columns, U2 = the rest), except that U1 now waits for the near-far slice only.
 int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,
                 int* dInfo, int batch, int64_t a_bs, int64_t linv_bs) {
   const BatchStrides bs{batch > 1 ? batch : 1, a_bs, linv_bs};
   const int nblk = np / TILE;
   const int OT = ctx->outer_tiles;
+  const int G = ctx->lazy_group > 0 ? ctx->lazy_group : 1;
   const int nouter = (nblk + OT - 1) / OT;
   GPX_TRY(ensure_events(ctx, nouter));
   hipStream_t smain = ctx->stream, span = ctx->pstream;
+  auto ob_of = [&](int k) { return (k * OT < nblk) ? k * OT : nblk; }; // first tile column of outer block k (clamped)
   // the panel stream starts after everything already queued on the main stream (Gram etc.)
   GPX_HIP(ctx, hipEventRecord(ctx->evU[nouter], smain));
   GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[nouter], 0));
   int rc = 0;
+  const bool early = ctx->early_diag != 0 && ctx->qstream != nullptr;
+  bool first_queued = false; // potf2 of the next outer block's first diagonal block already queued on the q stream
   for (int k = 0; k < nouter && rc >= 0; ++k) {
-    const int ob = k * OT;
-    const int oe = (ob + OT < nblk) ? ob + OT : nblk;
-    const int oe2 = (oe + OT < nblk) ? oe + OT : nblk;
+    const int ob = ob_of(k), oe = ob_of(k + 1);
+    const int gs = (k / G) * G;                                      // first block of k's group
+    const int ge = (gs + G - 1 < nouter - 1) ? gs + G - 1 : nouter - 1; // last block of k's group
     // P(k) on the panel stream (it follows U1(k-1) there, in stream order)
     ctx->s = span;
-    rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs);
+    rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs, first_queued);
+    first_queued = false;
     if (rc < 0) break;
     GPX_HIP(ctx, hipEventRecord(ctx->evP[k], span));
-    GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
-    if (oe < nblk) {
-      // U1(k): next panel's columns, on the PANEL stream (it is what P(k+1) waits for), after
-      // U2(k-1) which also wrote those columns.  U2(k) starts on the main stream at the same time:
-      // disjoint C tiles, so the big SYRKs run back to back with no U1 gap between them.
-      if (k > 0) GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
-      // (profiled / prioritised with the panel GEMMs: it is latency-critical and overlaps U2)
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, oe2, GPX_PROF_GEMM_OTHER, bs);
+    if (oe >= nblk) {
+      GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
+      break;
+    }
+    // U1(k): block k alone (K = its columns) onto outer columns k+1 .. ge+1, on the PANEL stream.  The first block of
+    // a group writes columns the previous group's near-far launch also wrote: wait for that launch (fixed order).
+    if (k == gs && k > 0) GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
+    int skip_tile = -1;
+    if (early) { // early diagonal: tile (oe, oe) first, potf2(oe) on the q stream while the rest of U1(k) runs
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, oe + 1, GPX_PROF_GEMM_OTHER, bs, oe);
       if (rc < 0) break;
+      rc = queue_potf2(ctx, dA, lda, oe, dLinv, dInfo, bs);
+      if (rc < 0) break;
+      first_queued = true;
+      skip_tile = oe;
+    }
+    rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, ob_of(ge + 2), GPX_PROF_GEMM_OTHER, bs, -1,
+                         skip_tile);
+    if (rc < 0) break;
+    if (k == ge) { // far update of the whole group on the main stream
+      GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
       ctx->s = smain;
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe2, oe2, nblk, GPX_PROF_GEMM_TRAILING, bs);
-      GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain));
+      const int gob = ob_of(gs);
+      // G = 1: no near-far slice (a launch of < 512 tiles fills the chip badly: 61 launches at 32.4 ms against 31 at
+      // 28.7 ms per factorisation) — one launch, the round-1 schedule
+      const int n0 = ob_of(ge + 2), n1 = (G == 1) ? nblk : ob_of(ge + G + 2);
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n0, n0, n1, GPX_PROF_GEMM_TRAILING, bs);
+      if (rc < 0) break;
+      GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain)); // what the next group's first U1 waits for
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n1, n1, nblk, GPX_PROF_GEMM_TRAILING, bs);
     }
   }
+  // everything queued on the q / panel streams happens-before whatever follows on the main stream
+  if (ctx->qstream) {
+    GPX_HIP(ctx, hipEventRecord(ctx->evQ, ctx->qstream));
+    GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evQ, 0));
+  }
+  GPX_HIP(ctx, hipEventRecord(ctx->evP[nouter], span));
+  GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[nouter], 0));
   ctx->s = smain;
   return rc;
 }

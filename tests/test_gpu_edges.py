@@ -137,3 +137,37 @@ def test_bad_arguments_are_errors_not_crashes(engine):
         engine.predict_sweep(1, np.ones((2, 2)), np.ones(2), np.ones(2), y, Xn[:, :1], False, 1e-6, None)  # d mismatch
     lml, info = engine.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
     assert info == 0
+
+
+def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
+    """linalg.hip potrf_lower: the bulk of the trailing matrix may take the panels of G outer blocks in one launch
+    (K = 512 G).  With accumulators starting from -C every tile's updates form ONE fma chain however the k range is
+    cut into launches, so the factor, the ride-along solve and the draws are bit-identical for every G (and for the
+    outer blocking itself)."""
+    import numpy as np
+    from bench_inputs import synthetic_problem
+    from gpax_amd import _lib
+
+    N, d, M = 2700, 2, 300  # 22 diagonal blocks = 6 outer blocks: several groups, a ragged last one, ride-along rows
+    X, y, Xn, p = synthetic_problem(N, d, M, seed=13)
+    eps = np.random.default_rng(1).standard_normal((2, 1, M))
+    ells = np.stack([p["k_length"], 1.1 * p["k_length"]])
+    outs = []
+    for group, outer, early in [("1", "4", "1"), ("1", "4", "0"), ("2", "4", "1"), ("3", "4", "0"), ("4", "4", "1"),
+                                ("1", "2", "1"), ("2", "3", "1")]:
+        monkeypatch.setenv("GPX_LAZY_GROUP", group)
+        monkeypatch.setenv("GPX_OUTER_TILES", outer)
+        monkeypatch.setenv("GPX_EARLY_DIAG", early)  # potf2 of the next diagonal block overlapped with the update
+        e = _lib.Engine(0)
+        e.set_train(X)
+        lml, info = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+        mean, cov, _ = e.posterior(Xn, p["noise"], 1e-6)
+        sweep = e.predict_sweep(1, ells, [p["k_scale"]] * 2, [p["noise"]] * 2, y, Xn, False, 1e-6, eps)
+        lml2, _ = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+        grad = e.lml_grad()
+        outs.append((lml, mean, cov, sweep[0], sweep[1], grad[0], grad[3]))
+        assert info == 0
+        e.close()
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
