@@ -214,7 +214,11 @@ int dev_grad(gpx_ctx* ctx, const BatchPlan& bp) {
     g.b_bs = w_bs;
     g.c_bs = bp.k_bs;
     const double n = (double)n128;
-    GPX_TRY(launch_gemm_nt(ctx, g, nt, nt, 0, GPX_PROF_GEMM_OTHER, n * n * n / 3.0));
+    // tiles of very different length (k range [row, N)) and nothing else in flight: persistent, dynamically scheduled
+    if (ctx->persist_scope_ok) ctx->persist_scope += 1;
+    const int rc_kinv = launch_gemm_nt(ctx, g, nt, nt, 0, GPX_PROF_GEMM_OTHER, n * n * n / 3.0);
+    if (ctx->persist_scope_ok) ctx->persist_scope -= 1;
+    GPX_TRY(rc_kinv);
   }
   const int nt64 = (N + 63) / 64;
   GPX_TRY(ensure(ctx, ctx->part, (size_t)B * nt64 * (nt64 + 1) / 2 * (GPX_MAX_DIM + 3) * sizeof(double)));
@@ -658,6 +662,10 @@ int gpx_init(int device, gpx_ctx** out) {
       }
     }
     ctx->cu_reserved = reserve;
+    ctx->persist_gemm = reserve > 0;
+    if (const char* e = getenv("GPX_PERSIST_GEMM")) ctx->persist_gemm = (e[0] == '1');
+    if (const char* e = getenv("GPX_PERSIST_SLACK")) ctx->persist_slack = atoi(e);
+    if (const char* e = getenv("GPX_PERSIST_SCOPE")) ctx->persist_scope_ok = (e[0] != '0');
     if (const char* e = getenv("GPX_LAZY_GROUP")) {
       const int lg = atoi(e);
       if (lg >= 1 && lg <= 16) ctx->lazy_group = lg;
@@ -696,7 +704,7 @@ void gpx_destroy(gpx_ctx* ctx) {
                       &ctx->part, &ctx->alpha, &ctx->Xnew,  &ctx->Vt,     &ctx->Cov,  &ctx->CovLinv,
                       &ctx->SplitK, &ctx->mean, &ctx->var,  &ctx->eps,    &ctx->draws, &ctx->tA,
                       &ctx->tB,   &ctx->tC,  &ctx->thtab,   &ctx->binfo, &ctx->bscal, &ctx->byres, &ctx->diagv, &ctx->st_eps, &ctx->st_yres,
-                      &ctx->st_means, &ctx->st_samples, &ctx->st_infos, &ctx->st_vars, &ctx->st_pred};
+                      &ctx->st_means, &ctx->st_samples, &ctx->st_infos, &ctx->st_vars, &ctx->st_pred, &ctx->tile_counters};
     for (DevBuf* b : bufs) b->release();
     ctx->pin_in.release();
     ctx->pin_out.release();

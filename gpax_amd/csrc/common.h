@@ -13,6 +13,7 @@
 
 namespace gpx {
 
+constexpr int GPX_TILE_COUNTERS = 1024;
 constexpr int TILE = 128;      // MFMA GEMM block tile and diagonal-block size
 constexpr int OUTER_TILES = 4; // default outer blocking of the right-looking sweeps (4*128 = 512); ctx->outer_tiles
 constexpr double AUG_BIG = 1e300;
@@ -150,6 +151,15 @@ struct gpx_ctx {
   // produced it is still running on the panel stream
   hipStream_t qstream = nullptr;
   hipEvent_t evD = nullptr, evQ = nullptr;
+  // persistent, dynamically scheduled big-tile GEMM (gemm_f64.hip) — switched on together with the CU reservation
+  bool persist_gemm = false;
+  // > 0 while a driver whose own panel chain holds no potf2 (the right-looking TRSM sweeps, the K^-1 = W W^T product)
+  // is queueing launches: its big-tile GEMMs run persistently (GPX_PERSIST_SCOPE=0 disables)
+  int persist_slack = 0;
+  int persist_scope = 0;
+  bool persist_scope_ok = true;
+  gpx::DevBuf tile_counters;
+  unsigned tile_counter_seq = 0;
   int early_diag = 0; // GPX_EARLY_DIAG=1 switches it on: measured slower (profiles/r02/chain_experiments.md), default off
   std::vector<hipEvent_t> evP, evU; // per-outer-block panel / next-panel-update events
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

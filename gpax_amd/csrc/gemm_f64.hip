@@ -218,18 +218,16 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)
 
 // ---- throughput shape -------------------------------------------------------------------------------
 typedef void __attribute__((address_space(3)))* lds_ptr_t;
+typedef const volatile double __attribute__((address_space(3)))* lds_cvd_t;
 
 // EPI: 0 beta == 0 | 1 alpha == -1, beta == 1 (accumulators start from -C) | 2 generic read-modify-write
 // TAG only gives the Cholesky trailing update (TAG = 1) its own symbol, so that rocprofv3 kernel statistics
 // separate the dominant kernel from the other GEMM launches (TAG = 0).
-template <int TAG, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
+template <int EPI>
+__device__ __forceinline__ void nt128_tile(const GemmArgs& g, double* smem, const int bx, const int by, const int bzz) {
   constexpr int BK = 16, BM = 128, BN = 128, TD = (BM + BN) * BK, GPW = 8;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (TAG == 0) __builtin_amdgcn_s_setprio(2); // non-trailing launches sit on the critical path of the look-ahead
-  const int bx = blockIdx.x, by = blockIdx.y;
-  const int bb = (g.batch > 1) ? blockIdx.z / g.nsplit : 0;
-  const int bz = blockIdx.z - bb * g.nsplit;
+  const int bb = (g.batch > 1) ? bzz / g.nsplit : 0;
+  const int bz = bzz - bb * g.nsplit;
   const int row0 = g.ti_off * 128 + by * BM, col0 = g.tj_off * 128 + bx * BN;
   if (g.lower && col0 > row0 + BM - 1) return; // entirely above the diagonal
   if (g.skip && (row0 >> 7) == g.skip_ti && (col0 >> 7) == g.skip_tj) return; // updated by its own launch
@@ -313,8 +311,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
         double af[4], bf[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          af[m] = cb[aoff[m] ^ (4 * kk)];
-          bf[m] = cb[boff[m] ^ (4 * kk)];
+          // volatile LDS-address-space loads: one ds_read_b64 each.  Left alone the compiler pairs fragments 2 KB
+          // apart into ds_read2st64_b64, whose 32-bank, 16-lane-group banking the swizzle is not made for
+          // (SQ_LDS_BANK_CONFLICT 2.6e7 per launch, profiles/r02/sq.md) and which moves half the bytes per LDS cycle
+          af[m] = *((lds_cvd_t)cb + (aoff[m] ^ (4 * kk)));
+          bf[m] = *((lds_cvd_t)cb + (boff[m] ^ (4 * kk)));
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -373,10 +374,86 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
   }
 }
 
+template <int TAG, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (TAG == 0) __builtin_amdgcn_s_setprio(2); // non-trailing launches sit on the critical path of the look-ahead
+  nt128_tile<EPI>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Tile enumeration of a persistent launch: only the tiles a launch really has (lower: tj_off + bx <= ti_off + by),
+// row-major (consecutive ids share their A row panel), one slab per (batch entry, split-K slab).
+struct TileMap {
+  int tiles_m, tiles_n, per_slab, total;
+  int a, f0, b, tri; // rows a .. b-1 hold f0, f0 + 1, ... tiles (the triangular part, `tri` tiles), rows >= b tiles_n each
+};
+
+// PERSISTENT, dynamically scheduled variant (used when CUs are reserved for the panel chain, gpx_init): the grid is
+// two workgroups per CU the stream may use; each takes the next tile from an atomic counter until none is left.  A
+// tile's arithmetic does not depend on who computes it, so results are those of gemm_nt128_kernel bit for bit; what
+// changes is that a CU-masked queue no longer suffers from the dispatcher spreading workgroups evenly over shader
+// engines of unequal size (profiles/r02/cu_reserve.md): every resident workgroup simply works until the queue is dry.
+template <int TAG, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt128_persist_kernel(GemmArgs g, TileMap tm, int* __restrict__ counter) {
+  constexpr int TD = 256 * 16;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (TAG == 0) __builtin_amdgcn_s_setprio(2);
+  int* s_tile = reinterpret_cast<int*>(smem + 2 * TD); // 16 B behind the two k-tile buffers (one LDS object only)
+  for (;;) {
+    if (threadIdx.x == 0) *s_tile = atomicAdd(counter, 1);
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane(*s_tile);
+    if (t >= tm.total) return;
+    const int bzz = t / tm.per_slab;
+    int l = t - bzz * tm.per_slab, by, bx;
+    if (!g.lower) {
+      by = l / tm.tiles_n;
+      bx = l - by * tm.tiles_n;
+    } else if (l < tm.tri) { // n = rows before `by` in the triangular part: n f0 + n (n - 1) / 2 <= l
+      const double q = 2.0 * tm.f0 - 1.0;
+      int n = (int)((-q + sqrt(q * q + 8.0 * l)) * 0.5);
+      while ((int64_t)(n + 1) * tm.f0 + (int64_t)(n + 1) * n / 2 <= l) ++n;
+      while ((int64_t)n * tm.f0 + (int64_t)n * (n - 1) / 2 > l) --n;
+      by = tm.a + n;
+      bx = l - (int)((int64_t)n * tm.f0 + (int64_t)n * (n - 1) / 2);
+    } else {
+      l -= tm.tri;
+      by = tm.b + l / tm.tiles_n;
+      bx = l - (l / tm.tiles_n) * tm.tiles_n;
+    }
+    nt128_tile<EPI>(g, smem, __builtin_amdgcn_readfirstlane(bx), __builtin_amdgcn_readfirstlane(by), bzz);
+    __syncthreads(); // every wave is done with the k-tile buffers and has read *s_tile
+  }
+}
+
+static TileMap make_tile_map(const GemmArgs& g, int tiles_m, int tiles_n) {
+  TileMap tm{};
+  tm.tiles_m = tiles_m;
+  tm.tiles_n = tiles_n;
+  if (!g.lower) {
+    tm.per_slab = tiles_m * tiles_n;
+  } else {
+    const int delta = g.ti_off - g.tj_off; // row by holds clamp(by + delta + 1, 0, tiles_n) tiles
+    int a = delta < 0 ? -delta : 0;
+    if (a > tiles_m) a = tiles_m;
+    int b = tiles_n - delta - 1;
+    if (b < a) b = a;
+    if (b > tiles_m) b = tiles_m;
+    tm.a = a;
+    tm.b = b;
+    tm.f0 = a + delta + 1;
+    const int64_t n = b - a;
+    tm.tri = (int)(n * tm.f0 + n * (n - 1) / 2);
+    tm.per_slab = tm.tri + (tiles_m - b) * tiles_n;
+  }
+  tm.total = tm.per_slab * g.nsplit * g.batch;
+  return tm;
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a function: every context sets it once
 // for each variant it launches (a process may hold contexts on several GPUs; contexts are also driven from
 // different host threads, so the "done" bits live in the context, not in a function-local static).
-enum : unsigned { ATTR_SMALL_22 = 0, ATTR_SMALL_24 = 1, ATTR_BIG_BASE = 2 /* + 3 * TAG + EPI */ };
+enum : unsigned { ATTR_SMALL_22 = 0, ATTR_SMALL_24 = 1, ATTR_BIG_BASE = 2 /* + 3 * TAG + EPI */, ATTR_PERSIST_BASE = 8 };
 
 template <int TAG, int MT, int NT, int BK, bool DBUF>
 static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int tiles_n, int splits) {
@@ -401,6 +478,28 @@ template <int TAG, int EPI>
 static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n) {
   constexpr size_t lds = (size_t)2 * 256 * 16 * sizeof(double); // 2 buffers x (128 A rows + 128 B rows) x 128 B
   constexpr unsigned bit = 1u << (ATTR_BIG_BASE + 3 * TAG + EPI);
+  if (ctx->persist_gemm || ctx->persist_scope > 0) {
+    constexpr unsigned pbit = 1u << (ATTR_PERSIST_BASE + 3 * TAG + EPI);
+    if (!(ctx->func_attr_mask & pbit)) {
+      GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_persist_kernel<TAG, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 16)));
+      ctx->func_attr_mask |= pbit;
+    }
+    const TileMap tm = make_tile_map(g, tiles_m, tiles_n);
+    if (tm.total <= 0) return 0;
+    // one counter per launch out of a ring: zeroed in stream order right before the launch that uses it
+    if (ctx->tile_counters.ensure(GPX_TILE_COUNTERS * sizeof(int)) != hipSuccess) return bad_arg(ctx, "tile counters");
+    int* counter = ctx->tile_counters.i() + (ctx->tile_counter_seq++ % GPX_TILE_COUNTERS);
+    GPX_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->s));
+    // persist_slack: workgroup slots deliberately left empty (GPX_PERSIST_SLACK) so that a chain kernel that cannot share
+    // a SIMD with two big-tile waves (potf2: 238 VGPRs) finds a CU with a single resident workgroup at once
+    int slots = 2 * (ctx->prop.multiProcessorCount - (ctx->rstream ? ctx->cu_reserved : 0));
+    if (ctx->persist_gemm && ctx->persist_slack > 0 && slots > 4 * ctx->persist_slack) slots -= ctx->persist_slack;
+    const int grid = tm.total < slots ? tm.total : slots;
+    gemm_nt128_persist_kernel<TAG, EPI><<<grid, 256, lds + 16, ctx->s>>>(g, tm, counter);
+    GPX_HIP(ctx, hipGetLastError());
+    return 0;
+  }
   if (!(ctx->func_attr_mask & bit)) {
     GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_kernel<TAG, EPI>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -443,7 +542,11 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
     const char* e = getenv("GPX_GEMM_SMALL");
     small_ok = (e && e[0] == '0') ? 0 : 1;
   }
-  if (small_ok && tiles < 400.0) {
+  // persistent mode: the trailing update's workgroups hold their slots until its queue is dry, so a big-shape launch
+  // on the panel stream would only find room on the reserved CUs: everything there takes the shapes that fit next to
+  // two resident trailing workgroups
+  const bool on_panel = (ctx->persist_gemm || ctx->persist_scope > 0) && ctx->s != ctx->stream;
+  if (small_ok && (tiles < 400.0 || on_panel)) {
     if (g.C == g.A) { // in-place (panel TRSM): one workgroup must own the whole row width
       // 32x128 strip, single LDS buffer: 22 KB and < 80 VGPRs, i.e. it fits in what two resident trailing-update
       // workgroups leave free on a CU (32 KB, 80 registers per SIMD) and is placed at once; the round-1 64x128 shape

@@ -153,11 +153,18 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
     eps = np.random.default_rng(1).standard_normal((2, 1, M))
     ells = np.stack([p["k_length"], 1.1 * p["k_length"]])
     outs = []
-    for group, outer, early in [("1", "4", "1"), ("1", "4", "0"), ("2", "4", "1"), ("3", "4", "0"), ("4", "4", "1"),
-                                ("1", "2", "1"), ("2", "3", "1")]:
-        monkeypatch.setenv("GPX_LAZY_GROUP", group)
-        monkeypatch.setenv("GPX_OUTER_TILES", outer)
-        monkeypatch.setenv("GPX_EARLY_DIAG", early)  # potf2 of the next diagonal block overlapped with the update
+    variants = [dict(), dict(GPX_EARLY_DIAG="1"), dict(GPX_LAZY_GROUP="2", GPX_EARLY_DIAG="1"), dict(GPX_LAZY_GROUP="3"),
+                dict(GPX_LAZY_GROUP="4", GPX_EARLY_DIAG="1"), dict(GPX_OUTER_TILES="2"),
+                dict(GPX_LAZY_GROUP="2", GPX_OUTER_TILES="3"),
+                # persistent, dynamically scheduled big-tile GEMM; with CUs reserved for the diagonal blocks
+                dict(GPX_PERSIST_GEMM="1"), dict(GPX_CU_RESERVE="8"), dict(GPX_CU_RESERVE="8", GPX_LAZY_GROUP="2"),
+                dict(GPX_PERSIST_SCOPE="0")]
+    for env in variants:
+        for k in ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_EARLY_DIAG", "GPX_PERSIST_GEMM", "GPX_CU_RESERVE",
+                  "GPX_PERSIST_SCOPE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         e = _lib.Engine(0)
         e.set_train(X)
         lml, info = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)

@@ -338,14 +338,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bl(const double* A, long lda, con
     for (int kk = 0; kk < 4; ++kk) {
       double af[4], bf[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) { af[m] = cb[aoff[m] ^ (4 * kk)]; bf[m] = cb[boff[m] ^ (4 * kk)]; }
+      for (int m = 0; m < 4; ++m) {
+        if (MODE == 12) {
+          typedef const volatile double __attribute__((address_space(3)))* lcvd_t;
+          af[m] = *((lcvd_t)cb + (aoff[m] ^ (4 * kk)));
+          bf[m] = *((lcvd_t)cb + (boff[m] ^ (4 * kk)));
+        } else {
+          af[m] = cb[aoff[m] ^ (4 * kk)];
+          bf[m] = cb[boff[m] ^ (4 * kk)];
+        }
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
-        if (MODE >= 8 && MODE != 11 && kk < 2) GLOAD(4 * kk + m, nxt, soff);
-        if (MODE == 11 && kk < 2 && m < 3) GLOAD(3 * kk + m, nxt, soff);
-        if (MODE == 11 && kk == 2 && m < 2) GLOAD(6 + m, nxt, soff);
+        if (MODE >= 8 && MODE < 11 && kk < 2) GLOAD(4 * kk + m, nxt, soff);
+        if (MODE >= 11 && kk < 2 && m < 3) GLOAD(3 * kk + m, nxt, soff);
+        if (MODE >= 11 && kk == 2 && m < 2) GLOAD(6 + m, nxt, soff);
       }
       if ((MODE == 9 || MODE == 10) && kk < 2) {
 #pragma unroll
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bl(const double* A, long lda, con
         }
         __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
       }
-      if (MODE == 11 && kk < 3) {
+      if (MODE >= 11 && kk < 3) {
 #pragma unroll
         for (int q = 0; q < (kk < 2 ? 3 : 2); ++q) {
           __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
@@ -489,6 +498,7 @@ int main(int argc, char** argv) {
         run_bl<8, false>(p, "bl loads spread (source order)", check);
         run_bl<9, false>(p, "bl loads spread + sgb", check);
         run_bl<11, false>(p, "bl loads 3+3+2 + sgb", check);
+        run_bl<12, false>(p, "bl 3+3+2 + sgb, volatile ds_read", check);
         run_bl<10, false>(p, "bl spread + sgb + stagger(diag)", check);
       } else {
         run_glds<2, 2, 2, 6>(p, "glds C-in-acc", check);
@@ -496,6 +506,7 @@ int main(int argc, char** argv) {
         run_bl<8, true>(p, "bl loads spread, C-in-acc", check);
         run_bl<9, true>(p, "bl loads spread + sgb, C-in-acc", check);
         run_bl<11, true>(p, "bl loads 3+3+2 + sgb, C-in-acc", check);
+        run_bl<12, true>(p, "bl 3+3+2 + sgb, C-in-acc, volatile ds_read", check);
         run_bl<10, true>(p, "bl spread+sgb+C-in-acc+stagger(diag)", check);
       }
     }
