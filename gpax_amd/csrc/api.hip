@@ -639,6 +639,13 @@ int gpx_init(int device, gpx_ctx** out) {
     const int ncu = ctx->prop.multiProcessorCount;
     reserve = (reserve / 8) * 8;
     if (reserve < 0 || reserve > ncu / 4 || ncu % 32 != 0) reserve = 0;
+    bool soft = false;
+    if (const char* e = getenv("GPX_CU_RESERVE_SOFT")) {
+      if (atoi(e) == 8 && ncu % 32 == 0) {
+        reserve = 8;
+        soft = true;
+      }
+    }
     if (reserve > 0) {
       const int words = ncu / 32;
       std::vector<uint32_t> m_main((size_t)words, 0xffffffffu), m_res((size_t)words, 0u);
@@ -646,7 +653,9 @@ int gpx_init(int device, gpx_ctx** out) {
         m_main[(size_t)(b / 32)] &= ~(1u << (b % 32));
         m_res[(size_t)(b / 32)] |= (1u << (b % 32));
       }
-      if (hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)words, m_main.data()) != hipSuccess ||
+      // soft reservation: only the q stream of the diagonal blocks is masked; the main stream stays an ordinary
+      // low-priority stream and the persistent GEMM keeps off the reserved CUs by itself
+      if ((!soft && hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)words, m_main.data()) != hipSuccess) ||
           hipExtStreamCreateWithCUMask(&ctx->rstream, (uint32_t)words, m_res.data()) != hipSuccess) {
         (void)hipGetLastError();
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -662,6 +671,7 @@ int gpx_init(int device, gpx_ctx** out) {
       }
     }
     ctx->cu_reserved = reserve;
+    ctx->soft_reserve = soft && reserve > 0;
     ctx->persist_gemm = reserve > 0;
     if (const char* e = getenv("GPX_PERSIST_GEMM")) ctx->persist_gemm = (e[0] == '1');
     if (const char* e = getenv("GPX_PERSIST_SLACK")) ctx->persist_slack = atoi(e);

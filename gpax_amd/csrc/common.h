@@ -156,6 +156,7 @@ struct gpx_ctx {
   // > 0 while a driver whose own panel chain holds no potf2 (the right-looking TRSM sweeps, the K^-1 = W W^T product)
   // is queueing launches: its big-tile GEMMs run persistently (GPX_PERSIST_SCOPE=0 disables)
   int persist_slack = 0;
+  bool soft_reserve = false; // GPX_CU_RESERVE_SOFT=8: rstream masked to 8 CUs, persistent GEMM workgroups avoid them themselves
   int persist_scope = 0;
   bool persist_scope_ok = true;
   gpx::DevBuf tile_counters;

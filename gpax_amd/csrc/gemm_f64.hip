@@ -394,9 +394,18 @@ struct TileMap {
 // changes is that a CU-masked queue no longer suffers from the dispatcher spreading workgroups evenly over shader
 // engines of unequal size (profiles/r02/cu_reserve.md): every resident workgroup simply works until the queue is dry.
 template <int TAG, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt128_persist_kernel(GemmArgs g, TileMap tm, int* __restrict__ counter) {
+__global__ __launch_bounds__(256, 2) void gemm_nt128_persist_kernel(GemmArgs g, TileMap tm, int* __restrict__ counter,
+                                                                    int avoid_cu0) {
   constexpr int TD = 256 * 16;
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (avoid_cu0) {
+    // "soft" CU reservation: workgroups that land on CU 0 of shader engine 0 of an XCD (the 8 CUs the q stream's CU
+    // mask names, tools/exp/cumask_probe.hip) retire at once; the others drain the tile queue.  Unlike a CU mask on
+    // this kernel's own queue this cannot unbalance the dispatcher (profiles/r02/cu_reserve.md).
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (((hw >> 8) & 0xf) == 0 && ((hw >> 12) & 1) == 0 && ((hw >> 13) & 7) == 0) return;
+  }
   if (TAG == 0) __builtin_amdgcn_s_setprio(2);
   int* s_tile = reinterpret_cast<int*>(smem + 2 * TD); // 16 B behind the two k-tile buffers (one LDS object only)
   for (;;) {
@@ -493,10 +502,10 @@ static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
     GPX_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->s));
     // persist_slack: workgroup slots deliberately left empty (GPX_PERSIST_SLACK) so that a chain kernel that cannot share
     // a SIMD with two big-tile waves (potf2: 238 VGPRs) finds a CU with a single resident workgroup at once
-    int slots = 2 * (ctx->prop.multiProcessorCount - (ctx->rstream ? ctx->cu_reserved : 0));
+    int slots = 2 * (ctx->prop.multiProcessorCount - ((ctx->rstream && !ctx->soft_reserve) ? ctx->cu_reserved : 0));
     if (ctx->persist_gemm && ctx->persist_slack > 0 && slots > 4 * ctx->persist_slack) slots -= ctx->persist_slack;
-    const int grid = tm.total < slots ? tm.total : slots;
-    gemm_nt128_persist_kernel<TAG, EPI><<<grid, 256, lds + 16, ctx->s>>>(g, tm, counter);
+    const int grid = (tm.total < slots && !ctx->soft_reserve) ? tm.total : slots;
+    gemm_nt128_persist_kernel<TAG, EPI><<<grid, 256, lds + 16, ctx->s>>>(g, tm, counter, ctx->soft_reserve ? 1 : 0);
     GPX_HIP(ctx, hipGetLastError());
     return 0;
   }
