@@ -388,6 +388,25 @@ struct TileMap {
   int a, f0, b, tri; // rows a .. b-1 hold f0, f0 + 1, ... tiles (the triangular part, `tri` tiles), rows >= b tiles_n each
 };
 
+// slab-local tile id -> (by, bx)
+__device__ __forceinline__ void decode_tile(const TileMap& tm, int lower, int l, int& by, int& bx) {
+  if (!lower) {
+    by = l / tm.tiles_n;
+    bx = l - by * tm.tiles_n;
+  } else if (l < tm.tri) { // n = rows before `by` in the triangular part: n f0 + n (n - 1) / 2 <= l
+    const double q = 2.0 * tm.f0 - 1.0;
+    int n = (int)((-q + sqrt(q * q + 8.0 * l)) * 0.5);
+    while ((int64_t)(n + 1) * tm.f0 + (int64_t)(n + 1) * n / 2 <= l) ++n;
+    while ((int64_t)n * tm.f0 + (int64_t)n * (n - 1) / 2 > l) --n;
+    by = tm.a + n;
+    bx = l - (int)((int64_t)n * tm.f0 + (int64_t)n * (n - 1) / 2);
+  } else {
+    l -= tm.tri;
+    by = tm.b + l / tm.tiles_n;
+    bx = l - (l / tm.tiles_n) * tm.tiles_n;
+  }
+}
+
 // PERSISTENT, dynamically scheduled variant (used when CUs are reserved for the panel chain, gpx_init): the grid is
 // two workgroups per CU the stream may use; each takes the next tile from an atomic counter until none is left.  A
 // tile's arithmetic does not depend on who computes it, so results are those of gemm_nt128_kernel bit for bit; what
@@ -414,35 +433,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_persist_kernel(GemmArgs g, 
     const int t = __builtin_amdgcn_readfirstlane(*s_tile);
     if (t >= tm.total) return;
     const int bzz = t / tm.per_slab;
-    int l = t - bzz * tm.per_slab, by, bx;
-    if (!g.lower) {
-      by = l / tm.tiles_n;
-      bx = l - by * tm.tiles_n;
-    } else if (l < tm.tri) { // n = rows before `by` in the triangular part: n f0 + n (n - 1) / 2 <= l
-      const double q = 2.0 * tm.f0 - 1.0;
-      int n = (int)((-q + sqrt(q * q + 8.0 * l)) * 0.5);
-      while ((int64_t)(n + 1) * tm.f0 + (int64_t)(n + 1) * n / 2 <= l) ++n;
-      while ((int64_t)n * tm.f0 + (int64_t)n * (n - 1) / 2 > l) --n;
-      by = tm.a + n;
-      bx = l - (int)((int64_t)n * tm.f0 + (int64_t)n * (n - 1) / 2);
-    } else {
-      l -= tm.tri;
-      by = tm.b + l / tm.tiles_n;
-      bx = l - (l / tm.tiles_n) * tm.tiles_n;
-    }
+    int by, bx;
+    decode_tile(tm, g.lower, t - bzz * tm.per_slab, by, bx);
     nt128_tile<EPI>(g, smem, __builtin_amdgcn_readfirstlane(bx), __builtin_amdgcn_readfirstlane(by), bzz);
     __syncthreads(); // every wave is done with the k-tile buffers and has read *s_tile
   }
 }
 
-static TileMap make_tile_map(const GemmArgs& g, int tiles_m, int tiles_n) {
+// tiles of a (tiles_m x tiles_n) grid; lower: row by holds clamp(by + delta + 1, 0, tiles_n) tiles (delta = ti_off - tj_off)
+static TileMap make_tile_map2(int lower, int delta, int tiles_m, int tiles_n, int slabs) {
   TileMap tm{};
   tm.tiles_m = tiles_m;
   tm.tiles_n = tiles_n;
-  if (!g.lower) {
+  if (tiles_n <= 0 || tiles_m <= 0) {
+    tm.per_slab = tm.total = 0;
+    return tm;
+  }
+  if (!lower) {
     tm.per_slab = tiles_m * tiles_n;
   } else {
-    const int delta = g.ti_off - g.tj_off; // row by holds clamp(by + delta + 1, 0, tiles_n) tiles
     int a = delta < 0 ? -delta : 0;
     if (a > tiles_m) a = tiles_m;
     int b = tiles_n - delta - 1;
@@ -455,8 +464,11 @@ static TileMap make_tile_map(const GemmArgs& g, int tiles_m, int tiles_n) {
     tm.tri = (int)(n * tm.f0 + n * (n - 1) / 2);
     tm.per_slab = tm.tri + (tiles_m - b) * tiles_n;
   }
-  tm.total = tm.per_slab * g.nsplit * g.batch;
+  tm.total = tm.per_slab * slabs;
   return tm;
+}
+static TileMap make_tile_map(const GemmArgs& g, int tiles_m, int tiles_n) {
+  return make_tile_map2(g.lower, g.ti_off - g.tj_off, tiles_m, tiles_n, g.nsplit * g.batch);
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a function: every context sets it once
