@@ -338,7 +338,8 @@ int mfma_peak(gpx_ctx* ctx, double* tflops);
 
 // potf2.hip
 int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo,
-                     int info_base, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0);
+                     int info_base, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0,
+                     const double* dPre = nullptr, int Kpre = 0);
 
 // linalg.hip
 int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,

@@ -56,13 +56,14 @@ static inline void set_batch(GemmArgs& g, int batch, int64_t a_bs, int64_t b_bs,
 // Factor the diagonal block kb on the q stream, after everything queued so far on the panel stream (which has just
 // brought that block up to date), and remember that the panel stream must wait for it (evQ) before it uses the result.
 static int queue_potf2(gpx_ctx* ctx, double* dA, int64_t lda, int kb, double* dLinv, int* dInfo,
-                       const BatchStrides& bs) {
+                       const BatchStrides& bs, const double* dPre = nullptr, int Kpre = 0) {
   hipStream_t span = ctx->s;
   GPX_HIP(ctx, hipEventRecord(ctx->evD, span));
   GPX_HIP(ctx, hipStreamWaitEvent(ctx->qstream, ctx->evD, 0));
   ctx->s = ctx->qstream;
   const int rc = launch_potf2_inv(ctx, dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE, lda,
-                                  dLinv + (int64_t)kb * TILE * TILE, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs);
+                                  dLinv + (int64_t)kb * TILE * TILE, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs,
+                                  dPre, Kpre);
   ctx->s = span;
   GPX_TRY(rc);
   GPX_HIP(ctx, hipEventRecord(ctx->evQ, ctx->qstream));
@@ -71,14 +72,15 @@ static int queue_potf2(gpx_ctx* ctx, double* dA, int64_t lda, int kb, double* dL
 
 // One outer block (diagonal blocks ob .. oe-1).  Per diagonal block kb: potf2 (+ inverse) -> panel TRSM (GEMM with
 // the inverse) -> update of the outer block's remaining columns.
-// EARLY DIAGONAL: potf2(kb + 1) only needs the diagonal tile (kb+1, kb+1) of that update.  The tile is updated by a
-// launch of its own, its factorisation is queued on the q stream at once, and the rest of the update (that tile
-// skipped) runs meanwhile on the panel stream: per step the chain is TRSM + max(potf2, update) instead of their sum
+// EARLY DIAGONAL: potf2(kb + 1) only needs the diagonal tile (kb+1, kb+1) of that update.  The factorisation kernel
+// applies the update to its own block (pre-update, potf2.hip) and is queued on the q stream right after the TRSM,
+// while the rest of the update (that tile skipped) runs on the panel stream: per step the chain is
+// TRSM + max(potf2, update) instead of their sum, with no additional launch
 // (inside the pipeline a potf2 launch costs ~160 us next to resident trailing-update workgroups, the update ~50 us).
 // Every tile still receives the same updates in the same order: results do not change (tests/test_gpu_edges.py).
-// MEASURED AND LEFT OFF BY DEFAULT (GPX_EARLY_DIAG=1 enables it; profiles/r02/chain_experiments.md): the extra
-// one-tile launches (161 per C3 factorisation) cost more than the overlap saves — every dependent launch of the chain
-// pays ~40-50 us next to the saturating trailing update, whatever its size: potrf 31.4 -> 32.6 ms.
+// MEASURED AND LEFT OFF BY DEFAULT (GPX_EARLY_DIAG=1 enables it; profiles/r02/chain_experiments.md): with or without
+// an extra launch for the diagonal tile, running two chain kernels side by side next to the saturating trailing
+// update slows each by what the other takes — potrf 30.7 -> 32.7 ms at C3.
 // first_queued: potf2(ob) was queued on the q stream by the caller (the early diagonal of U1).
 static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob, int oe,
                        double* dLinv, int* dInfo, const BatchStrides& bs, bool first_queued) {
@@ -110,9 +112,8 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
       g.lower = 1;
       g.ti_off = kb + 1;
       g.tj_off = kb + 1;
-      if (early) { // the next diagonal tile first, its factorisation on the q stream, then everything else
-        GPX_TRY(launch_gemm_nt(ctx, g, 1, 1, 0, GPX_PROF_GEMM_OTHER, (double)TILE * (TILE + 1.0) * TILE));
-        GPX_TRY(queue_potf2(ctx, dA, lda, kb + 1, dLinv, dInfo, bs));
+      if (early) { // the next diagonal block is updated by its own factorisation kernel, on the q stream, meanwhile
+        GPX_TRY(queue_potf2(ctx, dA, lda, kb + 1, dLinv, dInfo, bs, Apan, TILE));
         queued = true;
         g.skip = 1;
         g.skip_ti = kb + 1;
@@ -226,10 +227,9 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     // a group writes columns the previous group's near-far launch also wrote: wait for that launch (fixed order).
     if (k == gs && k > 0) GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
     int skip_tile = -1;
-    if (early) { // early diagonal: tile (oe, oe) first, potf2(oe) on the q stream while the rest of U1(k) runs
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, oe + 1, GPX_PROF_GEMM_OTHER, bs, oe);
-      if (rc < 0) break;
-      rc = queue_potf2(ctx, dA, lda, oe, dLinv, dInfo, bs);
+    if (early) { // early diagonal: potf2(oe) applies block k's update to its tile itself, on the q stream, while U1(k) runs
+      rc = queue_potf2(ctx, dA, lda, oe, dLinv, dInfo, bs, dA + (int64_t)oe * TILE * lda + (int64_t)ob * TILE,
+                       (oe - ob) * TILE);
       if (rc < 0) break;
       first_queued = true;
       skip_tile = oe;

@@ -297,9 +297,15 @@ __device__ long long gpx_potf2_trace[64];
 #define GPX_TRACE(slot) do { } while (0)
 #endif
 
+// PRE-UPDATE (Kpre > 0): the block first receives  A -= P P^T  with P = the 128 x Kpre strip `Ppre` (this block's rows of
+// the panel columns that have just been solved) — the update the panel chain would otherwise apply to this diagonal
+// tile with a GEMM launch of its own before the factorisation can start.  Same arithmetic as that launch: ascending
+// k in MFMA groups of 4, acc - a b (the GEMM kernels run -(-acc + a b): rounding is symmetric), so not a bit changes.
 __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t lda, double* Linv, int* info,
-                                                            int info_base, int64_t a_bs, int64_t linv_bs) {
+                                                            int info_base, int64_t a_bs, int64_t linv_bs,
+                                                            const double* Ppre, int Kpre) {
   A += (int64_t)blockIdx.x * a_bs; // one workgroup per batch entry
+  if (Ppre != nullptr) Ppre += (int64_t)blockIdx.x * a_bs; // the strip lives in the same matrix
   Linv += (int64_t)blockIdx.x * linv_bs;
   if (info != nullptr) info += blockIdx.x;
   __builtin_amdgcn_s_setprio(3);
@@ -333,6 +339,43 @@ __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t l
 #pragma unroll
   for (int u = 0; u < 7; ++u) R[u] = pd4_t{0.0, 0.0, 0.0, 0.0};
   int bad = 0;
+
+  if (Ppre != nullptr && Kpre > 0) {
+    // 16 columns of the strip at a time: 8 tiles (row tile i = rows 16 i ..) staged in LDS, double-buffered in
+    // Pbuf / Rrow (both idle until the factorisation starts); every wave updates its own 9 lower tiles
+    const int srow = tid >> 1, scol = (tid & 1) * 8; // 256 threads x 8 doubles = 128 rows x 16 columns
+    double stage[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(Ppre + (int64_t)srow * lda + k0 + scol + q);
+        stage[q] = v.x;
+        stage[q + 1] = v.y;
+      }
+    };
+    auto put = [&](double* buf) {
+      double* T = buf + (srow >> 4) * TSZ + (srow & 15) * TLD + scol;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) T[q] = stage[q];
+    };
+    fetch(0);
+    put(Pbuf);
+    __syncthreads();
+    const int nchunk = Kpre / 16;
+    for (int c = 0; c < nchunk; ++c) {
+      double* cur = (c & 1) ? Rrow : Pbuf;
+      double* nxt = (c & 1) ? Pbuf : Rrow;
+      if (c + 1 < nchunk) fetch((c + 1) * 16);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        int i, j;
+        lower_tile(4 * t + w, i, j);
+        C[t] = mma_nt(C[t], cur + i * TSZ, cur + j * TSZ, lane, -1.0);
+      }
+      if (c + 1 < nchunk) put(nxt);
+      __syncthreads();
+    }
+  }
 
   GPX_TRACE(0);
   for (int p = 0; p < 8; ++p) {
@@ -407,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t l
 
 namespace gpx {
 int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo, int info_base,
-                     int batch, int64_t a_bs, int64_t linv_bs) {
+                     int batch, int64_t a_bs, int64_t linv_bs, const double* dPre, int Kpre) {
   const int nb = batch > 1 ? batch : 1;
   // GPX_POTF2=column selects the column-by-column kernel (its > 64 KB of dynamic LDS is a per-device function
   // attribute: set once per context, i.e. on every device a process opens)
@@ -432,7 +475,9 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
     // algorithmic flops: factor n^3/3 + triangular inverse n^3/3
     ProfScope ps(ctx, GPX_PROF_POTF2, nb * 2.0 * PB * (double)PB * PB / 3.0);
     if (use_tile)
-      potf2_tile_kernel<<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
+      potf2_tile_kernel<<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs, dPre, Kpre);
+    else if (dPre != nullptr)
+      return bad_arg(ctx, "the column-by-column potf2 kernel has no pre-update");
     else
       potf2_inv_kernel<<<nb, 256, POTF2_LDS_BYTES, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
   }
