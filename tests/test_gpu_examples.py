@@ -21,3 +21,10 @@ def test_sparse_image_example():
     out = sparse_image.main(size=64, keep=0.2, num_steps=120, verbose=False)
     assert out["rmse"] < 0.25 * out["image_sd"]
     assert out["recon"].shape == (64, 64) and np.all(out["var"] > 0)
+
+
+def test_custom_priors_and_node_sweep_example():
+    import custom_priors_node_sweep as ex
+    with pytest.warns(UserWarning):  # kernel_prior: the reference's own warning (gp.py:116-123)
+        out = ex.main(num_warmup=120, num_samples=120, verbose=False)
+    assert out["same"] and out["rmse"] < 0.15 and 1.2 < out["t"] < 2.2

@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 from gpax_amd import ExactGP, viGP
 from gpax_amd.utils import get_keys
-from oracle import cpu_ref as ref  # synthetic inputs only
+import bench_inputs as ref  # BASELINE.md 3 workloads
 out = []
 for name, kernel, N, nuts, svi in [("C2", "RBF", 4096, (20, 20), 100), ("C3", "Matern", 16384, (5, 5), 30)]:
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
@@ -36,5 +36,5 @@ for name, kernel, N, nuts, svi in [("C2", "RBF", 4096, (20, 20), 100), ("C3", "M
                ms_per_svi_step=(t1 - t0) * 1e3 / svi, predict_ms=(t2 - t1) * 1e3, rmse_vs_truth=rmse)
     print(json.dumps(rec), flush=True)
     out.append(rec)
-os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/fit_predict_wallclock.json", "w"), indent=1)
+os.makedirs("gpurun_out/prof", exist_ok=True)
+json.dump(out, open("gpurun_out/prof/fit_predict_wallclock.json", "w"), indent=1)

@@ -32,6 +32,28 @@ run sq "$B --steps 1 --warmup 0" --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYC
 # C4: the 1000-sample sweep at N = 8192, d = 3 through ExactGP.predict, plain and under the kernel trace
 python tools/c4_sweep.py > $O/c4_sweep.json 2> $O/c4_sweep.err
 run c4trace "python tools/c4_sweep.py" --kernel-trace --stats
+# fit + predict wall-clock through the model API (BASELINE metric, first half), the roctx marker trace, the ASan smoke
+python tools/fit_predict_wallclock.py > $O/fit_predict_wallclock.log 2>&1
+rm -rf /tmp/prof_roctx
+GPX_ROCTX=1 timeout 300 rocprofv3 --marker-trace --kernel-trace --stats -d /tmp/prof_roctx -- python bench.py --no-cpu-baseline --steps 2 --warmup 1 --inflight 1 > $O/under_roctx.json 2> $O/roctx.err
+db=$(find /tmp/prof_roctx -name '*.db' | head -1)
+python - "$db" > $O/roctx.md 2>> $O/roctx.err <<'PY'
+import sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+cur = db.cursor()
+print("## roctx ranges (GPX_ROCTX=1) under rocprofv3 --marker-trace --kernel-trace: bench.py --steps 2 --warmup 1 --inflight 1\n")
+names = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')").fetchall()]
+if "regions" not in names:
+    print("(no `regions` view in this rocpd schema)")
+else:
+    # ROCm 7.2 rocpd: roctx ranges are rows of `regions` named roctxThreadRangeA, the message sits in extdata (JSON)
+    rows = cur.execute("select json_extract(extdata, '$.message') as msg, count(*), sum(duration), avg(duration) from regions "
+                       "where category like 'MARKER%' group by msg order by sum(duration) desc").fetchall()
+    print("| range | count | total ms (host side: the time the stage's launches take to enqueue) | avg us |\n|---|---|---|---|")
+    for n, c, s, a in rows:
+        print(f"| `{n}` | {c} | {s / 1e6:.3f} | {a / 1e3:.1f} |")
+PY
+bash tools/asan_smoke.sh > $O/sanitizer_smoke.log 2>&1; grep -v Woption-ignored $O/sanitizer_smoke.log | tail -4
 python bench.py > $O/bench_$RND.json 2> $O/bench_$RND.err
 cut -c1-400 $O/bench_$RND.json
 ls -la $O
