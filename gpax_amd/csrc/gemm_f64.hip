@@ -567,7 +567,12 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   // on the panel stream would only find room on the reserved CUs: everything there takes the shapes that fit next to
   // two resident trailing workgroups
   const bool on_panel = (ctx->persist_gemm || ctx->persist_scope > 0) && ctx->s != ctx->stream;
-  if (small_ok && (tiles < 400.0 || on_panel)) {
+  static double small_max = -1.0;
+  if (small_max < 0.0) {
+    const char* e = getenv("GPX_SMALL_TILES_MAX");
+    small_max = e ? atof(e) : 400.0;
+  }
+  if (small_ok && (tiles < small_max || on_panel)) {
     if (g.C == g.A) { // in-place (panel TRSM): one workgroup must own the whole row width
       // 32x128 strip, single LDS buffer: 22 KB and < 80 VGPRs, i.e. it fits in what two resident trailing-update
       // workgroups leave free on a CU (32 KB, 80 registers per SIMD) and is placed at once; the round-1 64x128 shape
