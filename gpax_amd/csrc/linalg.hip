@@ -127,15 +127,11 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
 }
 
 // C[rows r0.., cols c0..c1) -= Pan[rows, ob..oe) * Pan[cols, ob..oe)^T, lower tiles only.
-// only_tile >= 0: just the diagonal tile (only_tile, only_tile); skip_tile >= 0: everything but that diagonal tile.
+// skip_tile >= 0: everything but the diagonal tile (skip_tile, skip_tile) (its own factorisation kernel updates it).
 static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob,
                            int oe, int r0, int c0, int c1, int prof_cls, const BatchStrides& bs,
-                           int only_tile = -1, int skip_tile = -1) {
-  int rows = nblk + extra - r0, cols = c1 - c0;
-  if (only_tile >= 0) {
-    r0 = c0 = only_tile;
-    rows = cols = 1;
-  }
+                           int skip_tile = -1) {
+  const int rows = nblk + extra - r0, cols = c1 - c0;
   if (rows <= 0 || cols <= 0) return 0;
   const int K = (oe - ob) * TILE;
   const double* PanR = dA + (int64_t)r0 * TILE * lda + (int64_t)ob * TILE;
@@ -152,17 +148,13 @@ static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int 
   }
   // algorithmic flops: 2K per updated entry with column <= row
   double entries = 0.0;
-  if (only_tile >= 0) {
-    entries = 0.5 * TILE * (TILE + 1.0);
-  } else {
-    for (int t = 0; t < cols; ++t) {
-      const int first_row_tile = (c0 + t > r0) ? c0 + t : r0; // rows below the diagonal tile
-      const double full = (double)(nblk + extra - first_row_tile - (c0 + t >= r0 ? 1 : 0)) * TILE * TILE;
-      const double diag = (c0 + t >= r0) ? 0.5 * TILE * (TILE + 1.0) : 0.0;
-      entries += full + diag;
-    }
-    if (skip_tile >= 0) entries -= 0.5 * TILE * (TILE + 1.0);
+  for (int t = 0; t < cols; ++t) {
+    const int first_row_tile = (c0 + t > r0) ? c0 + t : r0; // rows below the diagonal tile
+    const double full = (double)(nblk + extra - first_row_tile - (c0 + t >= r0 ? 1 : 0)) * TILE * TILE;
+    const double diag = (c0 + t >= r0) ? 0.5 * TILE * (TILE + 1.0) : 0.0;
+    entries += full + diag;
   }
+  if (skip_tile >= 0) entries -= 0.5 * TILE * (TILE + 1.0);
   return launch_gemm_nt(ctx, g, rows, cols, 0, prof_cls, 2.0 * K * entries);
 }
 
@@ -234,7 +226,7 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
       first_queued = true;
       skip_tile = oe;
     }
-    rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, ob_of(ge + 2), GPX_PROF_GEMM_OTHER, bs, -1,
+    rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, ob_of(ge + 2), GPX_PROF_GEMM_OTHER, bs,
                          skip_tile);
     if (rc < 0) break;
     if (k == ge) { // far update of the whole group on the main stream

@@ -119,6 +119,10 @@ int node_fail(gpx_node* nd, const std::string& msg) {
   nd->err = msg;
   return -2;
 }
+int node_bad_arg(gpx_node* nd, const char* msg) {
+  nd->err = std::string("bad argument: ") + msg;
+  return -1;
+}
 
 #define NODE_HIP(nd, expr)                                                                        \
   do {                                                                                            \
@@ -227,12 +231,12 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
                             const double* Xnew, int M, int noiseless, double jitter, const double* eps, int n,
                             double* means, double* samples, int* infos, double* vars, int m_slice) {
   if (!nd || nd->devs.empty()) return -1;
-  if (S < 0 || n < 0) return node_fail(nd, "bad argument: negative count"), -1;
+  if (S < 0 || n < 0) return node_bad_arg(nd, "negative count");
   if (S == 0) return 0;
-  if (!X || !ells || !scales || !noises || !yres || !Xnew || !means) return node_fail(nd, "bad argument: null pointer"), -1;
-  if (N < 1 || M < 1 || d < 1 || d > GPX_MAX_DIM) return node_fail(nd, "bad argument: sizes"), -1;
-  if (n > 0 && (!eps || !samples)) return node_fail(nd, "bad argument: eps/samples required when n > 0"), -1;
-  if (yres_rows != 1 && yres_rows != S) return node_fail(nd, "bad argument: yres_rows must be 1 or S"), -1;
+  if (!X || !ells || !scales || !noises || !yres || !Xnew || !means) return node_bad_arg(nd, "null pointer");
+  if (N < 1 || M < 1 || d < 1 || d > GPX_MAX_DIM) return node_bad_arg(nd, "sizes");
+  if (n > 0 && (!eps || !samples)) return node_bad_arg(nd, "eps/samples required when n > 0");
+  if (yres_rows != 1 && yres_rows != S) return node_bad_arg(nd, "yres_rows must be 1 or S");
   const int G = (int)nd->devs.size();
   const int ne = d + (kind == GPX_KERNEL_PERIODIC ? 1 : 0);
 
