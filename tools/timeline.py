@@ -3,7 +3,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
 from gpax_amd import _lib
-from oracle import cpu_ref as ref
+import bench_inputs as ref
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 eng = _lib.Engine(0)
 X, y, Xn, p = ref.synthetic_problem(N, 2, 1024, seed=0)

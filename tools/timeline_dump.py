@@ -10,6 +10,8 @@ with open(sys.argv[2], 'w') as f:
     for n, q, s, a, b, gx, gy in rows:
         import re
         m = re.search(r'gemm_nt_kernel<(\d), (\d), (\d)', n)
-        short = (f'gemm{m.group(1)}_{m.group(2)}{m.group(3)}' if m else 'potf2' if 'potf2' in n else n.split('(')[0].split('::')[-1][:20].replace(',', ';'))
+        m2 = re.search(r'gemm_nt128(_persist)?_kernel<(\d), (\d)', n)
+        short = (f'gemm{m.group(1)}_{m.group(2)}{m.group(3)}' if m else f'big{m2.group(2)}_{m2.group(3)}{"p" if m2.group(1) else ""}' if m2
+                 else 'potf2' if 'potf2' in n else n.split('(')[0].split('::')[-1][:20].replace(',', ';'))
         f.write(f"{short},{q},{s},{(a - t0) / 1e3:.1f},{(b - t0) / 1e3:.1f},{(b - a) / 1e3:.1f},{gx},{gy}\n")
 print(len(rows), "kernels; span", (rows[-1][4] - t0) / 1e6, "ms")
