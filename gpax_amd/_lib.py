@@ -76,6 +76,7 @@ def load_library() -> C.CDLL:
         "gpx_profile_enable": (C.c_int, [vp, C.c_int]),
         "gpx_profile_reset": (C.c_int, [vp]),
         "gpx_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64), _dp, _dp]),
+        "gpx_profile_read_bytes": (C.c_int, [vp, C.c_int, _dp]),
         "gpx_time_stage": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
         "gpx_sweep_resident": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp]),
         "gpx_sweep_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
@@ -102,7 +103,7 @@ EXPORTED_SYMBOLS = (
     "gpx_init gpx_device_count gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
     "gpx_factor gpx_lml_grad gpx_lml_grad_diag gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
-    "gpx_profile_reset gpx_profile_read gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
+    "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_predict_sweep_multi"
 ).split()
 
@@ -404,6 +405,11 @@ class Engine:
         self._check(self._lib.gpx_profile_read(self._ctx, cls, C.byref(n), C.byref(ms), C.byref(work)),
                     "gpx_profile_read")
         return n.value, ms.value, work.value
+
+    def profile_read_bytes(self, cls: int) -> float:
+        b = C.c_double()
+        self._check(self._lib.gpx_profile_read_bytes(self._ctx, cls, C.byref(b)), "gpx_profile_read_bytes")
+        return b.value
 
     def time_stage(self, stage: int, reps: int) -> float:
         ms = C.c_double()

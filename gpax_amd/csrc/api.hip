@@ -689,7 +689,8 @@ int gpx_init(int device, gpx_ctx** out) {
     GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->qstream, hipStreamNonBlocking, hi));
     GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evD, hipEventDisableTiming));
     GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evQ, hipEventDisableTiming));
-    if (const char* e = getenv("GPX_EARLY_DIAG")) ctx->early_diag = (e[0] != '0');
+    if (const char* e = getenv("GPX_EARLY_DIAG")) ctx->early_diag = atoi(e); // 0 off, 1 everywhere, 2 in the tail
+    if (const char* e = getenv("GPX_TAIL_TILES")) ctx->tail_tiles = atoi(e);
     ctx->s = ctx->stream;
   }
   GPX_HIP(ctx, hipEventCreate(&ctx->ev0));
@@ -1163,6 +1164,7 @@ int gpx_profile_reset(gpx_ctx* ctx) {
   for (int c = 0; c < GPX_PROF_NCLASS; ++c) {
     ctx->prof[c].launches = 0;
     ctx->prof[c].work = 0.0;
+    ctx->prof[c].bytes = 0.0;
     ctx->prof[c].ms = 0.0;
   }
   return 0;
@@ -1178,6 +1180,13 @@ int gpx_profile_read(gpx_ctx* ctx, int cls, int64_t* launches, double* total_ms,
   if (launches) *launches = ctx->prof[cls].launches;
   if (total_ms) *total_ms = ctx->prof[cls].ms;
   if (total_work) *total_work = ctx->prof[cls].work;
+  return 0;
+}
+
+int gpx_profile_read_bytes(gpx_ctx* ctx, int cls, double* total_bytes) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (cls < 0 || cls >= GPX_PROF_NCLASS) return bad_arg(ctx, "profile class");
+  if (total_bytes) *total_bytes = ctx->prof[cls].bytes;
   return 0;
 }
 

@@ -130,6 +130,7 @@ struct BatchPlan {
 struct ProfAcc {
   int64_t launches = 0;
   double work = 0.0;
+  double bytes = 0.0; // algorithmic bytes of the MFMA classes: the C entries a launch reads and writes (16 B each)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double ms = 0.0;
 };
@@ -161,13 +162,14 @@ struct gpx_ctx {
   bool persist_scope_ok = true;
   gpx::DevBuf tile_counters;
   unsigned tile_counter_seq = 0;
+  int tail_tiles = 72; // GPX_TAIL_TILES: an outer block is in the chain-bound tail when fewer tile rows than this remain (0: no tail)
   int early_diag = 0; // GPX_EARLY_DIAG=1 switches it on: measured slower (profiles/r02/chain_experiments.md), default off
   std::vector<hipEvent_t> evP, evU; // per-outer-block panel / next-panel-update events
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   hipDeviceProp_t prop;
-  int lazy_group = 1; // GPX_LAZY_GROUP: outer blocks whose far (bulk) trailing update is applied in one launch (linalg.hip);
-                      // 2 is 2 % faster for one theta alone and 17 % slower with 3 contexts in flight: default 1
+  int lazy_group = 2; // GPX_LAZY_GROUP: outer blocks whose far (bulk) trailing update is applied in one launch while the
+                      // factorisation is GEMM-bound (linalg.hip): K = 1024 at the default outer block of 512 columns
   int outer_tiles = gpx::OUTER_TILES; // GPX_OUTER_TILES (experiments): K of the trailing update = 128 * outer_tiles
   unsigned func_attr_mask = 0; // kernels whose dynamic-LDS attribute this context has set on ITS device (bit per variant)
 
@@ -276,7 +278,7 @@ struct ProfScope {
   int cls;
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t st = nullptr;
-  ProfScope(gpx_ctx* c, int cls_, double work) : ctx(c), cls(cls_) {
+  ProfScope(gpx_ctx* c, int cls_, double work, double bytes = 0.0) : ctx(c), cls(cls_) {
     if (!ctx->prof_on) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
       a = b = nullptr;
@@ -284,6 +286,7 @@ struct ProfScope {
     }
     ctx->prof[cls].launches += 1;
     ctx->prof[cls].work += work;
+    ctx->prof[cls].bytes += bytes;
     st = ctx->s;
     (void)hipEventRecord(a, st);
   }

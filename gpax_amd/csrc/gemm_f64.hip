@@ -545,7 +545,9 @@ static int launch_big(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int tiles_n
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
                    int prof_cls, double work) {
   if (tiles_m <= 0 || tiles_n <= 0) return 0;
-  ProfScope ps(ctx, prof_cls, work * (g.batch > 1 ? g.batch : 1));
+  // algorithmic bytes: `work` = 2 K per updated entry => entries = work / (2 K), each read and written once (beta != 0)
+  const double bmul_p = (g.batch > 1 ? g.batch : 1);
+  ProfScope ps(ctx, prof_cls, work * bmul_p, (g.K > 0 ? work / (2.0 * g.K) : 0.0) * (g.beta != 0.0 ? 16.0 : 8.0) * bmul_p);
   if (prof_cls == GPX_PROF_GEMM_TRAILING) return launch_big<1>(ctx, g, tiles_m, tiles_n, splits);
   // latency-bound launches (too few 128x128 tiles to fill 256 CUs x 2): smaller workgroup tiles
   // Workgroups the launch would have with 128x128 tiles (batch entries included).  The choice of shape does

@@ -83,8 +83,7 @@ static int queue_potf2(gpx_ctx* ctx, double* dA, int64_t lda, int kb, double* dL
 // update slows each by what the other takes — potrf 30.7 -> 32.7 ms at C3.
 // first_queued: potf2(ob) was queued on the q stream by the caller (the early diagonal of U1).
 static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob, int oe,
-                       double* dLinv, int* dInfo, const BatchStrides& bs, bool first_queued) {
-  const bool early = ctx->early_diag != 0 && ctx->qstream != nullptr;
+                       double* dLinv, int* dInfo, const BatchStrides& bs, bool first_queued, bool early) {
   bool queued = first_queued;
   for (int kb = ob; kb < oe; ++kb) {
     double* Akk = dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE;
@@ -199,15 +198,40 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
   GPX_HIP(ctx, hipEventRecord(ctx->evU[nouter], smain));
   GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[nouter], 0));
   int rc = 0;
-  const bool early = ctx->early_diag != 0 && ctx->qstream != nullptr;
+  // ADAPTIVE schedule (the timeline of one C3 factorisation, profiles/r02/timeline_c3.md): while the remaining matrix is
+  // large the trailing updates follow each other without gaps and the panel chain hides behind them (GEMM-bound
+  // "head"); once an outer block's chain takes longer than the trailing update it overlaps with, the chain sets the
+  // pace (chain-bound "tail": 15 of 32 outer blocks, 23 % of the time for 10 % of the flops at C3).  What helps one
+  // phase hurts the other, so the knobs are set per outer block — every combination gives the same bits:
+  //   head: bulk updates take `lazy_group` outer blocks at a time (larger K), no early diagonal;
+  //   tail: one outer block per update, early diagonal if early_diag = 2 (potf2 of the next diagonal block overlapped
+  //         with the update that feeds it: the chip is not saturated any more, so the overlap is real).
+  // early_diag = 1 / lazy_group with tail_tiles = 0: everywhere (the experiments of chain_experiments.md).
+  const int tail_tiles = ctx->tail_tiles;
+  auto in_tail = [&](int k) { return tail_tiles > 0 && (nblk - ob_of(k + 1) + extra_tiles) < tail_tiles; };
+  // groups: consecutive head blocks are grouped G at a time, tail blocks stay single
+  std::vector<int> gfirst((size_t)nouter), glast((size_t)nouter);
+  for (int k = 0; k < nouter;) {
+    int len = 1;
+    if (!in_tail(k))
+      while (len < G && k + len < nouter && !in_tail(k + len)) ++len;
+    for (int j = 0; j < len; ++j) {
+      gfirst[(size_t)(k + j)] = k;
+      glast[(size_t)(k + j)] = k + len - 1;
+    }
+    k += len;
+  }
+  auto early_at = [&](int k) {
+    if (ctx->qstream == nullptr || k >= nouter) return false;
+    return ctx->early_diag == 1 || (ctx->early_diag == 2 && in_tail(k));
+  };
   bool first_queued = false; // potf2 of the next outer block's first diagonal block already queued on the q stream
   for (int k = 0; k < nouter && rc >= 0; ++k) {
     const int ob = ob_of(k), oe = ob_of(k + 1);
-    const int gs = (k / G) * G;                                      // first block of k's group
-    const int ge = (gs + G - 1 < nouter - 1) ? gs + G - 1 : nouter - 1; // last block of k's group
+    const int gs = gfirst[(size_t)k], ge = glast[(size_t)k];
     // P(k) on the panel stream (it follows U1(k-1) there, in stream order)
     ctx->s = span;
-    rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs, first_queued);
+    rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs, first_queued, early_at(k));
     first_queued = false;
     if (rc < 0) break;
     GPX_HIP(ctx, hipEventRecord(ctx->evP[k], span));
@@ -216,10 +240,10 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
       break;
     }
     // U1(k): block k alone (K = its columns) onto outer columns k+1 .. ge+1, on the PANEL stream.  The first block of
-    // a group writes columns the previous group's near-far launch also wrote: wait for that launch (fixed order).
+    // a group writes columns the previous group's far update also wrote: wait for the launch that did (fixed order).
     if (k == gs && k > 0) GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
     int skip_tile = -1;
-    if (early) { // early diagonal: potf2(oe) applies block k's update to its tile itself, on the q stream, while U1(k) runs
+    if (early_at(k + 1)) { // early diagonal: potf2(oe) applies block k's update to its tile itself, while U1(k) runs
       rc = queue_potf2(ctx, dA, lda, oe, dLinv, dInfo, bs, dA + (int64_t)oe * TILE * lda + (int64_t)ob * TILE,
                        (oe - ob) * TILE);
       if (rc < 0) break;
@@ -233,9 +257,12 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
       GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
       ctx->s = smain;
       const int gob = ob_of(gs);
-      // G = 1: no near-far slice (a launch of < 512 tiles fills the chip badly: 61 launches at 32.4 ms against 31 at
-      // 28.7 ms per factorisation) — one launch, the round-1 schedule
-      const int n0 = ob_of(ge + 2), n1 = (G == 1) ? nblk : ob_of(ge + G + 2);
+      // The next group's U1 launches write outer columns ge+2 .. ge_next+1.  If that group has several blocks those
+      // columns get a ("near-far") launch of their own, so that its first U1 need not wait for the bulk; a single
+      // next block is not worth a launch of < 512 tiles (61 launches at 32.4 ms against 31 at 28.7 ms per
+      // factorisation): one launch then, the round-1 schedule.
+      const int gn = (k + 1 < nouter) ? glast[(size_t)(k + 1)] : k + 1;
+      const int n0 = ob_of(ge + 2), n1 = (gn - ge >= 2) ? ob_of(gn + 2) : nblk;
       rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n0, n0, n1, GPX_PROF_GEMM_TRAILING, bs);
       if (rc < 0) break;
       GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain)); // what the next group's first U1 waits for

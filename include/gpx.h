@@ -213,6 +213,9 @@ int gpx_profile_enable(gpx_ctx* ctx, int on);
 int gpx_profile_reset(gpx_ctx* ctx);
 int gpx_profile_read(gpx_ctx* ctx, int cls, int64_t* launches, double* total_ms,
                      double* total_work);
+/* Algorithmic BYTES of the MFMA classes since the last reset: 16 B (one read, one write) per C entry a launch
+ * updates (8 B when beta == 0) — the per-launch figure bench.py's roofline block quotes beside the PMC traffic. */
+int gpx_profile_read_bytes(gpx_ctx* ctx, int cls, double* total_bytes);
 
 /* Device-only timed repetitions (inputs resident in HBM; used by bench.py so that `value`
  * excludes PCIe).  Each call runs `reps` passes of the named stage at the theta/Xnew last set

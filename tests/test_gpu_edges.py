@@ -153,7 +153,9 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
     eps = np.random.default_rng(1).standard_normal((2, 1, M))
     ells = np.stack([p["k_length"], 1.1 * p["k_length"]])
     outs = []
-    variants = [dict(), dict(GPX_EARLY_DIAG="1"), dict(GPX_LAZY_GROUP="2", GPX_EARLY_DIAG="1"), dict(GPX_LAZY_GROUP="3"),
+    variants = [dict(), dict(GPX_EARLY_DIAG="2", GPX_TAIL_TILES="12", GPX_LAZY_GROUP="2"),
+                dict(GPX_EARLY_DIAG="2", GPX_TAIL_TILES="9"), dict(GPX_LAZY_GROUP="3", GPX_TAIL_TILES="14"),
+                dict(GPX_EARLY_DIAG="1"), dict(GPX_LAZY_GROUP="2", GPX_EARLY_DIAG="1"), dict(GPX_LAZY_GROUP="3"),
                 dict(GPX_LAZY_GROUP="4", GPX_EARLY_DIAG="1"), dict(GPX_OUTER_TILES="2"),
                 dict(GPX_LAZY_GROUP="2", GPX_OUTER_TILES="3"),
                 # persistent, dynamically scheduled big-tile GEMM; with CUs reserved for the diagonal blocks
@@ -161,7 +163,7 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
                 dict(GPX_PERSIST_SCOPE="0"), dict(GPX_CU_RESERVE_SOFT="8"), dict(GPX_PERSIST_GEMM="1", GPX_PERSIST_SLACK="8")]
     for env in variants:
         for k in ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_EARLY_DIAG", "GPX_PERSIST_GEMM", "GPX_CU_RESERVE",
-                  "GPX_PERSIST_SCOPE", "GPX_CU_RESERVE_SOFT", "GPX_PERSIST_SLACK"):
+                  "GPX_PERSIST_SCOPE", "GPX_CU_RESERVE_SOFT", "GPX_PERSIST_SLACK", "GPX_TAIL_TILES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
