@@ -77,6 +77,7 @@ def load_library() -> C.CDLL:
         "gpx_profile_reset": (C.c_int, [vp]),
         "gpx_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64), _dp, _dp]),
         "gpx_profile_read_bytes": (C.c_int, [vp, C.c_int, _dp]),
+        "gpx_debug_tile_order": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_int), C.c_int]),
         "gpx_time_stage": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
         "gpx_sweep_resident": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp]),
         "gpx_sweep_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
@@ -103,7 +104,7 @@ EXPORTED_SYMBOLS = (
     "gpx_init gpx_device_count gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
     "gpx_factor gpx_lml_grad gpx_lml_grad_diag gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
-    "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
+    "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_tile_order gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_predict_sweep_multi"
 ).split()
 

@@ -691,6 +691,8 @@ int gpx_init(int device, gpx_ctx** out) {
     GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evQ, hipEventDisableTiming));
     if (const char* e = getenv("GPX_EARLY_DIAG")) ctx->early_diag = atoi(e); // 0 off, 1 everywhere, 2 in the tail
     if (const char* e = getenv("GPX_TAIL_TILES")) ctx->tail_tiles = atoi(e);
+    if (const char* e = getenv("GPX_TILE_SWIZZLE")) ctx->tile_swizzle = atoi(e);
+    if (const char* e = getenv("GPX_TILE_SWIZZLE_MIN")) ctx->tile_swizzle_min = atoi(e);
     ctx->s = ctx->stream;
   }
   GPX_HIP(ctx, hipEventCreate(&ctx->ev0));
@@ -1188,6 +1190,11 @@ int gpx_profile_read_bytes(gpx_ctx* ctx, int cls, double* total_bytes) {
   if (cls < 0 || cls >= GPX_PROF_NCLASS) return bad_arg(ctx, "profile class");
   if (total_bytes) *total_bytes = ctx->prof[cls].bytes;
   return 0;
+}
+
+int gpx_debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n, int* xcd_by_bx, int cap) {
+  if (tiles_m < 1 || tiles_n < 1 || cap < 0 || (cap > 0 && !xcd_by_bx)) return -1;
+  return gpx::debug_tile_order(lower, ti_off, tj_off, tiles_m, tiles_n, xcd_by_bx, cap);
 }
 
 int gpx_time_stage(gpx_ctx* ctx, int stage, int reps, double* elapsed_ms) {

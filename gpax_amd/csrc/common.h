@@ -14,6 +14,7 @@
 namespace gpx {
 
 constexpr int GPX_TILE_COUNTERS = 1024;
+constexpr int GPX_SWZ_MAX_STRIPS = 32; // XCD-aware tile order: strips of 8 tile rows, i.e. up to 256 tile rows (32768 matrix rows) per launch
 constexpr int TILE = 128;      // MFMA GEMM block tile and diagonal-block size
 constexpr int OUTER_TILES = 4; // default outer blocking of the right-looking sweeps (4*128 = 512); ctx->outer_tiles
 constexpr double AUG_BIG = 1e300;
@@ -162,6 +163,8 @@ struct gpx_ctx {
   bool persist_scope_ok = true;
   gpx::DevBuf tile_counters;
   unsigned tile_counter_seq = 0;
+  int tile_swizzle_min = 1024; // GPX_TILE_SWIZZLE_MIN: tiles a launch must have for the XCD-aware order
+  int tile_swizzle = 0; // GPX_TILE_SWIZZLE: XCD-aware tile order of the big-tile GEMM (8x8-tile chunks per XCD), 0 = grid order
   int tail_tiles = 72; // GPX_TAIL_TILES: an outer block is in the chain-bound tail when fewer tile rows than this remain (0: no tail)
   int early_diag = 0; // GPX_EARLY_DIAG=1 switches it on: measured slower (profiles/r02/chain_experiments.md), default off
   std::vector<hipEvent_t> evP, evU; // per-outer-block panel / next-panel-update events
@@ -335,6 +338,7 @@ struct GemmArgs {
   int batch;   // independent problems per launch (0 or 1 = one); element b at base + b * *_bs
   int64_t a_bs, b_bs, c_bs;
 };
+int debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n, int* out, int cap);
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
                    int prof_cls, double work);
 int mfma_peak(gpx_ctx* ctx, double* tflops);

@@ -381,6 +381,131 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
   nt128_tile<EPI>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// XCD-AWARE TILE ORDER.  Workgroup b of a launch runs on XCD b % 8 (observed dispatch rule, used for speed only), and
+// each XCD has its own 4 MB L2.  In grid order the 64 workgroups an XCD holds at a time (2 per CU) are every 8th tile
+// of ~7 consecutive tile rows: they share 7 A row panels but almost no B panels, and the A / B panels are fetched
+// 2.1 x as often as an ideal 8 x 8 block of tiles would need (profiles/r02/fetch.md: 1.9 GB fetched per launch for
+// 0.2 GB of C tiles).  Here the tiles are cut into strips of 8 tile rows; an ITEM is one tile column of a strip (up to 8
+// tiles that share their B panel), items are numbered strip by strip, left to right, and XCD x takes the CONTIGUOUS
+// item range xstart[x] .. xstart[x + 1]: its 64 resident workgroups are 8 neighbouring items = an 8 x 8 block of tiles
+// that needs 8 A + 8 B panels, each fetched once per XCD and k step while the block proceeds in step.  The ranges are
+// cut where the cumulative tile count passes k / 8 of the total, so every XCD gets the same number of tiles to within
+// one item (a round-robin of whole 8 x 8 chunks left up to 12 % imbalance: diagonal chunks hold 36 tiles, not 64).
+// A tile's arithmetic does not depend on who computes it or when: results are those of grid order bit for bit.
+struct SwzMap {
+  int tiles_m, tiles_n, nstrips, max_items;
+  int mode; // 1: contiguous item range per XCD; 2: items dealt round-robin (item i -> XCD i % 8)
+  int pre[GPX_SWZ_MAX_STRIPS + 1]; // items before strip t
+  int xstart[9];
+};
+
+static bool make_swz_map(const GemmArgs& g, int tiles_m, int tiles_n, SwzMap& sm) {
+  sm.tiles_m = tiles_m;
+  sm.tiles_n = tiles_n;
+  sm.nstrips = (tiles_m + 7) / 8;
+  if (sm.nstrips > GPX_SWZ_MAX_STRIPS) return false;
+  const int delta = g.ti_off - g.tj_off;
+  // tiles of item (t, bx): rows max(8 t, bx - delta) .. last(t) when lower, all rows of the strip otherwise
+  auto strip_last = [&](int t) { return 8 * t + 7 < tiles_m ? 8 * t + 7 : tiles_m - 1; };
+  auto strip_cols = [&](int t) {
+    if (!g.lower) return tiles_n;
+    int nc = strip_last(t) + delta + 1;
+    return nc < 0 ? 0 : (nc > tiles_n ? tiles_n : nc);
+  };
+  auto item_tiles = [&](int t, int bx) {
+    int lo = 8 * t;
+    if (g.lower && bx - delta > lo) lo = bx - delta;
+    return strip_last(t) - lo + 1;
+  };
+  int64_t total = 0;
+  int items = 0;
+  for (int t = 0; t < sm.nstrips; ++t) {
+    sm.pre[t] = items;
+    const int nc = strip_cols(t);
+    for (int bx = 0; bx < nc; ++bx) total += item_tiles(t, bx);
+    items += nc;
+  }
+  sm.pre[sm.nstrips] = items;
+  if (items <= 0 || total <= 0) return false;
+  if (sm.mode == 2) {
+    sm.max_items = (items + 7) / 8;
+    for (int k = 0; k <= 8; ++k) sm.xstart[k] = 0;
+    return true;
+  }
+  int x = 1, i = 0;
+  int64_t cum = 0;
+  sm.xstart[0] = 0;
+  for (int t = 0; t < sm.nstrips && x < 8; ++t) {
+    const int nc = strip_cols(t);
+    for (int bx = 0; bx < nc && x < 8; ++bx, ++i) {
+      const int64_t w = item_tiles(t, bx);
+      // item i goes to the range whose share its midpoint falls in
+      while (x < 8 && (cum + w / 2) * 8 >= total * x) sm.xstart[x++] = i;
+      cum += w;
+    }
+  }
+  while (x <= 8) sm.xstart[x++] = items;
+  sm.xstart[8] = items;
+  sm.max_items = 0;
+  for (int k = 0; k < 8; ++k)
+    if (sm.xstart[k + 1] - sm.xstart[k] > sm.max_items) sm.max_items = sm.xstart[k + 1] - sm.xstart[k];
+  return true;
+}
+
+// workgroup L of a launch -> its tile; false: nothing to do (range exhausted, or a row past the last strip's end)
+__host__ __device__ __forceinline__ bool swz_decode(const SwzMap& sm, int L, int& by, int& bx) {
+  const int x = L & 7, s = L >> 3; // slot s of XCD x: item xstart[x] + s / 8, row s % 8 of its strip
+  int item;
+  if (sm.mode == 2) {
+    item = ((s >> 3) << 3) + ((x + (s >> 3)) & 7); // rotated per group of 8: the short diagonal items go round the XCDs
+    if (item >= sm.pre[sm.nstrips]) return false;
+  } else {
+    item = sm.xstart[x] + (s >> 3);
+    if (item >= sm.xstart[x + 1]) return false;
+  }
+  int t = 0;
+  while (t + 1 < sm.nstrips && sm.pre[t + 1] <= item) ++t;
+  by = 8 * t + (s & 7);
+  bx = item - sm.pre[t];
+  return by < sm.tiles_m;
+}
+
+template <int TAG, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt128_swz_kernel(GemmArgs g, SwzMap sm) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (TAG == 0) __builtin_amdgcn_s_setprio(2);
+  int by, bx;
+  if (!swz_decode(sm, blockIdx.x, by, bx)) return;
+  nt128_tile<EPI>(g, smem, bx, by, blockIdx.y);
+}
+
+// host-side view of the order for tests: out[3 i .. 3 i + 2] = (xcd, by, bx) of the i-th tile a launch would compute
+// (lower: tiles above the diagonal are dropped as the kernel drops them); returns the count, -1 if the shape is not
+// handled (more than GPX_SWZ_MAX_STRIPS strips)
+int debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n, int* out, int cap) {
+  GemmArgs g{};
+  g.lower = lower;
+  g.ti_off = ti_off;
+  g.tj_off = tj_off;
+  SwzMap sm;
+  sm.mode = lower >= 2 ? 2 : 1; // diagnostic: lower = 2 / 3 selects the round-robin deal (3: lower triangle)
+  g.lower = lower = (lower == 1 || lower == 3);
+  if (!make_swz_map(g, tiles_m, tiles_n, sm)) return -1;
+  int n = 0;
+  for (int L = 0; L < sm.max_items * 64; ++L) {
+    int by, bx;
+    if (!swz_decode(sm, L, by, bx)) continue;
+    if (lower && (tj_off + bx) * 128 > (ti_off + by) * 128 + 127) continue;
+    if (n < cap) {
+      out[3 * n] = L & 7;
+      out[3 * n + 1] = by;
+      out[3 * n + 2] = bx;
+    }
+    ++n;
+  }
+  return n;
+}
+
 // Tile enumeration of a persistent launch: only the tiles a launch really has (lower: tj_off + bx <= ti_off + by),
 // row-major (consecutive ids share their A row panel), one slab per (batch entry, split-K slab).
 struct TileMap {
@@ -474,7 +599,7 @@ static TileMap make_tile_map(const GemmArgs& g, int tiles_m, int tiles_n) {
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a function: every context sets it once
 // for each variant it launches (a process may hold contexts on several GPUs; contexts are also driven from
 // different host threads, so the "done" bits live in the context, not in a function-local static).
-enum : unsigned { ATTR_SMALL_22 = 0, ATTR_SMALL_24 = 1, ATTR_BIG_BASE = 2 /* + 3 * TAG + EPI */, ATTR_PERSIST_BASE = 8 };
+enum : unsigned { ATTR_SMALL_22 = 0, ATTR_SMALL_24 = 1, ATTR_BIG_BASE = 2 /* + 3 * TAG + EPI */, ATTR_PERSIST_BASE = 8, ATTR_SWZ_BASE = 14 };
 
 template <int TAG, int MT, int NT, int BK, bool DBUF>
 static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int tiles_n, int splits) {
@@ -518,6 +643,21 @@ static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
     if (ctx->persist_gemm && ctx->persist_slack > 0 && slots > 4 * ctx->persist_slack) slots -= ctx->persist_slack;
     const int grid = (tm.total < slots && !ctx->soft_reserve) ? tm.total : slots;
     gemm_nt128_persist_kernel<TAG, EPI><<<grid, 256, lds + 16, ctx->s>>>(g, tm, counter, ctx->soft_reserve ? 1 : 0);
+    GPX_HIP(ctx, hipGetLastError());
+    return 0;
+  }
+  SwzMap sm;
+  // worth it from about two full rounds of workgroups (below that the ranges are too short to balance)
+  if (ctx->tile_swizzle && (double)tiles_m * tiles_n * (g.lower ? 0.5 : 1.0) >= ctx->tile_swizzle_min &&
+      make_swz_map(g, tiles_m, tiles_n, sm)) {
+    constexpr unsigned sbit = 1u << (ATTR_SWZ_BASE + 3 * TAG + EPI);
+    if (!(ctx->func_attr_mask & sbit)) {
+      GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_swz_kernel<TAG, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      ctx->func_attr_mask |= sbit;
+    }
+    dim3 grid(sm.max_items * 64, g.nsplit * g.batch, 1);
+    gemm_nt128_swz_kernel<TAG, EPI><<<grid, 256, lds, ctx->s>>>(g, sm);
     GPX_HIP(ctx, hipGetLastError());
     return 0;
   }

@@ -216,6 +216,11 @@ int gpx_profile_read(gpx_ctx* ctx, int cls, int64_t* launches, double* total_ms,
 /* Algorithmic BYTES of the MFMA classes since the last reset: 16 B (one read, one write) per C entry a launch
  * updates (8 B when beta == 0) — the per-launch figure bench.py's roofline block quotes beside the PMC traffic. */
 int gpx_profile_read_bytes(gpx_ctx* ctx, int cls, double* total_bytes);
+/* Diagnostic, host only (no device call): the XCD-aware tile order of the big-tile GEMM (GPX_TILE_SWIZZLE,
+ * DESIGN.md 3) for a launch of tiles_m x tiles_n 128-tiles whose first tile sits at (ti_off, tj_off); lower != 0:
+ * only tiles on or below the diagonal.  Writes (xcd, by, bx) triples in workgroup order, up to `cap` of them, and
+ * returns the number of tiles the launch computes (-1: shape not handled, the launch falls back to grid order). */
+int gpx_debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n, int* xcd_by_bx, int cap);
 
 /* Device-only timed repetitions (inputs resident in HBM; used by bench.py so that `value`
  * excludes PCIe).  Each call runs `reps` passes of the named stage at the theta/Xnew last set

@@ -49,3 +49,29 @@ def test_product_never_imports_oracle():
                     l for l in src.splitlines() if "oracle" in l and "import" in l] or False, f
                 for line in src.splitlines():
                     assert not re.match(r"\s*(from|import)\s+oracle", line), (f, line)
+
+
+def test_xcd_aware_tile_order_covers_every_tile_once_and_balances_the_xcds():
+    """The XCD-aware order of the big-tile GEMM (gemm_f64.hip make_swz_map / swz_decode, run on the host through the
+    diagnostic entry point): every tile of the launch exactly once — lower launches only those on or below the
+    diagonal, for square, near (ti_off > tj_off) and rectangular shapes — and the same tile count per XCD to within a
+    couple of items of 8 tiles."""
+    import ctypes as C
+    import numpy as np
+    from gpax_amd import _lib
+
+    lib = _lib.load_library()
+    for lower, ti, tj, tm, tn in [(1, 0, 0, 77, 77), (1, 5, 5, 40, 40), (1, 12, 4, 30, 38), (1, 4, 4, 124, 124),
+                                  (0, 0, 0, 33, 8), (0, 3, 0, 16, 64), (1, 0, 0, 9, 9), (1, 20, 0, 50, 20)]:
+        cap = tm * tn
+        out = np.zeros(3 * cap, dtype=np.int32)
+        n = lib.gpx_debug_tile_order(lower, ti, tj, tm, tn, out.ctypes.data_as(C.POINTER(C.c_int)), cap)
+        want = {(by, bx) for by in range(tm) for bx in range(tn) if not lower or tj + bx <= ti + by}
+        assert n == len(want), (lower, ti, tj, tm, tn, n, len(want))
+        trip = out[:3 * n].reshape(n, 3)
+        got = [(int(b), int(c)) for _, b, c in trip]
+        assert len(set(got)) == n and set(got) == want
+        per_xcd = np.bincount(trip[:, 0], minlength=8)
+        if n >= 1024:
+            assert per_xcd.max() - per_xcd.min() <= 24, per_xcd
+    assert lib.gpx_debug_tile_order(1, 0, 0, 8 * 40, 8, None, 0) == -1  # more strips than the map holds: grid order

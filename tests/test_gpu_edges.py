@@ -160,10 +160,12 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
                 dict(GPX_LAZY_GROUP="2", GPX_OUTER_TILES="3"),
                 # persistent, dynamically scheduled big-tile GEMM; with CUs reserved for the diagonal blocks
                 dict(GPX_PERSIST_GEMM="1"), dict(GPX_CU_RESERVE="8"), dict(GPX_CU_RESERVE="8", GPX_LAZY_GROUP="2"),
-                dict(GPX_PERSIST_SCOPE="0"), dict(GPX_CU_RESERVE_SOFT="8"), dict(GPX_PERSIST_GEMM="1", GPX_PERSIST_SLACK="8")]
+                dict(GPX_PERSIST_SCOPE="0"), dict(GPX_CU_RESERVE_SOFT="8"), dict(GPX_PERSIST_GEMM="1", GPX_PERSIST_SLACK="8"),
+                # XCD-aware tile order of the big-tile GEMM on / off
+                dict(GPX_TILE_SWIZZLE="1"), dict(GPX_TILE_SWIZZLE="0"), dict(GPX_TILE_SWIZZLE="1", GPX_LAZY_GROUP="1")]
     for env in variants:
         for k in ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_EARLY_DIAG", "GPX_PERSIST_GEMM", "GPX_CU_RESERVE",
-                  "GPX_PERSIST_SCOPE", "GPX_CU_RESERVE_SOFT", "GPX_PERSIST_SLACK", "GPX_TAIL_TILES"):
+                  "GPX_PERSIST_SCOPE", "GPX_CU_RESERVE_SOFT", "GPX_PERSIST_SLACK", "GPX_TAIL_TILES", "GPX_TILE_SWIZZLE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -29,7 +29,8 @@ def main():
     # gemm_nt_kernel<1, ...>)
     try:
         rows = cur.execute("select counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection "
-                           "where kernel_name like '%gemm_nt128_kernel<1,%' or kernel_name like '%gemm_nt_kernel<1,%' "
+                           "where kernel_name like '%gemm_nt128_kernel<1,%' or kernel_name like '%gemm_nt128_swz_kernel<1,%' "
+                           "or kernel_name like '%gemm_nt_kernel<1,%' "
                            "group by counter_name").fetchall()
     except Exception:
         rows = []
