@@ -7,7 +7,8 @@ NUTS defaults target_accept_prob=0.8, max_tree_depth=10, diagonal mass matrix, S
 warm-up windows.  Every leapfrog calls `potential_and_grad(u)`, which for the exact GP is one
 Gram + Cholesky + K^-1 + gradient-contraction pass on the GPU (gpx_factor + gpx_lml_grad).
 JAX's threefry streams cannot be reproduced, so chains are not bit-comparable with NumPyro's;
-the sampler is validated on distributional properties (tests/test_samplers.py).
+the sampler is validated on distributional properties (tests/test_samplers.py) and its deterministic building
+blocks on known answers (tests/test_sampler_known_answers.py).
 """
 from __future__ import annotations
 
@@ -95,6 +96,9 @@ def _energy(U, p, inv_mass):
 
 
 def _uturn(rho, p_left, p_right, inv_mass):
+    """Generalised termination criterion (Betancourt 2017, A.4.2) in the form NumPyro's `_is_turning` uses: the summed
+    momentum of the trajectory with its two end points weighted one half, against the velocities at both ends."""
+    rho = rho - 0.5 * (p_left + p_right)
     return (rho @ (inv_mass * p_left) <= 0) or (rho @ (inv_mass * p_right) <= 0)
 
 
@@ -217,7 +221,7 @@ def run_nuts(potential_and_grad: Callable[[np.ndarray], Tuple[float, np.ndarray]
                 if in_slow and wf.n > 1:
                     inv_mass = wf.variance()
                     wf = _Welford(dim)
-                    eps = find_reasonable_step_size(potential_and_grad, u, U, g, inv_mass, rng, math.exp(da.log_eps_bar))
+                    eps = find_reasonable_step_size(potential_and_grad, u, U, g, inv_mass, rng, eps)  # from the current step
                     da.restart(eps)
                 window += 1
             if it == num_warmup - 1:
