@@ -660,9 +660,6 @@ int gpx_init(int device, gpx_ctx** out) {
         (void)hipGetLastError();
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
-    if (ctx->evD) (void)hipEventDestroy(ctx->evD);
-    if (ctx->evQ) (void)hipEventDestroy(ctx->evQ);
-    if (ctx->qstream) (void)hipStreamDestroy(ctx->qstream);
         ctx->stream = ctx->rstream = nullptr;
         reserve = 0;
       } else {
@@ -689,8 +686,15 @@ int gpx_init(int device, gpx_ctx** out) {
     GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->qstream, hipStreamNonBlocking, hi));
     GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evD, hipEventDisableTiming));
     GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evQ, hipEventDisableTiming));
+    if (const char* e = getenv("GPX_SPLIT_FAR")) ctx->split_far = atoi(e);
+    if (ctx->split_far > 0) {
+      GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo));
+      GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evS2, hipEventDisableTiming));
+      GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evU2, hipEventDisableTiming));
+    }
     if (const char* e = getenv("GPX_EARLY_DIAG")) ctx->early_diag = atoi(e); // 0 off, 1 everywhere, 2 in the tail
     if (const char* e = getenv("GPX_TAIL_TILES")) ctx->tail_tiles = atoi(e);
+    if (const char* e = getenv("GPX_TAIL_OUTER_TILES")) ctx->tail_outer_tiles = atoi(e);
     if (const char* e = getenv("GPX_TILE_SWIZZLE")) ctx->tile_swizzle = atoi(e);
     if (const char* e = getenv("GPX_TILE_SWIZZLE_MIN")) ctx->tile_swizzle_min = atoi(e);
     ctx->s = ctx->stream;
@@ -733,6 +737,9 @@ void gpx_destroy(gpx_ctx* ctx) {
     if (ctx->evD) (void)hipEventDestroy(ctx->evD);
     if (ctx->evQ) (void)hipEventDestroy(ctx->evQ);
     if (ctx->qstream) (void)hipStreamDestroy(ctx->qstream);
+    if (ctx->evS2) (void)hipEventDestroy(ctx->evS2);
+    if (ctx->evU2) (void)hipEventDestroy(ctx->evU2);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->pstream) (void)hipStreamDestroy(ctx->pstream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   }

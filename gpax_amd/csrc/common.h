@@ -152,6 +152,11 @@ struct gpx_ctx {
   // early diagonal (linalg.hip): the next diagonal block is factored on `qstream` while the rest of the update that
   // produced it is still running on the panel stream
   hipStream_t qstream = nullptr;
+  // GPX_SPLIT_FAR: the trailing updates of the Cholesky are issued as two launches — even and odd tile rows — on two
+  // streams, so that the partly filled last round of one fills with the other's workgroups (linalg.hip)
+  int split_far = 0;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t evS2 = nullptr, evU2 = nullptr;
   hipEvent_t evD = nullptr, evQ = nullptr;
   // persistent, dynamically scheduled big-tile GEMM (gemm_f64.hip) — switched on together with the CU reservation
   bool persist_gemm = false;
@@ -165,6 +170,7 @@ struct gpx_ctx {
   unsigned tile_counter_seq = 0;
   int tile_swizzle_min = 1024; // GPX_TILE_SWIZZLE_MIN: tiles a launch must have for the XCD-aware order
   int tile_swizzle = 0; // GPX_TILE_SWIZZLE: XCD-aware tile order of the big-tile GEMM (8x8-tile chunks per XCD), 0 = grid order
+  int tail_outer_tiles = 0; // GPX_TAIL_OUTER_TILES: outer block width in the tail (0 / >= outer_tiles: same as the head)
   int tail_tiles = 72; // GPX_TAIL_TILES: an outer block is in the chain-bound tail when fewer tile rows than this remain (0: no tail)
   int early_diag = 0; // GPX_EARLY_DIAG=1 switches it on: measured slower (profiles/r02/chain_experiments.md), default off
   std::vector<hipEvent_t> evP, evU; // per-outer-block panel / next-panel-update events
@@ -334,6 +340,7 @@ struct GemmArgs {
   int64_t c_split_stride;
   int skip;    // != 0: the 128-tile (skip_ti, skip_tj) of the caller's global tile frame is left out (it was updated by
   int skip_ti, skip_tj; // an earlier launch of its own: the "early diagonal" of the Cholesky panel chain, linalg.hip)
+  int row_step, row_phase; // row_step > 1 (big-tile kernel only): the launch covers tile rows row_phase, row_phase + row_step, ...
   int nsplit;  // grid.z = nsplit * batch (filled in by launch_gemm_nt)
   int batch;   // independent problems per launch (0 or 1 = one); element b at base + b * *_bs
   int64_t a_bs, b_bs, c_bs;

@@ -378,7 +378,8 @@ template <int TAG, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // non-trailing launches sit on the critical path of the look-ahead
-  nt128_tile<EPI>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+  const int by = g.row_step > 1 ? (int)blockIdx.y * g.row_step + g.row_phase : (int)blockIdx.y;
+  nt128_tile<EPI>(g, smem, blockIdx.x, by, blockIdx.z);
 }
 
 // XCD-AWARE TILE ORDER.  Workgroup b of a launch runs on XCD b % 8 (observed dispatch rule, used for speed only), and
@@ -624,7 +625,7 @@ template <int TAG, int EPI>
 static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n) {
   constexpr size_t lds = (size_t)2 * 256 * 16 * sizeof(double); // 2 buffers x (128 A rows + 128 B rows) x 128 B
   constexpr unsigned bit = 1u << (ATTR_BIG_BASE + 3 * TAG + EPI);
-  if (ctx->persist_gemm || ctx->persist_scope > 0) {
+  if ((ctx->persist_gemm || ctx->persist_scope > 0) && g.row_step <= 1) {
     constexpr unsigned pbit = 1u << (ATTR_PERSIST_BASE + 3 * TAG + EPI);
     if (!(ctx->func_attr_mask & pbit)) {
       GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_persist_kernel<TAG, EPI>),
@@ -648,7 +649,7 @@ static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
   }
   SwzMap sm;
   // worth it from about two full rounds of workgroups (below that the ranges are too short to balance)
-  if (ctx->tile_swizzle && (double)tiles_m * tiles_n * (g.lower ? 0.5 : 1.0) >= ctx->tile_swizzle_min &&
+  if (ctx->tile_swizzle && g.row_step <= 1 && (double)tiles_m * tiles_n * (g.lower ? 0.5 : 1.0) >= ctx->tile_swizzle_min &&
       make_swz_map(g, tiles_m, tiles_n, sm)) {
     constexpr unsigned sbit = 1u << (ATTR_SWZ_BASE + 3 * TAG + EPI);
     if (!(ctx->func_attr_mask & sbit)) {

@@ -127,11 +127,16 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
 
 // C[rows r0.., cols c0..c1) -= Pan[rows, ob..oe) * Pan[cols, ob..oe)^T, lower tiles only.
 // skip_tile >= 0: everything but the diagonal tile (skip_tile, skip_tile) (its own factorisation kernel updates it).
+// parity >= 0: only the tile rows whose ABSOLUTE index has that parity (split far updates, potrf_lower).
 static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob,
                            int oe, int r0, int c0, int c1, int prof_cls, const BatchStrides& bs,
-                           int skip_tile = -1) {
-  const int rows = nblk + extra - r0, cols = c1 - c0;
-  if (rows <= 0 || cols <= 0) return 0;
+                           int skip_tile = -1, int parity = -1) {
+  const int rows_all = nblk + extra - r0, cols = c1 - c0;
+  if (rows_all <= 0 || cols <= 0) return 0;
+  const int step = parity >= 0 ? 2 : 1;
+  const int phase = parity >= 0 ? ((parity - r0) & 1) : 0;
+  const int rows = (rows_all - phase + step - 1) / step; // tile rows this launch covers
+  if (rows <= 0) return 0;
   const int K = (oe - ob) * TILE;
   const double* PanR = dA + (int64_t)r0 * TILE * lda + (int64_t)ob * TILE;
   const double* PanC = dA + (int64_t)c0 * TILE * lda + (int64_t)ob * TILE;
@@ -141,17 +146,21 @@ static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int 
   g.lower = 1;
   g.ti_off = r0;
   g.tj_off = c0;
+  if (step > 1) {
+    g.row_step = step;
+    g.row_phase = phase;
+  }
   if (skip_tile >= 0) {
     g.skip = 1;
     g.skip_ti = g.skip_tj = skip_tile;
   }
   // algorithmic flops: 2K per updated entry with column <= row
   double entries = 0.0;
-  for (int t = 0; t < cols; ++t) {
-    const int first_row_tile = (c0 + t > r0) ? c0 + t : r0; // rows below the diagonal tile
-    const double full = (double)(nblk + extra - first_row_tile - (c0 + t >= r0 ? 1 : 0)) * TILE * TILE;
-    const double diag = (c0 + t >= r0) ? 0.5 * TILE * (TILE + 1.0) : 0.0;
-    entries += full + diag;
+  for (int i = phase; i < rows_all; i += step) {
+    const int R = r0 + i; // absolute tile row: full tiles in columns c0 .. min(c1, R) - 1, half a tile on the diagonal
+    const int full = (R < c1 ? R : c1) - c0;
+    if (full > 0) entries += (double)full * TILE * TILE;
+    if (R >= c0 && R < c1) entries += 0.5 * TILE * (TILE + 1.0);
   }
   if (skip_tile >= 0) entries -= 0.5 * TILE * (TILE + 1.0);
   return launch_gemm_nt(ctx, g, rows, cols, 0, prof_cls, 2.0 * K * entries);
@@ -190,10 +199,23 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
   const int nblk = np / TILE;
   const int OT = ctx->outer_tiles;
   const int G = ctx->lazy_group > 0 ? ctx->lazy_group : 1;
-  const int nouter = (nblk + OT - 1) / OT;
+  // Outer block boundaries.  Head blocks are OT tiles wide; a block that would leave fewer than `tail_tiles` tile rows
+  // behind it belongs to the chain-bound tail and is `tail_outer_tiles` wide (narrower blocks: a shorter U1 + panel
+  // chain per trailing update there, where the chain and not the GEMM sets the pace).
+  const int tail_tiles = ctx->tail_tiles;
+  const int OTt = (ctx->tail_outer_tiles > 0 && ctx->tail_outer_tiles < OT) ? ctx->tail_outer_tiles : OT;
+  std::vector<int> bounds;
+  std::vector<char> is_tail;
+  for (int c = 0; c < nblk;) {
+    const bool t = tail_tiles > 0 && (nblk - (c + OT) + extra_tiles) < tail_tiles;
+    bounds.push_back(c);
+    is_tail.push_back(t ? 1 : 0);
+    c += t ? OTt : OT;
+  }
+  const int nouter = (int)bounds.size();
   GPX_TRY(ensure_events(ctx, nouter));
   hipStream_t smain = ctx->stream, span = ctx->pstream;
-  auto ob_of = [&](int k) { return (k * OT < nblk) ? k * OT : nblk; }; // first tile column of outer block k (clamped)
+  auto ob_of = [&](int k) { return k < nouter ? bounds[(size_t)k] : nblk; }; // first tile column of outer block k (clamped)
   // the panel stream starts after everything already queued on the main stream (Gram etc.)
   GPX_HIP(ctx, hipEventRecord(ctx->evU[nouter], smain));
   GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[nouter], 0));
@@ -207,8 +229,7 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
   //   tail: one outer block per update, early diagonal if early_diag = 2 (potf2 of the next diagonal block overlapped
   //         with the update that feeds it: the chip is not saturated any more, so the overlap is real).
   // early_diag = 1 / lazy_group with tail_tiles = 0: everywhere (the experiments of chain_experiments.md).
-  const int tail_tiles = ctx->tail_tiles;
-  auto in_tail = [&](int k) { return tail_tiles > 0 && (nblk - ob_of(k + 1) + extra_tiles) < tail_tiles; };
+  auto in_tail = [&](int k) { return k < nouter && is_tail[(size_t)k] != 0; };
   // groups: consecutive head blocks are grouped G at a time, tail blocks stay single
   std::vector<int> gfirst((size_t)nouter), glast((size_t)nouter);
   for (int k = 0; k < nouter;) {
@@ -225,6 +246,8 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     if (ctx->qstream == nullptr || k >= nouter) return false;
     return ctx->early_diag == 1 || (ctx->early_diag == 2 && in_tail(k));
   };
+  hipStream_t s2 = (ctx->split_far > 0 && !ctx->persist_gemm && ctx->tile_swizzle == 0) ? ctx->stream2 : nullptr;
+  bool s2_pending = false, u2_pending = false, split_done = false;
   bool first_queued = false; // potf2 of the next outer block's first diagonal block already queued on the q stream
   for (int k = 0; k < nouter && rc >= 0; ++k) {
     const int ob = ob_of(k), oe = ob_of(k + 1);
@@ -241,7 +264,13 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     }
     // U1(k): block k alone (K = its columns) onto outer columns k+1 .. ge+1, on the PANEL stream.  The first block of
     // a group writes columns the previous group's far update also wrote: wait for the launch that did (fixed order).
-    if (k == gs && k > 0) GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
+    if (k == gs && k > 0) {
+      GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
+      if (u2_pending) { // the odd-row half of that launch ran on stream2
+        GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU2, 0));
+        u2_pending = false;
+      }
+    }
     int skip_tile = -1;
     if (early_at(k + 1)) { // early diagonal: potf2(oe) applies block k's update to its tile itself, while U1(k) runs
       rc = queue_potf2(ctx, dA, lda, oe, dLinv, dInfo, bs, dA + (int64_t)oe * TILE * lda + (int64_t)ob * TILE,
@@ -255,7 +284,6 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     if (rc < 0) break;
     if (k == ge) { // far update of the whole group on the main stream
       GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
-      ctx->s = smain;
       const int gob = ob_of(gs);
       // The next group's U1 launches write outer columns ge+2 .. ge_next+1.  If that group has several blocks those
       // columns get a ("near-far") launch of their own, so that its first U1 need not wait for the bulk; a single
@@ -263,12 +291,39 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
       // factorisation): one launch then, the round-1 schedule.
       const int gn = (k + 1 < nouter) ? glast[(size_t)(k + 1)] : k + 1;
       const int n0 = ob_of(ge + 2), n1 = (gn - ge >= 2) ? ob_of(gn + 2) : nblk;
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n0, n0, n1, GPX_PROF_GEMM_TRAILING, bs);
+      // SPLIT (GPX_SPLIT_FAR): even tile rows on the main stream, odd tile rows on stream2 — two independent chains of
+      // launches (a tile keeps its stream for the whole factorisation, so every tile still receives its updates in
+      // order), whose partly filled last rounds fill with each other's workgroups.  Only while a half still has
+      // `split_far` tiles; from then on single launches again, which first wait for stream2's last one.
+      const double rows_left = (double)(nblk + extra_tiles - n0);
+      const bool split = s2 != nullptr && !split_done && 0.25 * rows_left * rows_left >= (double)ctx->split_far;
+      if (s2_pending && !split) { // back to single launches: they write both parities
+        GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evS2, 0));
+        s2_pending = false;
+        split_done = true;
+      }
+      if (split) {
+        GPX_HIP(ctx, hipStreamWaitEvent(s2, ctx->evP[k], 0));
+        ctx->s = s2;
+        rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n0, n0, n1, GPX_PROF_GEMM_TRAILING, bs, -1, 1);
+        if (rc < 0) break;
+        GPX_HIP(ctx, hipEventRecord(ctx->evU2, s2));
+        rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n1, n1, nblk, GPX_PROF_GEMM_TRAILING, bs, -1, 1);
+        if (rc < 0) break;
+        GPX_HIP(ctx, hipEventRecord(ctx->evS2, s2));
+        s2_pending = true;
+        u2_pending = true;
+      }
+      ctx->s = smain;
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n0, n0, n1, GPX_PROF_GEMM_TRAILING, bs, -1,
+                           split ? 0 : -1);
       if (rc < 0) break;
       GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain)); // what the next group's first U1 waits for
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n1, n1, nblk, GPX_PROF_GEMM_TRAILING, bs);
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n1, n1, nblk, GPX_PROF_GEMM_TRAILING, bs, -1,
+                           split ? 0 : -1);
     }
   }
+  if (s2_pending) GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evS2, 0));
   // everything queued on the q / panel streams happens-before whatever follows on the main stream
   if (ctx->qstream) {
     GPX_HIP(ctx, hipEventRecord(ctx->evQ, ctx->qstream));

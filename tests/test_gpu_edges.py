@@ -162,10 +162,17 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
                 dict(GPX_PERSIST_GEMM="1"), dict(GPX_CU_RESERVE="8"), dict(GPX_CU_RESERVE="8", GPX_LAZY_GROUP="2"),
                 dict(GPX_PERSIST_SCOPE="0"), dict(GPX_CU_RESERVE_SOFT="8"), dict(GPX_PERSIST_GEMM="1", GPX_PERSIST_SLACK="8"),
                 # XCD-aware tile order of the big-tile GEMM on / off
-                dict(GPX_TILE_SWIZZLE="1"), dict(GPX_TILE_SWIZZLE="0"), dict(GPX_TILE_SWIZZLE="1", GPX_LAZY_GROUP="1")]
+                dict(GPX_TILE_SWIZZLE="1"), dict(GPX_TILE_SWIZZLE="2", GPX_TILE_SWIZZLE_MIN="64"), dict(GPX_TILE_SWIZZLE="1", GPX_LAZY_GROUP="1", GPX_TILE_SWIZZLE_MIN="64"),
+                # narrower outer blocks in the tail
+                dict(GPX_TAIL_OUTER_TILES="2", GPX_TAIL_TILES="12"), dict(GPX_TAIL_OUTER_TILES="1", GPX_TAIL_TILES="15"),
+                dict(GPX_TAIL_OUTER_TILES="2", GPX_TAIL_TILES="40", GPX_OUTER_TILES="3"),
+                # far updates split in even / odd tile rows on two streams
+                dict(GPX_SPLIT_FAR="1"), dict(GPX_SPLIT_FAR="40"), dict(GPX_SPLIT_FAR="30", GPX_LAZY_GROUP="1"),
+                dict(GPX_SPLIT_FAR="1", GPX_LAZY_GROUP="3", GPX_TAIL_TILES="0")]
     for env in variants:
         for k in ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_EARLY_DIAG", "GPX_PERSIST_GEMM", "GPX_CU_RESERVE",
-                  "GPX_PERSIST_SCOPE", "GPX_CU_RESERVE_SOFT", "GPX_PERSIST_SLACK", "GPX_TAIL_TILES", "GPX_TILE_SWIZZLE"):
+                  "GPX_PERSIST_SCOPE", "GPX_CU_RESERVE_SOFT", "GPX_PERSIST_SLACK", "GPX_TAIL_TILES", "GPX_TILE_SWIZZLE", "GPX_TILE_SWIZZLE_MIN",
+                  "GPX_TAIL_OUTER_TILES", "GPX_SPLIT_FAR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
