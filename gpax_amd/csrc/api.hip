@@ -686,6 +686,8 @@ int gpx_init(int device, gpx_ctx** out) {
     GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->qstream, hipStreamNonBlocking, hi));
     GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evD, hipEventDisableTiming));
     GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evQ, hipEventDisableTiming));
+    GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evB, hipEventDisableTiming));
+    if (const char* e = getenv("GPX_U1_SPLIT")) ctx->u1_split = atoi(e);
     if (const char* e = getenv("GPX_SPLIT_FAR")) ctx->split_far = atoi(e);
     if (ctx->split_far > 0) {
       GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo));
@@ -737,6 +739,7 @@ void gpx_destroy(gpx_ctx* ctx) {
     if (ctx->evD) (void)hipEventDestroy(ctx->evD);
     if (ctx->evQ) (void)hipEventDestroy(ctx->evQ);
     if (ctx->qstream) (void)hipStreamDestroy(ctx->qstream);
+    if (ctx->evB) (void)hipEventDestroy(ctx->evB);
     if (ctx->evS2) (void)hipEventDestroy(ctx->evS2);
     if (ctx->evU2) (void)hipEventDestroy(ctx->evU2);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);

@@ -155,6 +155,8 @@ struct gpx_ctx {
   // GPX_SPLIT_FAR: the trailing updates of the Cholesky are issued as two launches — even and odd tile rows — on two
   // streams, so that the partly filled last round of one fills with the other's workgroups (linalg.hip)
   int split_far = 0;
+  int u1_split = 0; // GPX_U1_SPLIT: the columns of U1 the next potf2 + TRSM do not need run on the q stream (1: tail, 2: always)
+  hipEvent_t evB = nullptr;
   hipStream_t stream2 = nullptr;
   hipEvent_t evS2 = nullptr, evU2 = nullptr;
   hipEvent_t evD = nullptr, evQ = nullptr;

@@ -82,8 +82,11 @@ static int queue_potf2(gpx_ctx* ctx, double* dA, int64_t lda, int kb, double* dL
 // an extra launch for the diagonal tile, running two chain kernels side by side next to the saturating trailing
 // update slows each by what the other takes — potrf 30.7 -> 32.7 ms at C3.
 // first_queued: potf2(ob) was queued on the q stream by the caller (the early diagonal of U1).
+// wait_u1b: the rest of the previous block's U1 (columns ob+1 ..) runs on the q stream (split U1, potrf_lower): the first
+// inner update, which writes those columns next, waits for it (evB).
 static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob, int oe,
-                       double* dLinv, int* dInfo, const BatchStrides& bs, bool first_queued, bool early) {
+                       double* dLinv, int* dInfo, const BatchStrides& bs, bool first_queued, bool early,
+                       bool wait_u1b = false) {
   bool queued = first_queued;
   for (int kb = ob; kb < oe; ++kb) {
     double* Akk = dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE;
@@ -104,6 +107,10 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
                              2.0 * below * TILE * (double)TILE * TILE));
     }
     const int inner_cols = oe - kb - 1;
+    if (wait_u1b && (inner_cols > 0 || kb + 1 == oe)) { // also before the panel is declared done (single-tile blocks)
+      GPX_HIP(ctx, hipStreamWaitEvent(ctx->s, ctx->evB, 0));
+      wait_u1b = false;
+    }
     if (inner_cols > 0) { // update the rest of the outer block's columns (lower tiles)
       double* Cin = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)(kb + 1) * TILE;
       GemmArgs g = gemm_args(Apan, lda, Apan, lda, Cin, lda, TILE, -1.0, 1.0);
@@ -122,6 +129,7 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
                              2.0 * below * inner_cols * (double)TILE * TILE * TILE));
     }
   }
+  if (wait_u1b) GPX_HIP(ctx, hipStreamWaitEvent(ctx->s, ctx->evB, 0)); // nothing below the block: still join
   return 0;
 }
 
@@ -247,15 +255,16 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     return ctx->early_diag == 1 || (ctx->early_diag == 2 && in_tail(k));
   };
   hipStream_t s2 = (ctx->split_far > 0 && !ctx->persist_gemm && ctx->tile_swizzle == 0) ? ctx->stream2 : nullptr;
-  bool s2_pending = false, u2_pending = false, split_done = false;
+  bool s2_pending = false, u2_pending = false, split_done = false, u1b_pending = false;
   bool first_queued = false; // potf2 of the next outer block's first diagonal block already queued on the q stream
   for (int k = 0; k < nouter && rc >= 0; ++k) {
     const int ob = ob_of(k), oe = ob_of(k + 1);
     const int gs = gfirst[(size_t)k], ge = glast[(size_t)k];
     // P(k) on the panel stream (it follows U1(k-1) there, in stream order)
     ctx->s = span;
-    rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs, first_queued, early_at(k));
+    rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs, first_queued, early_at(k), u1b_pending);
     first_queued = false;
+    u1b_pending = false;
     if (rc < 0) break;
     GPX_HIP(ctx, hipEventRecord(ctx->evP[k], span));
     if (oe >= nblk) {
@@ -279,8 +288,24 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
       first_queued = true;
       skip_tile = oe;
     }
-    rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, ob_of(ge + 2), GPX_PROF_GEMM_OTHER, bs,
-                         skip_tile);
+    // SPLIT U1 (GPX_U1_SPLIT: 1 in the tail, 2 everywhere): the next panel starts with potf2 + TRSM on tile column oe
+    // alone, so only that column's update stays on the chain; the other columns of U1 run on the q stream meanwhile
+    // and are joined before the next panel's first inner update (panel_block, evB).
+    const int u1_end = ob_of(ge + 2);
+    const bool u1_split = ctx->qstream != nullptr && skip_tile < 0 && oe + 1 < u1_end &&
+                          (ctx->u1_split == 2 || (ctx->u1_split == 1 && in_tail(k)));
+    if (u1_split) {
+      GPX_HIP(ctx, hipEventRecord(ctx->evD, span)); // the panel of block k and everything U1(k) waited for
+      GPX_HIP(ctx, hipStreamWaitEvent(ctx->qstream, ctx->evD, 0));
+      ctx->s = ctx->qstream;
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe + 1, u1_end, GPX_PROF_GEMM_OTHER, bs);
+      ctx->s = span;
+      if (rc < 0) break;
+      GPX_HIP(ctx, hipEventRecord(ctx->evB, ctx->qstream));
+      u1b_pending = true;
+    }
+    rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, u1_split ? oe + 1 : u1_end,
+                         GPX_PROF_GEMM_OTHER, bs, skip_tile);
     if (rc < 0) break;
     if (k == ge) { // far update of the whole group on the main stream
       GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
