@@ -701,20 +701,12 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   const int nsplit = splits > 0 ? splits : 1;
   const int bmul = (g.batch > 1 && g.K >= 512) ? g.batch : 1;
   const double tiles = (double)tiles_m * tiles_n * nsplit * (g.lower ? 0.55 : 1.0) * bmul;
-  static int small_ok = -1;
-  if (small_ok < 0) {
-    const char* e = getenv("GPX_GEMM_SMALL");
-    small_ok = (e && e[0] == '0') ? 0 : 1;
-  }
   // persistent mode: the trailing update's workgroups hold their slots until its queue is dry, so a big-shape launch
   // on the panel stream would only find room on the reserved CUs: everything there takes the shapes that fit next to
   // two resident trailing workgroups
   const bool on_panel = (ctx->persist_gemm || ctx->persist_scope > 0) && ctx->s != ctx->stream;
-  static double small_max = -1.0;
-  if (small_max < 0.0) {
-    const char* e = getenv("GPX_SMALL_TILES_MAX");
-    small_max = e ? atof(e) : 400.0;
-  }
+  const bool small_ok = ctx->gemm_small;           // GPX_GEMM_SMALL (gpx_init)
+  const double small_max = ctx->small_tiles_max;   // GPX_SMALL_TILES_MAX
   if (small_ok && (tiles < small_max || on_panel)) {
     if (g.C == g.A) { // in-place (panel TRSM): one workgroup must own the whole row width
       // 32x128 strip, single LDS buffer: 22 KB and < 80 VGPRs, i.e. it fits in what two resident trailing-update

@@ -455,8 +455,7 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
   // GPX_POTF2=column selects the column-by-column kernel (its > 64 KB of dynamic LDS is a per-device function
   // attribute: set once per context, i.e. on every device a process opens)
   constexpr unsigned ATTR_POTF2_COLUMN = 1u << 31;
-  const char* e = getenv("GPX_POTF2");
-  const bool use_tile = !(e && e[0] == 'c');
+  const bool use_tile = !ctx->potf2_column; // GPX_POTF2=column (gpx_init)
   if (!use_tile && !(ctx->func_attr_mask & ATTR_POTF2_COLUMN)) {
     GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS_BYTES));
