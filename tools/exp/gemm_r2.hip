@@ -396,6 +396,102 @@ __global__ __launch_bounds__(256, 2) void gemm_bl(const double* A, long lda, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// 8-WAVE variant of gemm_bl: the same 128x128 tile, BK = 16, 2 LDS buffers (64 KB), but 512 threads = 2 x 4 waves of
+// 64 x 32 each (4 x 2 accumulators = 64 VGPRs): 2 workgroups / CU give FOUR waves per SIMD instead of two, so a wave
+// that waits (barrier, LDS, the vmcnt before the barrier) is covered by three others.  Costs 6 fragment reads per
+// 8 MFMAs instead of 8 per 16.  Each wave stages 4 x 1 KiB per k-step (waves 0-3: A rows, 4-7: B rows), one load
+// behind the MFMAs of each kk block.
+template <bool CACC, int OCC>
+__global__ __launch_bounds__(512, OCC) void gemm_bl8(const double* A, long lda, const double* B, long ldb, double* C,
+                                                     long ldc, int K, double alpha, double beta) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int BK = 16, BM = 128, BN = 128, ROWS = BM + BN, TD = ROWS * BK, GPW = 4;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, fk = lane >> 4;
+  const bool isA = wave < 4;
+  const double* base = isA ? A + (long)by * BM * lda : B + (long)bx * BN * ldb;
+  const long ldx = isA ? lda : ldb;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  int voff[GPW];
+#pragma unroll
+  for (int j = 0; j < GPW; ++j) {
+    const int row = (wave & 3) * 32 + j * 8 + (lane >> 3);
+    const int lrow = (isA ? 0 : BM) + row;
+    const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);
+    voff[j] = (int)((row * ldx + chunk * 2) * 8);
+  }
+  const int lds_wave = ((isA ? 0 : BM) + (wave & 3) * 32) * BK;
+  d4_t acc[4][2];
+  double* Cw = C + ((long)by * BM + wr * 64 + fk) * ldc + (long)bx * BN + wc * 32 + fr;
+  if (CACC) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n][r] = -Cw[(long)(m * 16 + 4 * r) * ldc + n * 16];
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[m][n] = d4_t{0, 0, 0, 0};
+  }
+  const int nk = K / BK;
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int ra = wr * 64 + m * 16 + fr;
+    aoff[m] = ra * BK + (((fk >> 1) ^ ((ra >> 1) & 7)) * 2) + (fk & 1);
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int rb = BM + wc * 32 + n * 16 + fr;
+    boff[n] = rb * BK + (((fk >> 1) ^ ((rb >> 1) & 7)) * 2) + (fk & 1);
+  }
+#define GLOAD8(j, buf, soff)                                                                                      \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + (buf) * TD + lds_wave + (j) * 8 * BK), 16, voff[j], \
+                                           (soff), 0, 0)
+#pragma unroll
+  for (int j = 0; j < GPW; ++j) GLOAD8(j, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  typedef const volatile double __attribute__((address_space(3)))* lcvd_t;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const int soff = ((kt + 1 < nk) ? kt + 1 : kt) * BK * 8;
+    const double* cb = smem + cur * TD;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double af[4], bf[2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) af[m] = *((lcvd_t)cb + (aoff[m] ^ (4 * kk)));
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bf[n] = *((lcvd_t)cb + (boff[n] ^ (4 * kk)));
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+      GLOAD8(kk, nxt, soff);
+      __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef GLOAD8
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        Cw[(long)(m * 16 + 4 * r) * ldc + n * 16] = CACC ? -acc[m][n][r] : alpha * acc[m][n][r];
+}
+
+// ---------------------------------------------------------------------------------------------
 struct Prob {
   const double *A, *B;
   double* C;
@@ -470,6 +566,15 @@ static void run_bl(Prob p, const char* name, bool check) {
   bench(p, [&]() { gemm_bl<MODE, CACC><<<grid, 256, lds>>>(p.A, p.ld, p.B, p.ld, p.C, p.ldc, p.K, p.alpha, p.beta); }, name, check);
 }
 
+template <bool CACC, int OCC>
+static void run_bl8(Prob p, const char* name, bool check) {
+  if (CACC) p.alpha = -1.0;
+  const size_t lds = (size_t)2 * 256 * 16 * 8;
+  CK(hipFuncSetAttribute((const void*)gemm_bl8<CACC, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid(p.N / 128, p.M / 128);
+  bench(p, [&]() { gemm_bl8<CACC, OCC><<<grid, 512, lds>>>(p.A, p.ld, p.B, p.ld, p.C, p.ldc, p.K, p.alpha, p.beta); }, name, check);
+}
+
 static void run_base(const Prob& p, const char* name, bool check) {
   const size_t lds = (size_t)4 * 128 * 17 * 8;
   CK(hipFuncSetAttribute((const void*)gemm_base<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -491,6 +596,16 @@ int main(int argc, char** argv) {
       Prob p{A, A, C, M, N, cfg == 0 ? 2048 : 512, ld, ldc, &h, cfg == 0 ? 0.0 : 1.0};
       printf("--- %s operands, K = %d, beta = %g ---\n", pass == 0 ? "random" : "zero", p.K, p.beta);
       const bool check = (pass == 0);
+      if (argc > 1 && argv[1][0] == '8') { // the 8-wave experiment against the shipped loop only
+        if (cfg == 0) {
+          run_bl<12, false>(p, "bl 3+3+2 + sgb, volatile ds_read", check);
+          run_bl8<false, 2>(p, "bl8: 8 waves of 64x32, 2 wg/CU", check);
+        } else {
+          run_bl<12, true>(p, "bl 3+3+2 + sgb, C-in-acc, volatile ds_read", check);
+          run_bl8<true, 2>(p, "bl8: 8 waves of 64x32, C-in-acc", check);
+        }
+        continue;
+      }
       run_base(p, "base 128x128 regstage LDT17", check);
       run_glds<2, 2, 2, 0>(p, "glds 128x128 2buf", check);
       if (cfg == 0) {
