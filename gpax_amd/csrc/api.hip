@@ -702,6 +702,7 @@ int gpx_init(int device, gpx_ctx** out) {
     if (const char* e = getenv("GPX_TAIL_OUTER_TILES")) ctx->tail_outer_tiles = atoi(e);
     if (const char* e = getenv("GPX_TILE_SWIZZLE")) ctx->tile_swizzle = atoi(e);
     if (const char* e = getenv("GPX_TILE_SWIZZLE_MIN")) ctx->tile_swizzle_min = atoi(e);
+    if (const char* e = getenv("GPX_GRID_PAD8")) ctx->grid_pad8 = atoi(e);
     ctx->s = ctx->stream;
   }
   GPX_HIP(ctx, hipEventCreate(&ctx->ev0));

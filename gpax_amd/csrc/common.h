@@ -173,6 +173,7 @@ struct gpx_ctx {
   bool persist_scope_ok = true;
   gpx::DevBuf tile_counters;
   unsigned tile_counter_seq = 0;
+  int grid_pad8 = 0; // GPX_GRID_PAD8: grid.x of the big-tile GEMM padded to a multiple of 8, so that XCD x (workgroup id % 8) sees tile columns x, x + 8, ... in every tile row
   int tile_swizzle_min = 1024; // GPX_TILE_SWIZZLE_MIN: tiles a launch must have for the XCD-aware order
   int tile_swizzle = 0; // GPX_TILE_SWIZZLE: XCD-aware tile order of the big-tile GEMM (8x8-tile chunks per XCD), 0 = grid order
   int tail_outer_tiles = 0; // GPX_TAIL_OUTER_TILES: outer block width in the tail (0 / >= outer_tiles: same as the head)
@@ -345,6 +346,7 @@ struct GemmArgs {
   int64_t c_split_stride;
   int skip;    // != 0: the 128-tile (skip_ti, skip_tj) of the caller's global tile frame is left out (it was updated by
   int skip_ti, skip_tj; // an earlier launch of its own: the "early diagonal" of the Cholesky panel chain, linalg.hip)
+  int nx;      // > 0: workgroups with blockIdx.x >= nx have no tile (grid.x padded to a multiple of 8, GPX_GRID_PAD8)
   int row_step, row_phase; // row_step > 1 (big-tile kernel only): the launch covers tile rows row_phase, row_phase + row_step, ...
   int nsplit;  // grid.z = nsplit * batch (filled in by launch_gemm_nt)
   int batch;   // independent problems per launch (0 or 1 = one); element b at base + b * *_bs

@@ -378,6 +378,7 @@ template <int TAG, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // non-trailing launches sit on the critical path of the look-ahead
+  if (g.nx > 0 && (int)blockIdx.x >= g.nx) return;
   const int by = g.row_step > 1 ? (int)blockIdx.y * g.row_step + g.row_phase : (int)blockIdx.y;
   nt128_tile<EPI>(g, smem, blockIdx.x, by, blockIdx.z);
 }
@@ -403,9 +404,31 @@ struct SwzMap {
 static bool make_swz_map(const GemmArgs& g, int tiles_m, int tiles_n, SwzMap& sm) {
   sm.tiles_m = tiles_m;
   sm.tiles_n = tiles_n;
+  const int delta = g.ti_off - g.tj_off;
+  if (sm.mode == 3) {
+    // ANTI-LOCALITY order (diagnostic): super blocks of 64 x 64 tiles; in round rho of a super block XCD x takes the
+    // wrapped diagonal { (i, (i + 8 rho + x) mod 64) }: its 64 resident workgroups share no A and no B panel.
+    sm.nstrips = (tiles_m + 63) / 64; // super-block rows
+    if (sm.nstrips > GPX_SWZ_MAX_STRIPS) return false;
+    const int ncb = (tiles_n + 63) / 64;
+    int acc = 0;
+    for (int R = 0; R < sm.nstrips; ++R) {
+      sm.pre[R] = acc;
+      int nc = ncb;
+      if (g.lower) {
+        const int last = (64 * R + 63 < tiles_m ? 64 * R + 63 : tiles_m - 1) + delta; // largest admissible column
+        nc = last < 0 ? 0 : last / 64 + 1;
+        if (nc > ncb) nc = ncb;
+      }
+      acc += nc;
+    }
+    sm.pre[sm.nstrips] = acc;
+    sm.max_items = acc * 64; // x 64 workgroups each in the launch arithmetic below = 4096 per super block
+    for (int k = 0; k <= 8; ++k) sm.xstart[k] = 0;
+    return acc > 0;
+  }
   sm.nstrips = (tiles_m + 7) / 8;
   if (sm.nstrips > GPX_SWZ_MAX_STRIPS) return false;
-  const int delta = g.ti_off - g.tj_off;
   // tiles of item (t, bx): rows max(8 t, bx - delta) .. last(t) when lower, all rows of the strip otherwise
   auto strip_last = [&](int t) { return 8 * t + 7 < tiles_m ? 8 * t + 7 : tiles_m - 1; };
   auto strip_cols = [&](int t) {
@@ -456,6 +479,16 @@ static bool make_swz_map(const GemmArgs& g, int tiles_m, int tiles_n, SwzMap& sm
 // workgroup L of a launch -> its tile; false: nothing to do (range exhausted, or a row past the last strip's end)
 __host__ __device__ __forceinline__ bool swz_decode(const SwzMap& sm, int L, int& by, int& bx) {
   const int x = L & 7, s = L >> 3; // slot s of XCD x: item xstart[x] + s / 8, row s % 8 of its strip
+  if (sm.mode == 3) {
+    const int rho = s >> 6, i = s & 63;
+    const int sb = rho >> 3, off = ((rho & 7) << 3) + ((x + i) & 7); // rotated with the row: every XCD gets every offset equally often
+    if (sb >= sm.pre[sm.nstrips]) return false;
+    int R = 0;
+    while (R + 1 < sm.nstrips && sm.pre[R + 1] <= sb) ++R;
+    by = 64 * R + i;
+    bx = 64 * (sb - sm.pre[R]) + ((i + off) & 63);
+    return by < sm.tiles_m && bx < sm.tiles_n;
+  }
   int item;
   if (sm.mode == 2) {
     item = ((s >> 3) << 3) + ((x + (s >> 3)) & 7); // rotated per group of 8: the short diagonal items go round the XCDs
@@ -489,8 +522,8 @@ int debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n
   g.ti_off = ti_off;
   g.tj_off = tj_off;
   SwzMap sm;
-  sm.mode = lower >= 2 ? 2 : 1; // diagnostic: lower = 2 / 3 selects the round-robin deal (3: lower triangle)
-  g.lower = lower = (lower == 1 || lower == 3);
+  sm.mode = lower >= 4 ? 3 : (lower >= 2 ? 2 : 1); // diagnostic: lower = 2 / 3: round-robin deal, 4 / 5: anti-locality
+  g.lower = lower = (lower & 1);
   if (!make_swz_map(g, tiles_m, tiles_n, sm)) return -1;
   int n = 0;
   for (int L = 0; L < sm.max_items * 64; ++L) {
@@ -666,6 +699,14 @@ static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
     GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_kernel<TAG, EPI>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ctx->func_attr_mask |= bit;
+  }
+  if (ctx->grid_pad8 && tiles_n > 8 && (tiles_n & 7) != 0) {
+    GemmArgs gp = g;
+    gp.nx = tiles_n;
+    dim3 grid((tiles_n + 7) & ~7, tiles_m, g.nsplit * g.batch);
+    gemm_nt128_kernel<TAG, EPI><<<grid, 256, lds, ctx->s>>>(gp);
+    GPX_HIP(ctx, hipGetLastError());
+    return 0;
   }
   dim3 grid(tiles_n, tiles_m, g.nsplit * g.batch);
   gemm_nt128_kernel<TAG, EPI><<<grid, 256, lds, ctx->s>>>(g);

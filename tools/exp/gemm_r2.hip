@@ -269,12 +269,16 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : 2) void gemm_gld
 //      9: as 8, pinned with sched_group_barrier     10: as 9 + odd workgroups start late (diagnostic)
 //      8/9: 4 + 4 loads in kk = 0, 1;  11: 3 + 3 + 2 in kk = 0, 1, 2 (pinned)
 // CACC: accumulators start from -C and the epilogue stores -acc (alpha = -1, beta = 1)
+// tile order experiment: ORDER_SKEW s > 0 maps workgroup (x, y) of the 2-D grid to tile column (x + s y) mod gridDim.x, so
+// that XCD w (workgroup id % 8; gridDim.x = 64 here) no longer sees the same tile columns in every tile row
+__constant__ int ORDER_SKEW;
 template <int MODE, bool CACC>
 __global__ __launch_bounds__(256, 2) void gemm_bl(const double* A, long lda, const double* B, long ldb, double* C,
                                                   long ldc, int K, double alpha, double beta) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int BK = 16, BM = 128, BN = 128, ROWS = BM + BN, TD = ROWS * BK, GPW = 8;
-  const int bx = blockIdx.x, by = blockIdx.y;
+  const int by = blockIdx.y;
+  const int bx = ORDER_SKEW > 0 ? (int)((blockIdx.x + ORDER_SKEW * blockIdx.y) % gridDim.x) : (int)blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fk = lane >> 4;
@@ -596,6 +600,18 @@ int main(int argc, char** argv) {
       Prob p{A, A, C, M, N, cfg == 0 ? 2048 : 512, ld, ldc, &h, cfg == 0 ? 0.0 : 1.0};
       printf("--- %s operands, K = %d, beta = %g ---\n", pass == 0 ? "random" : "zero", p.K, p.beta);
       const bool check = (pass == 0);
+      if (argc > 1 && argv[1][0] == 's') { // tile-order skew experiment on the shipped loop
+        for (int skew : {0, 1, 3, 5, 0}) {
+          CK(hipMemcpyToSymbol(HIP_SYMBOL(ORDER_SKEW), &skew, sizeof(int)));
+          char nm[64];
+          snprintf(nm, sizeof nm, "bl shipped loop, column skew %d", skew);
+          if (cfg == 0) run_bl<12, false>(p, nm, check);
+          else run_bl<12, true>(p, nm, check);
+        }
+        const int zero = 0;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(ORDER_SKEW), &zero, sizeof(int)));
+        continue;
+      }
       if (argc > 1 && argv[1][0] == '8') { // the 8-wave experiment against the shipped loop only
         if (cfg == 0) {
           run_bl<12, false>(p, "bl 3+3+2 + sgb, volatile ds_read", check);
