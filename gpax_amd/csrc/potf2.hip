@@ -178,7 +178,7 @@ typedef double pd4_t __attribute__((ext_vector_type(4)));
 constexpr int TS = 16;
 constexpr int TLD = 17;
 constexpr int TSZ = TS * TLD; // doubles per LDS tile
-constexpr size_t POTF2_TILE_LDS = (size_t)(17 * TSZ + 64) * sizeof(double);
+constexpr size_t POTF2_TILE_LDS = (size_t)(17 * TSZ + 160) * sizeof(double); // + scratch of the diagonal-tile factor
 
 __device__ __forceinline__ void lower_tile(int idx, int& i, int& j) { // idx = i (i + 1) / 2 + j
   i = (idx >= 28) ? 7 : (idx >= 21) ? 6 : (idx >= 15) ? 5 : (idx >= 10) ? 4 : (idx >= 6) ? 3 : (idx >= 3) ? 2 : (idx >= 1) ? 1 : 0;
@@ -276,6 +276,128 @@ __device__ __forceinline__ void diag16(double* D, double* Dinv, double* col /* 2
   }
 }
 
+// diag16, BLOCKED BY 4 COLUMNS (round 2) — the same arithmetic, entry by entry and in the same order, as diag16 above
+// (every S[r][i] still receives  S[r][i] = fma(-u_j[r], v_j[i], S[r][i])  for j = 0, 1, ... with u_j = column j,
+// v_j = column j x refined 1 / d_j: bit-identical results, tests/test_gpu_edges.py), but with TWO LDS round trips per
+// four columns instead of four.  Panel P = columns 4P .. 4P+3, owned by the lanes with q == P (one row each):
+//   1. its 4 x 4 diagonal block goes through LDS to every lane, which replays the block's four elimination steps in
+//      registers (pivots, reciprocals, multipliers v) — redundantly, so no further exchange is needed to bring the
+//      owners' own rows of the panel up to date;
+//   2. the owners publish U (their column entries, 1 on the pivot row) and V (entries x 1 / d); the lanes right of the
+//      panel apply the four rank-1 updates to their 4 entries, in column order.
+// MEASURED SLOWER AND LEFT OFF (GPX_POTF2_DIAG=blocked enables it; tools/exp/potf2_phase.hip): the diagonal-tile phase
+// takes 7050 cycles per panel against 5740 — the four column steps every lane replays cost ~60 fp64 VALU operations
+// at 8 cycles each, more than the two LDS round trips they save (a column step is ~360 cycles, of which the round
+// trip is about a third); 54 against 51 us per block.
+__device__ __forceinline__ double refined_rcp(double d) {
+  double ip = __builtin_amdgcn_rcp(d);
+  ip = fma(fma(-d, ip, 1.0), ip, ip);
+  ip = fma(fma(-d, ip, 1.0), ip, ip);
+  return ip;
+}
+
+__device__ __forceinline__ void diag16_blk(double* D, double* Dinv, double* scr /* 16 + 64 + 64 */, int lane, int& bad,
+                                           int base) {
+  const int r = lane & 15, q = lane >> 4;
+  double* blk = scr;
+  double* Ub = scr + 16;
+  double* Vb = scr + 80;
+  double e[4], mypiv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = 4 * q + t;
+    e[t] = (r >= i) ? D[r * TLD + i] : 0.0;
+    mypiv[t] = 1.0;
+  }
+#pragma unroll
+  for (int P = 0; P < 4; ++P) {
+    const int j0 = 4 * P;
+    const bool owner = (q == P);
+    if (owner && r >= j0 && r < j0 + 4) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) blk[(r - j0) * 4 + t] = e[t];
+    }
+    asm volatile("" ::: "memory"); // one wave: the LDS queue is in order (see diag16)
+    double b[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[a][c] = blk[a * 4 + c];
+    asm volatile("" ::: "memory");
+    double ipv[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const int j = j0 + s_;
+      const double dj = b[s_][s_];
+      const double ip2 = refined_rcp(dj);
+      ipv[s_] = ip2;
+      if (owner) mypiv[s_] = dj;
+      if (!(dj > 0.0) && bad == 0) bad = base + j + 1;
+#pragma unroll
+      for (int t = s_ + 1; t < 4; ++t) {
+        const double vv = b[t][s_] * ip2; // S[j0 + t][j] / d_j
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          if (a >= t || a <= s_) b[a][t] = fma(-((a == s_) ? 1.0 : b[a][s_]), vv, b[a][t]);
+        }
+        if (owner) {
+          const bool on = (r >= j0 + t) || (r <= j);
+          const double u = (r == j) ? 1.0 : e[s_];
+          if (on) e[t] = fma(-u, vv, e[t]);
+        }
+      }
+    }
+    if (P < 3) {
+      if (owner) {
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          Ub[r * 4 + s_] = (r == j0 + s_) ? 1.0 : e[s_];
+          Vb[r * 4 + s_] = e[s_] * ipv[s_];
+        }
+      }
+      asm volatile("" ::: "memory");
+      double u[4], vv[4][4];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) u[s_] = Ub[r * 4 + s_];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) vv[t][s_] = Vb[((4 * q + t) & 15) * 4 + s_];
+      asm volatile("" ::: "memory");
+      if (q > P) {
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int i = 4 * q + t;
+            const bool on = (r >= i) || (r <= j0 + s_);
+            if (on) e[t] = fma(-u[s_], vv[t][s_], e[t]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = 4 * q + t;
+    const double piv = sqrt(mypiv[t]);
+    const double ip = 1.0 / piv;
+    double lval, xval;
+    if (r > i) {
+      lval = e[t] * ip;
+      xval = 0.0;
+    } else if (r == i) {
+      lval = piv;
+      xval = ip;
+    } else {
+      lval = 0.0;
+      xval = e[t] * ip; // = Linv[i][r]
+    }
+    D[r * TLD + i] = lval;
+    Dinv[i * TLD + r] = xval;
+  }
+}
+
 // Phase tracing for tools/exp/potf2_phase.hip (compiled only with -DGPX_POTF2_TRACE): shader-clock stamps at
 // every barrier.  Measured per panel: dump 1650, diagonal factor 5750 (16 dependent column steps, each an LDS
 // write -> read round trip + the reciprocal), TRSM 1800, update 4300 .. 960 cycles; the diagonal factor is 45 %
@@ -301,6 +423,7 @@ __device__ long long gpx_potf2_trace[64];
 // the panel columns that have just been solved) — the update the panel chain would otherwise apply to this diagonal
 // tile with a GEMM launch of its own before the factorisation can start.  Same arithmetic as that launch: ascending
 // k in MFMA groups of 4, acc - a b (the GEMM kernels run -(-acc + a b): rounding is symmetric), so not a bit changes.
+template <bool BLK>
 __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t lda, double* Linv, int* info,
                                                             int info_base, int64_t a_bs, int64_t linv_bs,
                                                             const double* Ppre, int Kpre) {
@@ -396,7 +519,8 @@ __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t l
     GPX_TRACE(1 + 4 * p);
     // ---- B: diagonal tile -----------------------------------------------------------------------
     if (w == 0) {
-      diag16(Pbuf + p * TSZ, Dinv, col, lane, bad, p * TS);
+      if (BLK) diag16_blk(Pbuf + p * TSZ, Dinv, col, lane, bad, p * TS);
+      else diag16(Pbuf + p * TSZ, Dinv, col, lane, bad, p * TS);
       const int r = lane & 15, q = lane >> 4;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -473,8 +597,10 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
   {
     // algorithmic flops: factor n^3/3 + triangular inverse n^3/3
     ProfScope ps(ctx, GPX_PROF_POTF2, nb * 2.0 * PB * (double)PB * PB / 3.0);
-    if (use_tile)
-      potf2_tile_kernel<<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs, dPre, Kpre);
+    if (use_tile && ctx->potf2_diag_blocked)
+      potf2_tile_kernel<true><<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs, dPre, Kpre);
+    else if (use_tile)
+      potf2_tile_kernel<false><<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs, dPre, Kpre);
     else if (dPre != nullptr)
       return bad_arg(ctx, "the column-by-column potf2 kernel has no pre-update");
     else

@@ -193,3 +193,33 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.gpu
+def test_blocked_diagonal_tile_factor_is_bit_identical_to_the_column_version(monkeypatch):
+    """potf2.hip diag16_blk (16 x 16 diagonal tiles of the 128 x 128 block kernel factored four columns per LDS round
+    trip) restates diag16 (one column per round trip) operation by operation: factor, block inverses (through the solve
+    they feed) and the pivot report must agree bit for bit — also on a matrix that is not positive definite."""
+    import numpy as np
+    from gpax_amd import _lib
+
+    rng = np.random.default_rng(5)
+    mats = []
+    for n in (128, 200, 640):
+        B = rng.standard_normal((n, n + 8))
+        mats.append(B @ B.T / n + 0.3 * np.eye(n))
+    bad = mats[1].copy()
+    bad[150, 150] = -1.0  # pivot 151 fails
+    mats.append(bad)
+    res = {}
+    for mode in ("column", "blocked"):
+        monkeypatch.setenv("GPX_POTF2_DIAG", mode)
+        e = _lib.Engine(0)
+        res[mode] = [e.potrf(A) for A in mats]
+        e.close()
+    for (L0, i0), (L1, i1) in zip(res["column"], res["blocked"]):
+        assert i0 == i1
+        assert np.array_equal(L0, L1, equal_nan=True)
+    assert [i for _, i in res["blocked"]] == [0, 0, 0, 151]
+    L = res["blocked"][2][0]
+    assert np.abs(np.tril(L) @ np.tril(L).T - mats[2]).max() < 1e-12

@@ -10,15 +10,20 @@ int main() {
   double *dA, *dL;
   hipMalloc(&dA, n * n * 8);
   hipMalloc(&dL, n * n * 8);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(gpx::potf2_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipFuncSetAttribute(reinterpret_cast<const void*>(gpx::potf2_tile_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)gpx::POTF2_TILE_LDS);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(gpx::potf2_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)gpx::POTF2_TILE_LDS);
   long long t[64];
+  for (int variant = 0; variant < 2; ++variant) {
   for (int rep = 0; rep < 3; ++rep) {
     hipMemcpy(dA, h.data(), n * n * 8, hipMemcpyHostToDevice);
-    gpx::potf2_tile_kernel<<<1, 256, gpx::POTF2_TILE_LDS>>>(dA, n, dL, nullptr, 0, 0, 0);
+    if (variant == 0) gpx::potf2_tile_kernel<false><<<1, 256, gpx::POTF2_TILE_LDS>>>(dA, n, dL, nullptr, 0, 0, 0, nullptr, 0);
+    else gpx::potf2_tile_kernel<true><<<1, 256, gpx::POTF2_TILE_LDS>>>(dA, n, dL, nullptr, 0, 0, 0, nullptr, 0);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(t, HIP_SYMBOL(gpx::gpx_potf2_trace), sizeof t);
   }
+  printf("%s\n", variant == 0 ? "diagonal tiles column by column (round 1)" : "diagonal tiles blocked by 4 columns");
   printf("shader-clock cycles per phase\n p:   A(dump)  B(diag)  C(trsm)  D(update)\n");
   long long tot[4] = {0, 0, 0, 0};
   for (int p = 0; p < 8; ++p) {
@@ -28,5 +33,6 @@ int main() {
     tot[0] += a; tot[1] += b; tot[2] += c; tot[3] += d;
   }
   printf("sum: %7lld %8lld %8lld %8lld   total %lld\n", tot[0], tot[1], tot[2], tot[3], t[32] - t[0]);
+  }
   return 0;
 }
