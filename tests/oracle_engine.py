@@ -71,7 +71,11 @@ class OracleEngine:
         if getattr(self, "_diag", None) is not None:
             K = K + np.diag(self._diag)
         try:
+            if not np.all(np.isfinite(K)):  # extreme theta: the device kernel reports a failed pivot here too
+                raise np.linalg.LinAlgError("non-finite Gram matrix")
             self._L = np.linalg.cholesky(K)
+            if not np.all(np.isfinite(self._L)):
+                raise np.linalg.LinAlgError("non-finite factor")
         except np.linalg.LinAlgError:
             self._L = None
             return float("nan"), 1

@@ -98,3 +98,15 @@ def test_base_functions_match_the_oracle_restatement_of_base_acq():
         np.testing.assert_allclose(ucb((mean, var), beta=0.4, maximize=maximize), ref.acq_ucb((mean, var), 0.4, maximize),
                                    rtol=1e-15)
     np.testing.assert_allclose(ue((mean, var)), ref.acq_ue((mean, var)), rtol=1e-15)
+
+
+def test_readme_bayesian_optimisation_loop_finds_the_minimum():
+    """examples/bo_loop.py = steps A - D of the reference README (fit, UCB on the unmeasured grid, argmax, measure),
+    here on the test-only oracle engine: the loop localises the global minimum of the 1-D black box."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import bo_loop
+    out = bo_loop.main(num_steps=8, num_warmup=40, num_samples=40, verbose=False)
+    assert out["n_measured"] == 12
+    assert abs(out["x_best"] - out["x_true"]) <= 0.1 and out["y_best"] <= out["y_true"] + 0.1

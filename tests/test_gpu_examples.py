@@ -28,3 +28,10 @@ def test_custom_priors_and_node_sweep_example():
     with pytest.warns(UserWarning):  # kernel_prior: the reference's own warning (gp.py:116-123)
         out = ex.main(num_warmup=120, num_samples=120, verbose=False)
     assert out["same"] and out["rmse"] < 0.15 and 1.2 < out["t"] < 2.2
+
+
+def test_bayesian_optimisation_loop_example():
+    import bo_loop
+    out = bo_loop.main(num_steps=10, num_warmup=60, num_samples=60, verbose=False)
+    assert out["n_measured"] == 14
+    assert abs(out["x_best"] - out["x_true"]) <= 0.1 and out["y_best"] <= out["y_true"] + 0.1
