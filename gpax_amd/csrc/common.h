@@ -158,6 +158,7 @@ struct gpx_ctx {
   bool potf2_column = false;      // GPX_POTF2=column: the column-by-column diagonal-block kernel of round 1
   bool gemm_small = true;         // GPX_GEMM_SMALL=0: no latency shapes
   double small_tiles_max = 400.0; // GPX_SMALL_TILES_MAX: launches with fewer 128x128 tiles take the latency shapes
+  int far_after_u1 = 40; // GPX_FAR_AFTER_U1: tile rows below which the (single-sample) far update waits for U1 of the same block (0: never)
   int split_far = 0;
   int u1_split = 0; // GPX_U1_SPLIT: the columns of U1 the next potf2 + TRSM do not need run on the q stream (1: tail, 2: always)
   hipEvent_t evB = nullptr;

@@ -309,6 +309,14 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     if (rc < 0) break;
     if (k == ge) { // far update of the whole group on the main stream
       GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
+      // GPX_FAR_AFTER_U1 = t: once fewer than t tile rows remain (deep in the chain-bound tail, where the far update is
+      // shorter than the chain it hides behind) it starts only when U1(k) is done, so that U1 — on the chain — has the
+      // chip to itself instead of sharing it with the update that has time to spare.  Single-sample launches only: a
+      // batched update is B times longer and sets the pace itself.
+      if (ctx->far_after_u1 > 0 && bs.batch == 1 && (nblk - oe + extra_tiles) < ctx->far_after_u1) {
+        GPX_HIP(ctx, hipEventRecord(ctx->evD, span));
+        GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evD, 0));
+      }
       const int gob = ob_of(gs);
       // The next group's U1 launches write outer columns ge+2 .. ge_next+1.  If that group has several blocks those
       // columns get a ("near-far") launch of their own, so that its first U1 need not wait for the bulk; a single

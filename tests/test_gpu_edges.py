@@ -172,11 +172,11 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
                 # U1 split: only the next diagonal column stays on the chain, the rest runs on the q stream
                 dict(GPX_U1_SPLIT="2"), dict(GPX_U1_SPLIT="1", GPX_TAIL_TILES="12"), dict(GPX_U1_SPLIT="2", GPX_LAZY_GROUP="3"),
                 dict(GPX_U1_SPLIT="2", GPX_OUTER_TILES="2", GPX_LAZY_GROUP="1"), dict(GPX_U1_SPLIT="2", GPX_SPLIT_FAR="1"), dict(GPX_GRID_PAD8="1"),
-                dict(GPX_TILE_SWIZZLE="3", GPX_TILE_SWIZZLE_MIN="64")]
+                dict(GPX_TILE_SWIZZLE="3", GPX_TILE_SWIZZLE_MIN="64"), dict(GPX_FAR_AFTER_U1="0"), dict(GPX_FAR_AFTER_U1="100", GPX_LAZY_GROUP="1")]
     for env in variants:
         for k in ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_EARLY_DIAG", "GPX_PERSIST_GEMM", "GPX_CU_RESERVE",
                   "GPX_PERSIST_SCOPE", "GPX_CU_RESERVE_SOFT", "GPX_PERSIST_SLACK", "GPX_TAIL_TILES", "GPX_TILE_SWIZZLE", "GPX_TILE_SWIZZLE_MIN",
-                  "GPX_TAIL_OUTER_TILES", "GPX_SPLIT_FAR", "GPX_U1_SPLIT", "GPX_GRID_PAD8"):
+                  "GPX_TAIL_OUTER_TILES", "GPX_SPLIT_FAR", "GPX_U1_SPLIT", "GPX_GRID_PAD8", "GPX_FAR_AFTER_U1"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
