@@ -438,6 +438,8 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
       rc = rest_update(ob, oe, oe, oe2);
       if (rc < 0) break;
       ctx->s = smain;
+      // (starting a short far update only after U1, as potrf_lower does in its tail, was measured here too: the fit
+      // step gets 0.4 - 0.9 % slower — profiles/r02/chain_experiments.md)
       rc = rest_update(ob, oe, oe2, nblk);
       GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain));
     }
