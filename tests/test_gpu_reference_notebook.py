@@ -1,40 +1,86 @@
-"""The product against outputs of the reference itself: gpax_amd.ExactGP on the GPU, run exactly as the first cell of
-the reference's tutorial notebook runs gpax.ExactGP (examples/gpax_simpleGP.ipynb, cells 11 - 14: the `np.random.seed(0)`
-data, RBF kernel, default priors, 2000 warm-up + 2000 samples, one chain), must print the posterior summary the notebook
-holds — within its two decimals and the Monte-Carlo error of two independent chains — and agree with the exact integrals
-of tests/test_reference_notebook_pins.py.  The random streams differ (JAX threefry there, NumPy here), the posterior is
-the same."""
+"""The product against outputs of the reference itself: the models of gpax_amd on the GPU, run the way the reference's
+tutorial notebooks run gpax, must reproduce what those notebooks printed (tests/test_reference_notebook_pins.py holds the
+numbers, the data cells and the exact integrals of the oracle's model):
+
+  A  gpax_simpleGP.ipynb    ExactGP(1, 'RBF').fit(key, X, y, num_chains=1)                      default 2000 + 2000 NUTS
+  D  gpax_UIGP.ipynb        ExactGP(1, 'Matern', Gamma(2, 5) length prior, HalfNormal(0.1) noise prior)
+  E  MeasuredNoiseGP.ipynb  MeasuredNoiseGP(1, 'Matern').fit(key, X, y, measured_noise)
+  V  compare_GPs.ipynb      viGP(1, 'RBF').fit(key, X, y): the point estimate after 1000 SVI steps and its loss
+
+The random streams differ (JAX threefry there, NumPy here), the posteriors are the same: summaries agree within the two
+printed decimals and the Monte-Carlo error of two independent chains."""
 import numpy as np
 import pytest
 
-from tests.test_reference_notebook_pins import PRINTED, notebook_data, posterior_marginals
+from tests.test_reference_notebook_pins import KERNEL, PRINTED, PRINTED_SVI, notebook_data, posterior_marginals
 
 pytestmark = pytest.mark.gpu
 
 
-def test_exactgp_on_the_gpu_reproduces_the_tutorial_notebook_summary():
+def _check(samples, case, num_samples):
+    exact = posterior_marginals(case)
+    for name, (mean, std, median, n_eff) in PRINTED[case].items():
+        draws = np.asarray(samples[name]).reshape(-1)
+        assert draws.size == num_samples
+        q_mean, q_std, q_med = exact[name]
+        se = q_std / np.sqrt(min(n_eff, 0.2 * num_samples))  # a pessimistic effective size for our own chain
+        # against the exact posterior of the oracle's model
+        assert abs(draws.mean() - q_mean) <= 4 * se, (case, name, draws.mean(), q_mean)
+        assert abs(np.median(draws) - q_med) <= 5 * se, (case, name, np.median(draws), q_med)
+        # against what the reference printed (two chains' errors add in quadrature, plus the rounding)
+        assert abs(draws.mean() - mean) <= 0.005 + 4 * se * np.sqrt(2.0), (case, name, draws.mean(), mean)
+        assert abs(np.median(draws) - median) <= 0.005 + 5 * se * np.sqrt(2.0), (case, name, np.median(draws), median)
+
+
+def test_exactgp_rbf_reproduces_the_simplegp_notebook_summary():
     from gpax_amd import ExactGP
     from gpax_amd.utils import get_keys
 
-    X, y = notebook_data("A")
+    X, y, _ = notebook_data("A")
     key1, key2 = get_keys()
     gp_model = ExactGP(1, kernel="RBF")
     gp_model.fit(key1, X, y, num_chains=1, progress_bar=False, print_summary=False)  # defaults: 2000 + 2000
-    s = gp_model.get_samples()
-    exact = posterior_marginals("A")
-    for name, (mean, std, median, n_eff) in PRINTED["A"].items():
-        draws = np.asarray(s[name]).reshape(-1)
-        assert draws.size == 2000
-        q_mean, q_std, q_med = exact[name]
-        se = q_std / np.sqrt(min(n_eff, 400.0))  # our chain's effective size is not larger than the reference's
-        # against the exact posterior of the oracle's model
-        assert abs(draws.mean() - q_mean) <= 4 * se, (name, draws.mean(), q_mean)
-        assert abs(np.median(draws) - q_med) <= 5 * se, (name, np.median(draws), q_med)
-        # against what the reference printed (two chains' errors add in quadrature, plus the rounding)
-        assert abs(draws.mean() - mean) <= 0.005 + 4 * se * np.sqrt(2.0), (name, draws.mean(), mean)
-        assert abs(np.median(draws) - median) <= 0.005 + 5 * se * np.sqrt(2.0), (name, np.median(draws), median)
+    _check(gp_model.get_samples(), "A", 2000)
     # and the prediction of cell 16 has the shapes of the reference (posterior mean, (samples, n, points))
     X_test = np.linspace(-1, 1, 100)
     posterior_mean, f_samples = gp_model.predict(key2, X_test, n=20)
     assert posterior_mean.shape == (100,) and f_samples.shape == (2000, 20, 100)
     assert np.sqrt(np.mean((posterior_mean - np.sin(10 * X_test)) ** 2)) < 0.4  # 25 points for three periods
+
+
+def test_exactgp_matern_with_gamma_and_halfnormal_priors_reproduces_the_uigp_notebook_summary():
+    from gpax_amd import ExactGP, priors
+    from gpax_amd.utils import get_keys
+
+    X, y, _ = notebook_data("D")
+    model = ExactGP(1, KERNEL["D"], lengthscale_prior_dist=priors.gamma_dist(2, 5),
+                    noise_prior_dist=priors.halfnormal_dist(0.1))
+    model.fit(get_keys()[0], X, y, num_warmup=1500, num_samples=2500, progress_bar=False, print_summary=False)
+    _check(model.get_samples(), "D", 2500)
+
+
+def test_measured_noise_gp_reproduces_its_notebook_summary():
+    from gpax_amd import MeasuredNoiseGP
+    from gpax_amd.utils import get_keys
+
+    X, y, measured_noise = notebook_data("E")
+    model = MeasuredNoiseGP(1, "Matern")
+    model.fit(get_keys()[0], X, y, measured_noise, progress_bar=False, print_summary=False)  # 2000 + 2000
+    s = model.get_samples()
+    _check(s, "E", 2000)
+    assert np.all(np.asarray(s["noise"]) == 0.0)  # the deterministic site of mngp.py:84, printed as 0.00
+
+
+def test_vigp_reaches_the_state_the_compare_gps_notebook_printed():
+    from gpax_amd import viGP
+    from gpax_amd.utils import get_keys
+
+    X, y, _ = notebook_data("A")
+    m = viGP(1, kernel="RBF")
+    m.fit(get_keys()[0], X, y, progress_bar=False, print_summary=False)  # 1000 steps, step 5e-3, Delta guide
+    s = {k: float(np.asarray(v).reshape(-1)[0]) for k, v in m.get_samples().items()}
+    loss = np.asarray(m.loss)
+    p = PRINTED_SVI
+    assert abs(s["k_length"] - p["k_length"]) < 0.002 and abs(s["k_scale"] - p["k_scale"]) < 0.01
+    assert abs(s["noise"] - p["noise"]) < 0.0015
+    assert abs(loss[950:1000].mean() - p["avg_loss_951_1000"]) < 0.05 and abs(loss[0] - p["init_loss"]) < 1.5
