@@ -10,17 +10,16 @@ The reference (ziatdinovmax/gpax v0.1.9) is pure Python on JAX + NumPyro; neithe
 the build container (and they never travel to the GPU box), so the reference cannot be imported to generate vectors, and
 its own tests pin no numeric value on this path.  What the reference does hold are the committed cell
 outputs of its tutorial notebooks (examples/gpax_simpleGP.ipynb, gpax_UIGP.ipynb, MeasuredNoiseGP.ipynb, gpax_GPBO.ipynb,
-compare_GPs.ipynb): the NUTS posterior summaries (mean, std, median, n_eff of k_length, k_scale, noise) gpax printed for
-six problems whose data are fixed by np.random.seed(k) — ExactGP with RBF and Matern kernels, LogNormal / Gamma /
+GP_sGP.ipynb, compare_GPs.ipynb): the NUTS posterior summaries (mean, std, median, n_eff of k_length, k_scale, noise) gpax printed for
+seven problems whose data are fixed by np.random.seed(k) — ExactGP with RBF and Matern kernels, LogNormal / Gamma /
 HalfNormal priors, MeasuredNoiseGP — and the point estimate and loss of a viGP fit after 1000 SVI steps.
 tests/test_reference_notebook_pins.py integrates the two- / three-dimensional posteriors of THIS file's model exactly
 (tensor grid; correlation matrices from the kernel functions below; likelihood tied to exactgp_log_likelihood) and
-requires all 51 printed numbers to agree within their two decimals plus the Monte-Carlo error the printed n_eff implies,
+requires all 60 printed numbers to agree within their two decimals plus the Monte-Carlo error the printed n_eff implies,
 requires the negative log joint at the printed viGP state to sit within 0.04 of the printed loss, and shows that plausible
-restatement errors (no 1/2 in the RBF exponent, RBF for Matern, a Matern-5/2 without its quadratic term, another noise
-prior, measured variances left out) fail.  That pins kernel formulas, noise / jitter / measured-noise placement, priors and
-the likelihood (its constants included) to the reference statistically — k_length to 1 - 5 %, the log joint to 0.3 %;
-Matern-3/2 against Matern-5/2 is the one distinction two printed decimals do not resolve.  The posterior / draw arithmetic
+restatement errors (no 1/2 in the RBF exponent, RBF or Matern-3/2 for Matern-5/2, a Matern-5/2 without its quadratic term,
+another noise prior, measured variances left out) fail.  That pins kernel formulas, noise / jitter / measured-noise placement, priors and
+the likelihood (its constants included) to the reference statistically — k_length to 1 - 5 %, the log joint to 0.3 %.  The posterior / draw arithmetic
 (get_mvn_posterior, MVN sampling) and everything bit-level remain UNPINNED by reference-generated numbers.  Beyond that, this restatement follows the
 reference line by line (file:line cited per function, paths relative to the reference checkout) and is cross-checked
 independently (tests/test_oracle.py): direct-formula Gram in mpmath at 50 digits, scipy.stats.multivariate_normal for
