@@ -79,6 +79,9 @@ class OracleEngine:
         except np.linalg.LinAlgError:
             self._L = None
             return float("nan"), 1
+        if not np.all(np.isfinite(self._yres)):  # a mean function overflowed: the device returns NaN for the lml as well
+            self._w = np.full(self.N, np.nan)
+            return float("nan"), 0
         w = sla.solve_triangular(self._L, self._yres, lower=True)
         self._w = w
         lml = -0.5 * w @ w - np.log(np.diag(self._L)).sum() - 0.5 * self.N * ref.LOG_2PI

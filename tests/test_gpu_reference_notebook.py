@@ -5,6 +5,7 @@ numbers, the data cells and the exact integrals of the oracle's model):
   A  gpax_simpleGP.ipynb    ExactGP(1, 'RBF').fit(key, X, y, num_chains=1)                      default 2000 + 2000 NUTS
   D  gpax_UIGP.ipynb        ExactGP(1, 'Matern', Gamma(2, 5) length prior, HalfNormal(0.1) noise prior)
   E  MeasuredNoiseGP.ipynb  MeasuredNoiseGP(1, 'Matern').fit(key, X, y, measured_noise)
+  H  GP_sGP.ipynb           ExactGP(1, 'Matern', mean_fn=piecewise1, mean_fn_prior=piecewise1_priors): the structured GP
   V  compare_GPs.ipynb      viGP(1, 'RBF').fit(key, X, y): the point estimate after 1000 SVI steps and its loss
 
 The random streams differ (JAX threefry there, NumPy here), the posteriors are the same: summaries agree within the two
@@ -12,7 +13,8 @@ printed decimals and the Monte-Carlo error of two independent chains."""
 import numpy as np
 import pytest
 
-from tests.test_reference_notebook_pins import KERNEL, PRINTED, PRINTED_SVI, notebook_data, posterior_marginals
+from tests.test_reference_notebook_pins import (KERNEL, PRINTED, PRINTED_SVI, check_structured_gp_summary, notebook_data,
+                                                piecewise1, piecewise1_priors, posterior_marginals)
 
 pytestmark = pytest.mark.gpu
 
@@ -84,3 +86,13 @@ def test_vigp_reaches_the_state_the_compare_gps_notebook_printed():
     assert abs(s["k_length"] - p["k_length"]) < 0.002 and abs(s["k_scale"] - p["k_scale"]) < 0.01
     assert abs(s["noise"] - p["noise"]) < 0.0015
     assert abs(loss[950:1000].mean() - p["avg_loss_951_1000"]) < 0.05 and abs(loss[0] - p["init_loss"]) < 1.5
+
+
+def test_structured_gp_reproduces_the_sgp_notebook_summary():
+    from gpax_amd import ExactGP
+    from gpax_amd.utils import get_keys
+
+    X, y, _ = notebook_data("G")
+    gp_model = ExactGP(1, kernel="Matern", mean_fn=piecewise1, mean_fn_prior=piecewise1_priors)
+    gp_model.fit(get_keys()[0], X, y, num_warmup=2000, num_samples=2000, progress_bar=False, print_summary=False)
+    check_structured_gp_summary(gp_model.get_samples(), own_n_eff=300.0)

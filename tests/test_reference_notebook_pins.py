@@ -10,6 +10,8 @@ priors, jitter 1e-6:
   E  examples/MeasuredNoiseGP.ipynb cells 9-11    MeasuredNoiseGP Matern, 6 points with measured variances
   F  examples/gpax_GPBO.ipynb       cells 14-22   ExactGP RBF, noise ~ HalfNormal(0.01), the 10 seed points (step 1 / 7)
   G  examples/GP_sGP.ipynb          cells 15-18   ExactGP Matern, default priors, 15 points of a piecewise power law
+  H  examples/GP_sGP.ipynb          cells 24-28   as G with the mean function piecewise1 and its prior callable (t ~ U(0.5, 2.5),
+                                                  beta1, beta2 ~ LogNormal(0, 1)): six parameters — NUTS against NUTS
   V  examples/compare_GPs.ipynb     cell 20       viGP RBF on problem A: the point estimate after 1000 SVI steps and the
                                                   average loss of steps 951-1000
 
@@ -46,6 +48,9 @@ PRINTED = {
     "F": {"k_length": (0.76, 0.15, 0.74, 470.72), "k_scale": (12.88, 5.87, 11.61, 1199.93), "noise": (0.01, 0.01, 0.01, 558.75)},
     "G": {"k_length": (0.61, 0.17, 0.58, 549.76), "k_scale": (19.08, 9.91, 16.54, 915.50), "noise": (0.28, 0.39, 0.17, 555.31)},
 }
+# GP_sGP.ipynb cell 28, first model ("structured GP"): six-dimensional, compared chain against chain
+PRINTED_H = {"beta1": (4.46, 0.06, 4.47, 417.39), "beta2": (2.47, 0.04, 2.48, 300.77), "k_length": (3.56, 2.65, 2.83, 540.74),
+             "k_scale": (0.58, 0.62, 0.36, 408.26), "noise": (0.03, 0.03, 0.03, 398.94), "t": (1.83, 0.13, 1.83, 345.14)}
 # compare_GPs.ipynb cell 20: viGP(1, 'RBF').fit(rng_key, X, y) on problem A — "Inferred GP parameters" and the progress bar
 PRINTED_SVI = {"k_length": 0.1487, "k_scale": 0.6521, "noise": 0.024, "init_loss": 33.8362, "avg_loss_951_1000": 11.9065}
 
@@ -311,3 +316,49 @@ def test_host_nuts_on_the_oracle_engine_matches_the_exact_posterior(exact):
             se = q_std / np.sqrt(150.0)  # a deliberately pessimistic effective sample size
             assert abs(draws.mean() - q_mean) <= 4 * se, (case, name, draws.mean(), q_mean)
             assert abs(np.median(draws) - q_med) <= 5 * se, (case, name, np.median(draws), q_med)
+
+
+def piecewise1(x, params):
+    """GP_sGP.ipynb cell 24: power laws before and after the transition point t."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    return np.where(x < params["t"], x ** params["beta1"], x ** params["beta2"])
+
+
+def piecewise1_priors():
+    """GP_sGP.ipynb cell 26 with gpax_amd.sample in place of numpyro.sample."""
+    import gpax_amd as gpax
+    t = gpax.sample("t", gpax.dist.Uniform(0.5, 2.5))
+    beta1 = gpax.sample("beta1", gpax.dist.LogNormal(0, 1))
+    beta2 = gpax.sample("beta2", gpax.dist.LogNormal(0, 1))
+    return {"t": t, "beta1": beta1, "beta2": beta2}
+
+
+def check_structured_gp_summary(samples, own_n_eff):
+    """Our chain against the table the reference printed for the structured GP: means where the marginal is compact,
+    medians for the heavy-tailed kernel parameters; both chains' Monte-Carlo errors and the two printed decimals."""
+    for name, (mean, std, median, n_eff) in PRINTED_H.items():
+        draws = np.asarray(samples[name]).reshape(-1)
+        se = std * np.sqrt(1.0 / n_eff + 1.0 / own_n_eff)
+        if name in ("k_length", "k_scale"):
+            assert abs(np.median(draws) - median) <= 0.005 + 5 * 1.2533 * se, (name, np.median(draws), median)
+        else:
+            assert abs(draws.mean() - mean) <= 0.005 + 4 * se, (name, draws.mean(), mean)
+            assert 0.5 * std - 0.005 <= draws.std() <= 1.6 * std + 0.005, (name, draws.std(), std)
+
+
+def test_structured_gp_with_a_mean_function_prior_reproduces_the_sgp_notebook_summary():
+    """ExactGP(1, 'Matern', mean_fn=piecewise1, mean_fn_prior=piecewise1_priors) — the reference's "structured GP" — on
+    the test-only oracle engine (a shorter chain than the notebook's 2000 + 2000; the GPU test runs the full one)."""
+    from gpax_amd import ExactGP, _lib
+    from gpax_amd.utils import get_keys
+    from tests.oracle_engine import OracleEngine
+
+    _lib.set_engine(OracleEngine())
+    try:
+        X, y, _ = notebook_data("G")
+        m = ExactGP(1, kernel="Matern", mean_fn=piecewise1, mean_fn_prior=piecewise1_priors)
+        m.fit(get_keys()[0], X, y, num_warmup=600, num_samples=800, progress_bar=False, print_summary=False)
+        s = m.get_samples()
+    finally:
+        _lib.set_engine(None)
+    check_structured_gp_summary(s, own_n_eff=100.0)
