@@ -500,6 +500,11 @@ class ExactGP:
             x = s.dist.transform(ui)
             samples[s.name] = x.reshape(x.shape[:2] + tuple(s.shape)) if s.shape else x[..., 0]
             off += s.size
+        # numpyro.deterministic sites of a kernel_prior (constants, e.g. a fixed period) are part of MCMC.get_samples()
+        for name, val in getattr(self, "_det", {}).items():
+            if name not in samples:
+                v = np.asarray(val, dtype=np.float64)
+                samples[name] = np.broadcast_to(v, draws.shape[:2] + v.shape).copy()
         self._samples = samples
         self._chain_shape = draws.shape[:2]
         self.mcmc = _MCMCResult(self, stats)

@@ -6,6 +6,7 @@ numbers, the data cells and the exact integrals of the oracle's model):
   D  gpax_UIGP.ipynb        ExactGP(1, 'Matern', Gamma(2, 5) length prior, HalfNormal(0.1) noise prior)
   E  MeasuredNoiseGP.ipynb  MeasuredNoiseGP(1, 'Matern').fit(key, X, y, measured_noise)
   H  GP_sGP.ipynb           ExactGP(1, 'Matern', mean_fn=piecewise1, mean_fn_prior=piecewise1_priors): the structured GP
+  P6 simpleGP.ipynb         ExactGP(1, 'Periodic', kernel_prior=callable with the period fixed to 0.6)
   V  compare_GPs.ipynb      viGP(1, 'RBF').fit(key, X, y): the point estimate after 1000 SVI steps and its loss
 
 The random streams differ (JAX threefry there, NumPy here), the posteriors are the same: summaries agree within the two
@@ -96,3 +97,24 @@ def test_structured_gp_reproduces_the_sgp_notebook_summary():
     gp_model = ExactGP(1, kernel="Matern", mean_fn=piecewise1, mean_fn_prior=piecewise1_priors)
     gp_model.fit(get_keys()[0], X, y, num_warmup=2000, num_samples=2000, progress_bar=False, print_summary=False)
     check_structured_gp_summary(gp_model.get_samples(), own_n_eff=300.0)
+
+
+def test_exactgp_periodic_with_a_kernel_prior_callable_reproduces_the_simplegp_notebook_summary():
+    """simpleGP.ipynb cells 24-26, period fixed to 0.6 through numpyro.deterministic in the kernel_prior callable —
+    here with gpax_amd.sample / deterministic."""
+    import gpax_amd as gpax
+    from gpax_amd.utils import get_keys
+
+    def kernel_prior():
+        length = gpax.sample("k_length", gpax.dist.Gamma(2, 5))
+        scale = gpax.sample("k_scale", gpax.dist.LogNormal(0, 1))
+        period = gpax.deterministic("period", 0.6)
+        return {"k_length": length, "k_scale": scale, "period": period}
+
+    X, y, _ = notebook_data("P6")
+    with pytest.warns(UserWarning):  # kernel_prior: the reference's own deprecation warning
+        gp_model = gpax.ExactGP(1, kernel="Periodic", kernel_prior=kernel_prior)
+    gp_model.fit(get_keys()[0], X, y, num_chains=1, progress_bar=False, print_summary=False)  # 2000 + 2000
+    s = gp_model.get_samples()
+    assert np.all(np.asarray(s["period"]) == 0.6)
+    _check(s, "P6", 2000)

@@ -10,6 +10,8 @@ priors, jitter 1e-6:
   E  examples/MeasuredNoiseGP.ipynb cells 9-11    MeasuredNoiseGP Matern, 6 points with measured variances
   F  examples/gpax_GPBO.ipynb       cells 14-22   ExactGP RBF, noise ~ HalfNormal(0.01), the 10 seed points (step 1 / 7)
   G  examples/GP_sGP.ipynb          cells 15-18   ExactGP Matern, default priors, 15 points of a piecewise power law
+  P3, P6, P10  examples/simpleGP.ipynb cells 10, 24-26  ExactGP Periodic on the data of A through a kernel_prior callable:
+                                                  k_length ~ Gamma(2, 5), k_scale ~ LogNormal(0, 1), period fixed to 0.3 / 0.6 / 1.0
   H  examples/GP_sGP.ipynb          cells 24-28   as G with the mean function piecewise1 and its prior callable (t ~ U(0.5, 2.5),
                                                   beta1, beta2 ~ LogNormal(0, 1)): six parameters — NUTS against NUTS
   V  examples/compare_GPs.ipynb     cell 20       viGP RBF on problem A: the point estimate after 1000 SVI steps and the
@@ -47,7 +49,11 @@ PRINTED = {
     "E": {"k_length": (0.12, 0.05, 0.11, 1259.94), "k_scale": (26.24, 12.94, 23.17, 1095.03)},
     "F": {"k_length": (0.76, 0.15, 0.74, 470.72), "k_scale": (12.88, 5.87, 11.61, 1199.93), "noise": (0.01, 0.01, 0.01, 558.75)},
     "G": {"k_length": (0.61, 0.17, 0.58, 549.76), "k_scale": (19.08, 9.91, 16.54, 915.50), "noise": (0.28, 0.39, 0.17, 555.31)},
+    "P3": {"k_length": (0.34, 0.30, 0.24, 1672.28), "k_scale": (0.28, 0.24, 0.23, 1299.81), "noise": (0.61, 0.22, 0.58, 1658.78)},
+    "P6": {"k_length": (1.13, 0.33, 1.10, 1576.93), "k_scale": (0.74, 0.56, 0.58, 960.05), "noise": (0.07, 0.03, 0.07, 1220.55)},
+    "P10": {"k_length": (0.43, 0.28, 0.39, 1487.66), "k_scale": (0.33, 0.32, 0.25, 872.96), "noise": (0.58, 0.20, 0.55, 1481.98)},
 }
+PERIOD = {"P3": 0.3, "P6": 0.6, "P10": 1.0}
 # GP_sGP.ipynb cell 28, first model ("structured GP"): six-dimensional, compared chain against chain
 PRINTED_H = {"beta1": (4.46, 0.06, 4.47, 417.39), "beta2": (2.47, 0.04, 2.48, 300.77), "k_length": (3.56, 2.65, 2.83, 540.74),
              "k_scale": (0.58, 0.62, 0.36, 408.26), "noise": (0.03, 0.03, 0.03, 398.94), "t": (1.83, 0.13, 1.83, 345.14)}
@@ -57,10 +63,10 @@ PRINTED_SVI = {"k_length": 0.1487, "k_scale": 0.6521, "noise": 0.024, "init_loss
 
 def notebook_data(case):
     """The data cells of the notebooks (legacy NumPy global stream = RandomState(seed)).  Returns (X, y, measured_noise)."""
-    if case in "ABC":
+    if case in ("A", "B", "C", "P3", "P6", "P10"):
         rs = np.random.RandomState(0)
         X = rs.uniform(-1.0, 1.0, 25)
-        f = np.sin(10 * X) if case == "A" else np.sin(10 * X) * X ** 2
+        f = np.sin(10 * X) if case in ("A", "P3", "P6", "P10") else np.sin(10 * X) * X ** 2
         return X, f + rs.normal(0.0, 0.1, 25), None
     if case == "D":  # inputs are observed with an error the plain GP ignores: y belongs to the shifted inputs
         rs = np.random.RandomState(42)
@@ -86,7 +92,8 @@ def notebook_data(case):
     raise KeyError(case)
 
 
-KERNEL = {"A": "RBF", "B": "RBF", "C": "RBF", "D": "Matern", "E": "Matern", "F": "RBF", "G": "Matern"}
+KERNEL = {"A": "RBF", "B": "RBF", "C": "RBF", "D": "Matern", "E": "Matern", "F": "RBF", "G": "Matern",
+          "P3": "Periodic", "P6": "Periodic", "P10": "Periodic"}
 
 
 def log_priors_u(case):
@@ -96,13 +103,17 @@ def log_priors_u(case):
     gamma25 = lambda u: 2.0 * u - 5.0 * np.exp(u)
     halfnormal = lambda s: (lambda u: u - np.exp(2.0 * u) / (2.0 * s * s))
     return {"A": (ln, ln, ln), "B": (ln, ln, ln), "C": (gamma25, ln, ln), "D": (gamma25, ln, halfnormal(0.1)),
-            "E": (ln, ln, None), "F": (ln, ln, halfnormal(0.01)), "G": (ln, ln, ln)}[case]
+            "E": (ln, ln, None), "F": (ln, ln, halfnormal(0.01)), "G": (ln, ln, ln),
+            "P3": (gamma25, ln, ln), "P6": (gamma25, ln, ln), "P10": (gamma25, ln, ln)}[case]
 
 
 def _corr(case, X, ell):
     """Correlation matrix from the oracle's kernel function (scale 1, no noise, no jitter)."""
     X2 = X[:, None]
-    return ref.get_kernel(KERNEL[case])(X2, X2, {"k_length": np.array([ell]), "k_scale": 1.0}, noise=0.0, jitter=0.0)
+    params = {"k_length": np.array([ell]), "k_scale": 1.0}
+    if case in PERIOD:
+        params["period"] = PERIOD[case]
+    return ref.get_kernel(KERNEL[case])(X2, X2, params, noise=0.0, jitter=0.0)
 
 
 def eig_loglik(case, X, y, mn, ell, scale, noise):
@@ -113,10 +124,10 @@ def eig_loglik(case, X, y, mn, ell, scale, noise):
     return float(-0.5 * (yt ** 2 / d).sum() - 0.5 * np.log(d).sum() - 0.5 * np.log(D).sum() - 0.5 * X.size * LOG_2PI)
 
 
-GRID = {"ul": (-5.0, 4.0), "us": (-7.0, 7.5), "un": (-14.0, 3.0)}
+GRID = {"ul": (-8.0, 4.0), "us": (-7.0, 7.5), "un": (-14.0, 3.0)}
 
 
-def posterior_marginals(case, nl=260, ns=220, nn=200):
+def posterior_marginals(case, nl=340, ns=220, nn=200):
     X, y, mn = notebook_data(case)
     lp_l, lp_s, lp_n = log_priors_u(case)
     ul, us = np.linspace(*GRID["ul"], nl), np.linspace(*GRID["us"], ns)
@@ -170,8 +181,10 @@ def test_quadrature_likelihood_is_the_oracle_likelihood():
         for _ in range(6):
             ell, s = np.exp(rng.normal(-1.0, 1.0)), np.exp(rng.normal(0.0, 1.5))
             n = 0.0 if mn is not None else np.exp(rng.normal(-3.0, 1.5))
-            want = ref.exactgp_log_likelihood(X[:, None], y, {"k_length": np.array([ell]), "k_scale": s, "noise": n},
-                                              kernel=KERNEL[case], jitter=JITTER, measured_noise=mn)
+            params = {"k_length": np.array([ell]), "k_scale": s, "noise": n}
+            if case in PERIOD:
+                params["period"] = PERIOD[case]
+            want = ref.exactgp_log_likelihood(X[:, None], y, params, kernel=KERNEL[case], jitter=JITTER, measured_noise=mn)
             assert abs(eig_loglik(case, X, y, mn, ell, s, n) - want) <= 1e-7 * max(1.0, abs(want)), case
 
 
@@ -187,14 +200,14 @@ def test_oracle_posterior_reproduces_the_summaries_the_reference_printed(exact):
             # sample standard deviations of these heavy right tails converge slowly (and from below)
             assert -0.45 * q_std - half <= std - q_std <= 0.25 * q_std + half, (case, name, "std", q_std, std)
             checked += 3
-    assert checked == 60
+    assert checked == 87
 
 
 def test_the_pin_has_teeth():
     """The same integrals under plausible restatement errors land outside the tolerance: the RBF exponent without its
     1/2 (k_length comes out a factor sqrt(2) larger), a HalfNormal(1) noise prior instead of LogNormal(0, 1), the RBF
     kernel, Matern-3/2 or a Matern-5/2 without its quadratic term where Matern-5/2 belongs, measured variances left out."""
-    def mean_with(case, name, corr=None, lp_noise=None, drop_measured=False, nl=200, ns=160, nn=140):
+    def mean_with(case, name, corr=None, lp_noise=None, drop_measured=False, nl=260, ns=160, nn=140):
         X, y, mn = notebook_data(case)
         if drop_measured:
             mn = np.zeros_like(mn)
