@@ -10,12 +10,12 @@ The reference (ziatdinovmax/gpax v0.1.9) is pure Python on JAX + NumPyro; neithe
 the build container (and they never travel to the GPU box), so the reference cannot be imported to generate vectors, and
 its own tests pin no numeric value on this path.  What the reference does hold are the committed cell
 outputs of its tutorial notebooks (examples/gpax_simpleGP.ipynb, gpax_UIGP.ipynb, MeasuredNoiseGP.ipynb, gpax_GPBO.ipynb,
-GP_sGP.ipynb, compare_GPs.ipynb): the NUTS posterior summaries (mean, std, median, n_eff of k_length, k_scale, noise) gpax printed for
-seven problems whose data are fixed by np.random.seed(k) — ExactGP with RBF and Matern kernels, LogNormal / Gamma /
-HalfNormal priors, MeasuredNoiseGP — and the point estimate and loss of a viGP fit after 1000 SVI steps.
+GP_sGP.ipynb, simpleGP.ipynb, compare_GPs.ipynb): the NUTS posterior summaries (mean, std, median, n_eff of k_length, k_scale, noise) gpax printed for
+ten problems whose data are fixed by np.random.seed(k) — ExactGP with RBF, Matern and Periodic kernels, LogNormal /
+Gamma / HalfNormal priors, MeasuredNoiseGP — and the point estimate and loss of a viGP fit after 1000 SVI steps.
 tests/test_reference_notebook_pins.py integrates the two- / three-dimensional posteriors of THIS file's model exactly
 (tensor grid; correlation matrices from the kernel functions below; likelihood tied to exactgp_log_likelihood) and
-requires all 60 printed numbers to agree within their two decimals plus the Monte-Carlo error the printed n_eff implies,
+requires all 87 printed numbers to agree within their two decimals plus the Monte-Carlo error the printed n_eff implies,
 requires the negative log joint at the printed viGP state to sit within 0.04 of the printed loss, and shows that plausible
 restatement errors (no 1/2 in the RBF exponent, RBF or Matern-3/2 for Matern-5/2, a Matern-5/2 without its quadratic term,
 another noise prior, measured variances left out) fail.  That pins kernel formulas, noise / jitter / measured-noise placement, priors and
