@@ -11,9 +11,16 @@ value = posteriors per second over all ranks (weak scaling: every rank runs K st
 theta samples; the sweep has no data-path collective, only the final gather of results).
 
     python bench.py --gpus N --steps K --warmup W
-N > 1: one rank per GPU under torch.distributed.run (RCCL).  The driver launches the ranks itself; when bench.py
-is started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) it re-executes itself under
-`python -m torch.distributed.run --nproc-per-node N` and relays the ranks' output.
+N = 1: K steps of the resident sweep (gpx_sweep_resident), `--inflight` contexts on the GPU.
+N > 1: one process per GPU, NO PyTorch: every rank (RANK / LOCAL_RANK / WORLD_SIZE set by the launcher — the driver's
+`python -m torch.distributed.run`, or bench.py's own `gpax_amd.launch.spawn_ranks` when it is started plainly with
+--gpus N) joins the library's RCCL communicator (gpx_rank_*, ncclCommInitRank over the rendezvous of
+gpax_amd/launch.py) and the timed region is ONE collective gpx_rank_predict_sweep over S = N * K theta samples:
+rank 0's H2D of the inputs, ncclBroadcast over xGMI, every rank's block of K samples, ncclSend / ncclRecv gather, D2H
+on rank 0 — bracketed by a barrier on both sides (gpx_rank_barrier: own contexts synchronised + all-reduce), time =
+max over ranks (gpx_rank_allreduce_max).  A second record, `c4_sweep`, times BASELINE.json configs[3] (S = 1000,
+N = 8192, d = 3) the same way and against rank 0 alone.  `multi_gpu_path` says which transport ran ("rank-rccl";
+"rank-file" = the library's file transport, the fallback when RCCL cannot initialise).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -41,27 +48,23 @@ def parse():
     ap.add_argument("--kernel", default="Matern")
     ap.add_argument("--inflight", type=int, default=3, help="theta samples in flight per GPU (libgpx contexts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
-                    "exercise the multi-rank control flow on a box with fewer GPUs than ranks)")
-    ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses GPU 0")
+    ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses GPU 0 (file transport: RCCL "
+                    "refuses two ranks on one device)")
+    ap.add_argument("--transport", default=None, choices=["auto", "rccl", "file"], help="N > 1: transport of the "
+                    "rank communicator (default: $GPX_RANK_TRANSPORT or auto = RCCL, file on failure)")
+    ap.add_argument("--c4-S", type=int, default=1000, help="N > 1: samples of the C4 record (0: skip it)")
+    ap.add_argument("--c4-N", type=int, default=8192)
+    ap.add_argument("--force-rank-path", action="store_true", help="run the N > 1 code path whatever the world size "
+                    "(1 rank over RCCL on a 1-GPU box)")
+    ap.add_argument("--init-timeout", type=float, default=120.0, help="N > 1: seconds before a hung RCCL "
+                    "initialisation is abandoned for the file transport")
     ap.add_argument("--cpu-baseline-N", type=int, default=0, help="override the CPU sample size")
     ap.add_argument("--cpu-budget-s", type=float, default=150.0,
                     help="budget of the CPU leg; the same-workload sample (one posterior at the bench N) runs when its "
                          "estimate fits, else N is halved")
     ap.add_argument("--dry-launch", action="store_true",
-                    help="print the torch.distributed.run command --gpus N would re-execute under, and exit")
+                    help="print the launch bench.py --gpus N performs when started without a launcher, and exit")
     return ap.parse_args()
-
-
-def self_launch_command(a, argv):
-    """The command line `bench.py --gpus N` (N > 1, started without a launcher) re-executes itself under: one rank
-    per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def cpu_baseline(N, d, M, kernel, budget_s=150.0):
@@ -142,57 +145,141 @@ def gram_bytes_written(N, Np):
     return total
 
 
-def main():
-    a = parse()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # started plainly: launch the N ranks ourselves (one process per GPU over RCCL) and relay their output
-        import subprocess
-        argv = [x for x in sys.argv[1:] if x != "--dry-launch"]
-        cmd = self_launch_command(a, argv)
-        if a.dry_launch:
-            print(json.dumps({"launch": cmd}))
-            return
-        env = dict(os.environ)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        sys.exit(subprocess.run(cmd, env=env).returncode)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch = None
-    if "WORLD_SIZE" in os.environ and "RANK" in os.environ:  # launched by torch.distributed.run (any N, also 1)
-        # torch first: its bundled HIP runtime must be the one libgpx binds to (same SONAME)
-        import torch  # noqa: F811
-        import torch.distributed as dist  # noqa: F811
-        if a.share_gpu:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if a.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=a.dist_backend)
+def committed_pmc_record(N, d, M):
+    """HBM traffic and the serialised launch time of the dominant kernel from the committed rocprofv3 --pmc passes of
+    this same command (profiles/<round>/traffic.json; FETCH_SIZE doubled per the gfx950 correction,
+    MI355X_MICROARCH.md §HBM).  Under a PMC pass every dispatch runs alone, so the average duration there is the
+    kernel's rate WITHOUT the panel chain sharing the CUs."""
+    out = {"traffic": None, "traffic_note": None, "serialised_avg_launch_ms": None}
+    if (N, d, M) != (16384, 2, 1024):
+        return out
+    for rnd in ("r03", "r02", "r01"):
+        tj = os.path.join(ROOT, "profiles", rnd, "traffic.json")
+        if not os.path.exists(tj):
+            continue
+        t = json.load(open(tj))
+        if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+            out["traffic"] = (2.0 * t["FETCH_SIZE"]["avg_per_launch"] + t["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
+            out["traffic_note"] = (f"bytes per launch, profiles/{rnd}/{{fetch,write}}.md: (2*FETCH_SIZE + WRITE_SIZE) KB"
+                                   + ("" if rnd == "r03" else " (an earlier round's kernel)"))
+            us = [v["avg_duration_us"] for v in t.values() if isinstance(v, dict) and "avg_duration_us" in v]
+            if us:
+                out["serialised_avg_launch_ms"] = float(np.mean(us)) * 1e-3
+                out["serialised_note"] = f"average duration of the same kernel under the --pmc passes of profiles/{rnd} (every dispatch alone on the chip)"
+            break
+    return out
+
+
+def device_record(eng, a, lml):
+    """Rank 0, after the timed region: the roofline block of the dominant kernel (HIP events around every launch on the
+    launching stream, gpx_profile_*), stage timings and the fractions of the fp64 MFMA peak they imply."""
+    from gpax_amd import _lib
+    N, d, M = a.N, a.d, a.M
+    eng.profile_enable(True)
+    eng.profile_reset()
+    eng.time_stage(_lib.STAGE_PREDICT, 1)
+    n_l, ms, flops = eng.profile_read(_lib.PROF_GEMM_TRAILING)
+    alg_bytes = eng.profile_read_bytes(_lib.PROF_GEMM_TRAILING)
+    n_o, ms_o, flops_o = eng.profile_read(_lib.PROF_GEMM_OTHER)
+    n_p, ms_p, _ = eng.profile_read(_lib.PROF_POTF2)
+    n_g, ms_g, bytes_g = eng.profile_read(_lib.PROF_GRAM)
+    eng.profile_enable(False)
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    # stage timings (device events), fit step = lml + analytic gradient (one leapfrog of NUTS)
+    stages = {}
+    for name, st in [("gram", _lib.STAGE_GRAM), ("potrf", _lib.STAGE_POTRF), ("fit_step", _lib.STAGE_FITSTEP),
+                     ("posterior", _lib.STAGE_POSTERIOR), ("predict", _lib.STAGE_PREDICT)]:
+        eng.time_stage(st, 1)  # warm-up
+        stages[name + "_ms"] = float(np.median([eng.time_stage(st, 1) for _ in range(5)]))
+    pmc = committed_pmc_record(N, d, M)
+    post_flops = N ** 3 / 3 + N * N * M + N * M * M + 2 * N * N + 2 * N * M
+    pk = FP64_MFMA_PEAK_TFLOPS * 1e12
+    roof = {
+        "bound": "mfma",
+        "kernel": "gpx::gemm_nt128_kernel<1,1> (Cholesky trailing SYRK, lower tiles, LDS-direct staging; K = 1024 while the "
+                  "factorisation is GEMM-bound, 512 in the chain-bound tail)",
+        "achieved": achieved,
+        "peak": FP64_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+        "traffic": pmc["traffic"],
+        "traffic_note": pmc["traffic_note"],
+        "alg_bytes_per_launch_avg": (alg_bytes / n_l) if n_l else None,
+        "traffic_over_alg_bytes": (pmc["traffic"] / (alg_bytes / n_l)) if (pmc["traffic"] and n_l) else None,
+        "launches": n_l,
+        "avg_launch_ms": ms / n_l if n_l else None,
+        "alg_flops_per_launch_avg": flops / n_l if n_l else None,
+        "serialised_avg_launch_ms": pmc["serialised_avg_launch_ms"],
+        "serialised_frac": ((flops / n_l) / (pmc["serialised_avg_launch_ms"] * 1e-3) / pk)
+        if (pmc["serialised_avg_launch_ms"] and n_l) else None,
+        "serialised_note": pmc.get("serialised_note"),
+    }
+    return {
+        "roofline": roof,
+        "stages": stages,
+        "stages_frac_of_fp64_peak": {
+            "potrf": (N ** 3 / 3) / (stages["potrf_ms"] * 1e-3) / pk,
+            "fit_step": N ** 3 / (stages["fit_step_ms"] * 1e-3) / pk,
+            "posterior": post_flops / (stages["posterior_ms"] * 1e-3) / pk,
+            "predict": (post_flops + M ** 3 / 3 + M * M) / (stages["predict_ms"] * 1e-3) / pk,
+        },
+        "fit_step_tflops": N ** 3 / (stages["fit_step_ms"] * 1e-3) / 1e12,
+        "potrf_tflops": (N ** 3 / 3) / (stages["potrf_ms"] * 1e-3) / 1e12,
+        "kernel_classes_ms_per_predict": {"gemm_trailing": ms, "gemm_other": ms_o, "potf2": ms_p, "gram": ms_g},
+        "gram_alg_GBps": bytes_g / (ms_g * 1e-3) / 1e9 if ms_g > 0 else None,
+        "gram_written_GBps": (gram_bytes_written(N, (N + 1 + 127) // 128 * 128) / (stages["gram_ms"] * 1e-3) / 1e9),
+        "gram_note": "alg = 8 N^2 credited to the symmetric build (SURVEY 8d); written = bytes the lower 32x512 "
+                     "tiles actually store, over the stand-alone Gram stage",
+        "mfma_f64_microbench_tflops": eng.mfma_f64_peak(),
+        "lml_check": lml,
+    }
+
+
+def base_line(a, world, K, W, dt, n_fl, parallelism):
+    N, d, M = a.N, a.d, a.M
+    post_flops = N ** 3 / 3 + N * N * M + N * M * M + 2 * N * N + 2 * N * M + M ** 3 / 3 + M * M
+    return {
+        "metric": f"exactgp_posteriors_per_sec_N{N}_d{d}",
+        "value": world * K / dt,
+        "unit": "posteriors/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"C3: ExactGP {a.kernel} N={N} d={d} M={M}, 1 MVN draw per theta sample "
+                               "(BASELINE.json configs[2]); theta samples sharded over the GPUs, "
+                               + ("inputs resident in HBM" if world == 1 else
+                                  "inputs broadcast from rank 0 and results gathered there inside the timed region"),
+                   "parallelism": parallelism},
+        "inflight_per_gpu": n_fl,
+        "pipeline_tflops": world * post_flops / (dt / K) / 1e12,
+        "pipeline_frac_of_fp64_peak": post_flops / (dt / K) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+    }
+
+
+def single_gpu(a, device=0):
+    """N = 1: K steps of the resident sweep on one GPU, `--inflight` contexts (the round-1/2 headline, unchanged)."""
+    import threading
 
     from bench_inputs import synthetic_problem, synthetic_theta_samples  # BASELINE.md §3 workloads
     from gpax_amd import _lib
 
-    if world != a.gpus and rank == 0:
-        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
-    eng = _lib.Engine(local_rank)
+    eng = _lib.Engine(device)
     kind = _lib.kernel_kind(a.kernel)
     N, d, M = a.N, a.d, a.M
     X, y, Xnew, p = synthetic_problem(N, d, M, seed=0)
     K, W = a.steps, a.warmup
-    # every rank sweeps its own block of theta samples (contiguous shard of the global table)
-    thetas = synthetic_theta_samples(world * (K + W), d, seed=1)
-    lo = rank * (K + W)
-    sl_w = slice(lo, lo + W)
-    sl_k = slice(lo + W, lo + W + K)
-
+    thetas = synthetic_theta_samples(K + W, d, seed=1)
+    sl_w, sl_k = slice(0, W), slice(W, W + K)
     # Several theta samples in flight per GPU: independent libgpx contexts on the same device fill the
     # latency-bound tail of one sample's pipeline with the GEMM-heavy head of another (DESIGN.md §5).
-    import threading
     n_fl = max(1, min(a.inflight, K // 2))  # at least two steps per context
-    engines = [eng] + [_lib.Engine(local_rank) for _ in range(n_fl - 1)]
+    engines = [eng] + [_lib.Engine(device) for _ in range(n_fl - 1)]
     # resident state: X, yres, Xnew, eps on the device before the timed region
     for e in engines:
         e.set_train(X)
@@ -201,9 +288,6 @@ def main():
         e.mvn_draw(np.random.default_rng(2).standard_normal((1, M)))
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
         for e in engines:
             e.synchronize()
 
@@ -236,95 +320,141 @@ def main():
     ev_ms = sweep(sl_k)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
-    out = None
-    if rank == 0:
-        # ---- roofline of the dominant kernel (MFMA GEMM, trailing SYRK of the Cholesky) --------
-        eng.profile_enable(True)
-        eng.profile_reset()
-        eng.time_stage(_lib.STAGE_PREDICT, 1)
-        n_l, ms, flops = eng.profile_read(_lib.PROF_GEMM_TRAILING)
-        alg_bytes = eng.profile_read_bytes(_lib.PROF_GEMM_TRAILING)
-        n_o, ms_o, flops_o = eng.profile_read(_lib.PROF_GEMM_OTHER)
-        n_p, ms_p, _ = eng.profile_read(_lib.PROF_POTF2)
-        n_g, ms_g, bytes_g = eng.profile_read(_lib.PROF_GRAM)
-        eng.profile_enable(False)
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # stage timings (device events), fit step = lml + analytic gradient (one leapfrog of NUTS)
-        stages = {}
-        for name, st in [("gram", _lib.STAGE_GRAM), ("potrf", _lib.STAGE_POTRF), ("fit_step", _lib.STAGE_FITSTEP),
-                         ("posterior", _lib.STAGE_POSTERIOR), ("predict", _lib.STAGE_PREDICT)]:
-            eng.time_stage(st, 1)  # warm-up
-            stages[name + "_ms"] = float(np.median([eng.time_stage(st, 1) for _ in range(5)]))
-        # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-        # (profiles/r01/traffic.json; FETCH_SIZE doubled per the gfx950 correction, MI355X_MICROARCH.md §HBM)
-        traffic, traffic_note = None, None
-        for rnd in ("r02", "r01"):
-            tj = os.path.join(ROOT, "profiles", rnd, "traffic.json")
-            if os.path.exists(tj) and (N, d, M) == (16384, 2, 1024):
-                t = json.load(open(tj))
-                if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
-                    traffic = (2.0 * t["FETCH_SIZE"]["avg_per_launch"] + t["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
-                    traffic_note = (f"bytes per launch, profiles/{rnd}/{{fetch,write}}.md: (2*FETCH_SIZE + WRITE_SIZE) KB"
-                                    + ("" if rnd == "r02" else " (previous round's kernel)"))
-                    break
-        post_flops = N ** 3 / 3 + N * N * M + N * M * M + 2 * N * N + 2 * N * M + M ** 3 / 3 + M * M
-        out = {
-            "metric": f"exactgp_posteriors_per_sec_N{N}_d{d}",
-            "value": world * K / dt,
-            "unit": "posteriors/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": dt / K * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"C3: ExactGP {a.kernel} N={N} d={d} M={M}, 1 MVN draw per theta sample "
-                                   "(BASELINE.json configs[2]); per-rank theta shard, inputs resident in HBM",
-                       "parallelism": f"sample-sharded x{world}, {n_fl} samples in flight per GPU"},
-            "roofline": {
-                "bound": "mfma",
-                "kernel": "gpx::gemm_nt128_kernel<1,1> (Cholesky trailing SYRK, lower tiles, LDS-direct staging; K = 1024 while the "
-                          "factorisation is GEMM-bound, 512 in the chain-bound tail)",
-                "achieved": achieved,
-                "peak": FP64_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": traffic,
-                "traffic_note": traffic_note,
-                "alg_bytes_per_launch_avg": (alg_bytes / n_l) if n_l else None,
-                "launches": n_l,
-                "avg_launch_ms": ms / n_l if n_l else None,
-                "alg_flops_per_launch_avg": flops / n_l if n_l else None,
-            },
-            "event_ms_longest_context": ev_ms,
-            "inflight_per_gpu": n_fl,
-            "pipeline_tflops": post_flops / (dt / K) / 1e12,
-            "pipeline_frac_of_fp64_peak": post_flops / (dt / K) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-            "stages": stages,
-            "fit_step_tflops": N ** 3 / (stages["fit_step_ms"] * 1e-3) / 1e12,
-            "potrf_tflops": (N ** 3 / 3) / (stages["potrf_ms"] * 1e-3) / 1e12,
-            "kernel_classes_ms_per_predict": {"gemm_trailing": ms, "gemm_other": ms_o, "potf2": ms_p, "gram": ms_g},
-            "gram_alg_GBps": bytes_g / (ms_g * 1e-3) / 1e9 if ms_g > 0 else None,
-            "gram_written_GBps": (gram_bytes_written(N, (N + 1 + 127) // 128 * 128) / (stages["gram_ms"] * 1e-3) / 1e9),
-            "gram_note": "alg = 8 N^2 credited to the symmetric build (SURVEY 8d); written = bytes the lower 32x512 "
-                         "tiles actually store, over the stand-alone Gram stage",
-            "mfma_f64_microbench_tflops": eng.mfma_f64_peak(),
-            "lml_check": lml,
-        }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_N or N, d, M, a.kernel, a.cpu_budget_s)
+    out = base_line(a, 1, K, W, dt, n_fl, f"sample-sharded x1, {n_fl} samples in flight per GPU")
+    out["event_ms_longest_context"] = ev_ms
+    out["multi_gpu_path"] = None
+    out.update(device_record(eng, a, lml))
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_N or N, d, M, a.kernel, a.cpu_budget_s)
+    print(json.dumps(out), flush=True)
+
+
+def multi_rank(a, env):
+    """N > 1: one process per GPU over the library's own communicator (module docstring)."""
+    from bench_inputs import synthetic_problem, synthetic_theta_samples
+    from gpax_amd import _lib, launch
+
+    world, rank = env.world, env.rank
+    root = rank == 0
+    if world != a.gpus and root:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    device = 0 if a.share_gpu else env.local_rank
+    transport = a.transport or ("file" if a.share_gpu else None)
+    K, W = a.steps, a.warmup
+    n_fl = max(1, min(a.inflight, max(1, K // 2)))
+    rk = launch.init_rank(env, device=device, inflight=n_fl, transport=transport, timeout=a.init_timeout,
+                          reexec_on_hang=True)
+    info = rk.info()
+    kind = _lib.kernel_kind(a.kernel)
+    N, d, M = a.N, a.d, a.M
+    arrays = {}
+    if root:  # only rank 0 holds inputs; the sweep broadcasts them
+        X, y, Xnew, p = synthetic_problem(N, d, M, seed=0)
+        th = synthetic_theta_samples(world * (K + W), d, seed=1)
+        eps = np.random.default_rng(2).standard_normal((world * (K + W), 1, M))
+        arrays = dict(X=X, yres=y, Xnew=Xnew)
+
+    def sweep(lo, hi):
+        kw = dict(arrays)
+        if root:
+            kw.update(ells=th["k_length"][lo:hi], scales=th["k_scale"][lo:hi], noises=th["noise"][lo:hi], eps=eps[lo:hi])
+        return rk.predict_sweep(kind, N, d, hi - lo, M, 1, False, 1e-6, **kw)
+
+    if W > 0:
+        sweep(0, world * W)
+    rk.barrier()
+    t0 = time.perf_counter()
+    res = sweep(world * W, world * (W + K))
+    rk.barrier()
+    dt = float(rk.allreduce_max([time.perf_counter() - t0])[0])
+
+    # ---- second record: C4 (BASELINE.json configs[3]) through the same collective, and on rank 0 alone -------------------
+    c4 = None
+    if a.c4_S > 0:
+        N4, d4, M4, S4 = a.c4_N, 3, 1024, a.c4_S
+        arr4 = {}
+        if root:
+            X4, y4, Xn4, _ = synthetic_problem(N4, d4, M4, seed=0)
+            th4 = synthetic_theta_samples(S4, d4, seed=1)
+            eps4 = np.random.default_rng(2).standard_normal((S4, 1, M4))
+            arr4 = dict(X=X4, yres=y4, Xnew=Xn4, ells=th4["k_length"], scales=th4["k_scale"], noises=th4["noise"], eps=eps4)
+        warm = min(S4, 24 * world)  # >= one full batch (B = 7 at N = 8192) per context in flight
+        wk = {k: (v[:warm] if k in ("ells", "scales", "noises", "eps") else v) for k, v in arr4.items()}
+        rk.predict_sweep(kind, N4, d4, warm, M4, 1, False, 1e-6, **wk)  # allocations at this shape
+        rk.barrier()
+        t0 = time.perf_counter()
+        res4 = rk.predict_sweep(kind, N4, d4, S4, M4, 1, False, 1e-6, **arr4)
+        rk.barrier()
+        dt4 = float(rk.allreduce_max([time.perf_counter() - t0])[0])
+        dt4_one = None
+        if root:  # the same sweep on rank 0's GPU alone: the single-GPU product path (ExactGP.predict's engine pool)
+            engines = [_lib.Engine(device) for _ in range(max(1, a.inflight))]
+            sl = slice(0, min(S4, 64))
+            _lib.concurrent_sweep(engines, X4, kind, th4["k_length"][sl], th4["k_scale"][sl], th4["noise"][sl], y4, Xn4,
+                                  False, 1e-6, eps4[sl])
+            t0 = time.perf_counter()
+            one = _lib.concurrent_sweep(engines, X4, kind, th4["k_length"], th4["k_scale"], th4["noise"], y4, Xn4, False,
+                                        1e-6, eps4)
+            dt4_one = time.perf_counter() - t0
+            same = bool(np.array_equal(one[0], res4[0]) and np.array_equal(one[1], res4[1]))
+            for e in engines:
+                e.close()
+            flop4 = N4 ** 3 / 3 + N4 * N4 * M4 + N4 * M4 * M4 + 2 * N4 * N4 + 2 * N4 * M4 + M4 ** 3 / 3 + M4 * M4
+            c4 = {"config": f"C4: {S4}-sample predictive sweep N={N4} d={d4} M={M4} n=1 (BASELINE.json configs[3]), host "
+                            "arrays in, host arrays out",
+                  "S": S4, "seconds": dt4, "posteriors_per_s": S4 / dt4, "rccl_ranks": world if info["transport"] == "rccl" else 0,
+                  "ranks": world, "seconds_one_gpu": dt4_one, "posteriors_per_s_one_gpu": S4 / dt4_one,
+                  "speedup_vs_1": dt4_one / dt4, "tflops": S4 * flop4 / dt4 / 1e12,
+                  "frac_of_fp64_peak_per_gpu": S4 * flop4 / dt4 / 1e12 / FP64_MFMA_PEAK_TFLOPS / world,
+                  "identical_to_one_gpu": same, "nan_rows": int(np.isnan(res4[1]).any(axis=(1, 2)).sum())}
+        rk.barrier()
+
+    if root:
+        out = base_line(a, world, K, W, dt, n_fl,
+                        f"sample-sharded x{world} (one process per GPU), {n_fl} samples in flight per GPU")
+        out["multi_gpu_path"] = "rank-" + info["transport"]
+        out["rccl_version"] = info["rccl_version"]
+        out["rccl_ranks"] = world if info["transport"] == "rccl" else 0
+        out["collective"] = ("gpx_rank_predict_sweep: H2D on rank 0, ncclBroadcast, per-rank block, ncclSend/ncclRecv "
+                             "gather, D2H on rank 0 — all inside the timed region; barrier = gpx_rank_barrier, time = "
+                             "max over ranks (gpx_rank_allreduce_max)")
+        out["nan_rows"] = int(np.isnan(res[1]).any(axis=(1, 2)).sum())
+        eng = _lib.Engine(device)
+        eng.set_train(X)
+        lml, _ = eng.factor(kind, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+        eng.posterior(Xnew, p["noise"], 1e-6, want_cov=True)
+        eng.mvn_draw(np.random.default_rng(2).standard_normal((1, M)))
+        out.update(device_record(eng, a, lml))
+        if c4 is not None:
+            out["c4_sweep"] = c4
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    launch.finalize(env, rk)
+
+
+def main():
+    a = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL across processes needs here
+    from gpax_amd import launch
+
+    env = launch.rank_env()
+    if env is None and a.gpus > 1:
+        # started plainly: launch the N ranks ourselves (one process per GPU; no torch anywhere)
+        argv = [x for x in sys.argv[1:] if x != "--dry-launch"]
+        if a.dry_launch:
+            print(json.dumps({"launch": launch.spawn_command(__file__, argv, a.gpus)}))
+            return
+        sys.exit(launch.spawn_ranks(__file__, argv, a.gpus))
+    if a.dry_launch:
+        print(json.dumps({"launch": None}))
+        return
+    if a.force_rank_path and env is None:
+        import tempfile
+        env = launch.RankEnv(0, 1, 0, tempfile.mkdtemp(prefix="gpx_rdzv_"), 0, True)
+    if env is None or (env.world == 1 and not a.force_rank_path):
+        single_gpu(a, 0 if (env is None or a.share_gpu) else env.local_rank)
+    else:
+        multi_rank(a, env)
 
 
 if __name__ == "__main__":

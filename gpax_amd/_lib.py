@@ -91,6 +91,18 @@ def load_library() -> C.CDLL:
         "gpx_predict_sweep_multi": (C.c_int, [vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
                                               _dp, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip, _dp,
                                               C.c_int]),
+        "gpx_rank_unique_id": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
+        "gpx_rank_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]),
+        "gpx_rank_destroy": (None, [vp]),
+        "gpx_rank_last_error": (C.c_char_p, [vp]),
+        "gpx_rank_info": (C.c_int, [vp, _ip, _ip, _ip, _ip, _ip]),
+        "gpx_rank_barrier": (C.c_int, [vp]),
+        "gpx_rank_allreduce_max": (C.c_int, [vp, _dp, C.c_int]),
+        "gpx_rank_bcast": (C.c_int, [vp, _dp, C.c_int64]),
+        "gpx_rank_predict_sweep": (C.c_int, [vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
+                                             _dp, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip, _dp,
+                                             C.c_int, C.c_int]),
+        "gpx_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
@@ -105,7 +117,9 @@ EXPORTED_SYMBOLS = (
     "gpx_factor gpx_lml_grad gpx_lml_grad_diag gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
     "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_tile_order gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
-    "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_predict_sweep_multi"
+    "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_predict_sweep_multi "
+    "gpx_rank_unique_id gpx_rank_init gpx_rank_destroy gpx_rank_last_error gpx_rank_info gpx_rank_barrier "
+    "gpx_rank_allreduce_max gpx_rank_bcast gpx_rank_predict_sweep gpx_shard_range"
 ).split()
 
 
@@ -538,6 +552,122 @@ class Node:
         if want_var:
             return means, samples, infos, vars_
         return means, samples, infos
+
+
+UNIQUE_ID_BYTES = 128
+
+
+def shard_range(S: int, part: int, parts: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of part `part` out of `parts` over S samples — the library's own rule
+    (gpx_shard_range; host only, needs no GPU)."""
+    lo, hi = C.c_int(), C.c_int()
+    if load_library().gpx_shard_range(int(S), int(part), int(parts), C.byref(lo), C.byref(hi)) != 0:
+        raise ValueError(f"shard_range({S}, {part}, {parts})")
+    return lo.value, hi.value
+
+
+def rccl_unique_id() -> bytes:
+    """The 128-byte id rank 0 creates for ncclCommInitRank (gpx_rank_unique_id)."""
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    err = C.create_string_buffer(512)
+    rc = load_library().gpx_rank_unique_id(buf, err, 512)
+    if rc != 0:
+        raise GpxError(f"gpx_rank_unique_id failed ({rc}): {err.value.decode(errors='replace')}")
+    return buf.raw
+
+
+class Rank:
+    """One process = one GPU = one rank of the sharded predictive sweep (include/gpx.h gpx_rank_*): `inflight` libgpx
+    contexts on `device` and rank `rank` of an RCCL communicator over `nranks` processes.  predict_sweep is collective:
+    rank 0 passes the arrays and receives the results, the other ranks pass None and receive None.
+    Transport: RCCL (unique_id from rank 0's rccl_unique_id()) or, with file_dir, files in a directory all ranks share
+    (tests with several ranks on one GPU; fallback).  gpax/models/gp.py:392-395."""
+
+    def __init__(self, device: int, rank: int, nranks: int, unique_id: Optional[bytes] = None,
+                 file_dir: Optional[str] = None, inflight: Optional[int] = None):
+        self._lib = load_library()
+        self._rk = C.c_void_p()
+        self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
+        self.inflight = sweep_inflight() if inflight is None else max(1, int(inflight))
+        if file_dir is None and (unique_id is None or len(unique_id) != UNIQUE_ID_BYTES):
+            raise GpxError("Rank: the rccl transport needs rank 0's 128-byte unique id")
+        rc = self._lib.gpx_rank_init(self.device, self.rank, self.nranks, unique_id,
+                                     None if file_dir is None else os.fsencode(file_dir), self.inflight,
+                                     C.byref(self._rk))
+        if rc != 0:
+            msg = self._lib.gpx_rank_last_error(self._rk).decode() if self._rk else "gpx_rank_init failed"
+            if self._rk:
+                self._lib.gpx_rank_destroy(self._rk)
+                self._rk = C.c_void_p()
+            raise GpxError(f"gpx_rank_init(device={device}, rank={rank}/{nranks}) failed ({rc}): {msg}")
+
+    def close(self):
+        if getattr(self, "_rk", None):
+            self._lib.gpx_rank_destroy(self._rk)
+            self._rk = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise GpxError(f"{what} failed ({rc}) on rank {self.rank}: {self._lib.gpx_rank_last_error(self._rk).decode()}")
+
+    def info(self) -> dict:
+        r, n, f, t, v = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.gpx_rank_info(self._rk, C.byref(r), C.byref(n), C.byref(f), C.byref(t), C.byref(v)),
+                    "gpx_rank_info")
+        return {"rank": r.value, "nranks": n.value, "inflight": f.value, "transport": "rccl" if t.value else "file",
+                "rccl_version": v.value}
+
+    def barrier(self):
+        self._check(self._lib.gpx_rank_barrier(self._rk), "gpx_rank_barrier")
+
+    def allreduce_max(self, values) -> np.ndarray:
+        v = _f64(values).reshape(-1).copy()
+        self._check(self._lib.gpx_rank_allreduce_max(self._rk, _ptr(v), int(v.size)), "gpx_rank_allreduce_max")
+        return v
+
+    def bcast(self, arr: np.ndarray) -> np.ndarray:
+        """In-place broadcast of a float64 array of the SAME size on every rank (rank 0's content wins)."""
+        a = _f64(arr)
+        if a is not arr:
+            a = a.copy()
+        self._check(self._lib.gpx_rank_bcast(self._rk, _ptr(a), int(a.size)), "gpx_rank_bcast")
+        return a
+
+    def predict_sweep(self, kind: int, N: int, d: int, S: int, M: int, n: int, noiseless: bool, jitter: float,
+                      yres_rows: int = 1, X=None, ells=None, scales=None, noises=None, yres=None, Xnew=None, eps=None,
+                      want_var: bool = False, m_slice: int = 0):
+        """Collective.  Sizes / flags on every rank; arrays on rank 0 (ignored elsewhere).  Returns
+        (means, samples, infos[, vars]) on rank 0, None on the other ranks."""
+        root = self.rank == 0
+        means = samples = infos = vars_ = None
+        if root:
+            X = _f64(X, (N, d))
+            ells = _f64(ells, (S, n_ell(kind, d)))
+            scales, noises = _f64(scales, (S,)), _f64(noises, (S,))
+            yres = _f64(yres, (yres_rows, N))
+            Xnew = _f64(Xnew, (M, d))
+            eps = None if n == 0 else _f64(eps, (S, n, M))
+            means = np.empty((S, M))
+            samples = np.empty((S, n, M))
+            infos = np.zeros(S, dtype=np.int32)
+            vars_ = np.empty((S, M)) if want_var else None
+        else:
+            X = ells = scales = noises = yres = Xnew = eps = None
+        rc = self._lib.gpx_rank_predict_sweep(
+            self._rk, int(kind), _ptr(X), int(N), int(d), int(S), _ptr(ells), _ptr(scales), _ptr(noises), _ptr(yres),
+            int(yres_rows), _ptr(Xnew), int(M), int(bool(noiseless)), float(jitter), _ptr(eps), int(n), _ptr(means),
+            _ptr(samples) if (root and n) else None, None if infos is None else infos.ctypes.data_as(_ip), _ptr(vars_),
+            int(bool(want_var)), int(m_slice))
+        self._check(rc, "gpx_rank_predict_sweep")
+        if not root:
+            return None
+        return (means, samples, infos, vars_) if want_var else (means, samples, infos)
 
 
 def visible_device_count() -> int:

@@ -19,59 +19,13 @@
 // entry.  GPX_NODE_TRANSPORT=memcpy replaces the two RCCL steps by hipMemcpyPeerAsync; it exists so that the
 // sharding / threading logic can be exercised on a box with a single GPU (the same device listed twice, which RCCL
 // refuses) and is never selected implicitly.
-#include <dlfcn.h>
-#include <rccl/rccl.h>
-
 #include <cstdlib>
-#include <thread>
 
-#include "common.h"
+#include "rccl_bind.h"
 
 using namespace gpx;
 
 namespace {
-
-struct RcclApi {
-  void* handle = nullptr;
-  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
-  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  ncclResult_t (*GetVersion)(int*) = nullptr;
-};
-
-bool load_rccl(RcclApi& r, std::string& err) {
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) {
-    r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (r.handle) break;
-  }
-  if (!r.handle) {
-    err = std::string("cannot load RCCL (librccl.so.1): ") + dlerror();
-    return false;
-  }
-#define GPX_SYM(field, name)                                              \
-  r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name));   \
-  if (!r.field) {                                                         \
-    err = std::string("RCCL symbol missing: ") + name;                    \
-    return false;                                                         \
-  }
-  GPX_SYM(CommInitAll, "ncclCommInitAll")
-  GPX_SYM(CommDestroy, "ncclCommDestroy")
-  GPX_SYM(GetErrorString, "ncclGetErrorString")
-  GPX_SYM(Broadcast, "ncclBroadcast")
-  GPX_SYM(Send, "ncclSend")
-  GPX_SYM(Recv, "ncclRecv")
-  GPX_SYM(GroupStart, "ncclGroupStart")
-  GPX_SYM(GroupEnd, "ncclGroupEnd")
-  GPX_SYM(GetVersion, "ncclGetVersion")
-#undef GPX_SYM
-  return true;
-}
 
 struct NodeDev {
   int device = -1;
@@ -79,25 +33,6 @@ struct NodeDev {
   hipStream_t cs = nullptr;   // communication / staging stream
   DevBuf payload;             // [X | X_new | y_res | eps] as broadcast
   DevBuf out;                 // this GPU's result block (the root's holds every block: the gather target)
-};
-
-// contiguous block [start, stop) of part `r` out of `parts` over S items, sizes differing by at most 1
-inline void shard_range(int S, int r, int parts, int* lo, int* hi) {
-  const int base = S / parts, rem = S % parts;
-  *lo = r * base + (r < rem ? r : rem);
-  *hi = *lo + base + (r < rem ? 1 : 0);
-}
-
-// result block of c samples, in doubles: [means c*M | draws c*n*M | vars c*M | pivots: 2c ints in c doubles]
-struct BlockLayout {
-  int64_t means, draws, vars, infos, total;
-  BlockLayout(int c, int n, int M) {
-    means = 0;
-    draws = (int64_t)c * M;
-    vars = draws + (int64_t)c * n * M;
-    infos = vars + (int64_t)c * M;
-    total = infos + c;
-  }
 };
 
 } // namespace
@@ -241,18 +176,17 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
   const int ne = d + (kind == GPX_KERNEL_PERIODIC ? 1 : 0);
 
   // ---- 1. payload: one upload to the root GPU, one broadcast over xGMI ----------------------------------------
-  const int64_t o_X = 0, o_Xn = o_X + (int64_t)N * d, o_y = o_Xn + (int64_t)M * d,
-                o_eps = o_y + (int64_t)yres_rows * N, p_total = o_eps + (int64_t)S * n * M;
-  const size_t p_bytes = (size_t)p_total * sizeof(double);
+  const PayloadLayout pl(N, d, M, yres_rows, S, n, ne, false);
+  const size_t p_bytes = (size_t)pl.total * sizeof(double);
   NodeDev& root = nd->devs[0];
   NODE_HIP(nd, hipSetDevice(root.device));
   NODE_HIP(nd, hipStreamSynchronize(root.cs)); // previous use of the staging buffers is over
   NODE_HIP(nd, nd->pin_in.ensure(p_bytes));
   double* hp = nd->pin_in.d();
-  std::memcpy(hp + o_X, X, (size_t)N * d * sizeof(double));
-  std::memcpy(hp + o_Xn, Xnew, (size_t)M * d * sizeof(double));
-  std::memcpy(hp + o_y, yres, (size_t)yres_rows * N * sizeof(double));
-  if (n > 0) std::memcpy(hp + o_eps, eps, (size_t)S * n * M * sizeof(double));
+  std::memcpy(hp + pl.X, X, (size_t)N * d * sizeof(double));
+  std::memcpy(hp + pl.Xn, Xnew, (size_t)M * d * sizeof(double));
+  std::memcpy(hp + pl.y, yres, (size_t)yres_rows * N * sizeof(double));
+  if (n > 0) std::memcpy(hp + pl.eps, eps, (size_t)S * n * M * sizeof(double));
   for (int r = 0; r < G; ++r) {
     NODE_HIP(nd, hipSetDevice(nd->devs[(size_t)r].device));
     NODE_HIP(nd, nd->devs[(size_t)r].payload.ensure(p_bytes));
@@ -260,12 +194,17 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
   NODE_HIP(nd, hipSetDevice(root.device));
   NODE_HIP(nd, hipMemcpyAsync(root.payload.p, hp, p_bytes, hipMemcpyHostToDevice, root.cs));
   if (nd->use_rccl) {
+    // errors inside a group are collected; the group is ALWAYS closed before returning (an open group would poison
+    // every later RCCL call of this process)
+    ncclResult_t first = ncclSuccess;
     NODE_NCCL(nd, nd->rccl.GroupStart());
-    for (int r = 0; r < G; ++r) {
+    for (int r = 0; r < G && first == ncclSuccess; ++r) {
       NodeDev& D = nd->devs[(size_t)r];
-      NODE_NCCL(nd, nd->rccl.Broadcast(D.payload.p, D.payload.p, (size_t)p_total, ncclDouble, 0, nd->comms[(size_t)r], D.cs));
+      first = nd->rccl.Broadcast(D.payload.p, D.payload.p, (size_t)pl.total, ncclDouble, 0, nd->comms[(size_t)r], D.cs);
     }
-    NODE_NCCL(nd, nd->rccl.GroupEnd());
+    const ncclResult_t ge = nd->rccl.GroupEnd();
+    if (first == ncclSuccess) first = ge;
+    if (first != ncclSuccess) return node_fail(nd, std::string("ncclBroadcast: ") + nd->rccl.GetErrorString(first));
   } else {
     for (int r = 1; r < G; ++r) {
       NodeDev& D = nd->devs[(size_t)r];
@@ -294,37 +233,15 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
   }
   // below N ~ 3000 one context's batched sweep already fills a GPU: one context per GPU there
   const int per_gpu = (N < 3000) ? 1 : (int)root.ctxs.size();
+  const ShardJob jb{kind, N, d, M, n, yres_rows, noiseless, m_slice, ne, jitter, vars != nullptr, ells, scales, noises};
   std::vector<std::thread> threads;
   std::vector<int> rcs((size_t)G * per_gpu, 0);
   std::vector<int> cblock((size_t)G * per_gpu, M);
   for (int r = 0; r < G; ++r) {
-    const int c_r = hi[(size_t)r] - lo[(size_t)r];
-    if (c_r <= 0) continue;
-    const BlockLayout bl(c_r, n, M);
     NodeDev& D = nd->devs[(size_t)r];
-    const int parts = per_gpu < c_r ? per_gpu : c_r;
-    for (int c = 0; c < parts; ++c) {
-      int slo, shi;
-      shard_range(c_r, c, parts, &slo, &shi);
-      gpx_ctx* ctx = D.ctxs[(size_t)c];
-      double* blk = D.out.d(); // block r starts at offset 0 of its own buffer (the root's block is block 0 of the gather buffer)
-      const double* pl = D.payload.d();
-      const int g0 = lo[(size_t)r] + slo; // first global sample of this context
-      const int cnt = shi - slo;
-      int* rc_slot = &rcs[(size_t)r * per_gpu + c];
-      int* cb_slot = &cblock[(size_t)r * per_gpu + c];
-      threads.emplace_back([=]() {
-        int rc = sweep_device_io(ctx, kind, cnt, ells + (int64_t)g0 * ne, scales + g0, noises + g0, pl + o_X, N, d,
-                                 pl + o_y + (yres_rows == 1 ? 0 : (int64_t)g0 * N), yres_rows == 1 ? 1 : cnt, pl + o_Xn,
-                                 M, noiseless, jitter, n > 0 ? pl + o_eps + (int64_t)g0 * n * M : nullptr, n,
-                                 blk + bl.means + (int64_t)slo * M, n > 0 ? blk + bl.draws + (int64_t)slo * n * M : nullptr,
-                                 reinterpret_cast<int*>(blk + bl.infos) + 2 * slo, vars ? blk + bl.vars + (int64_t)slo * M : nullptr,
-                                 m_slice);
-        if (rc == 0) rc = gpx_synchronize(ctx);
-        *rc_slot = rc;
-        *cb_slot = ctx_cov_block(ctx);
-      });
-    }
+    // block r starts at offset 0 of its own buffer (the root's block is block 0 of the gather buffer)
+    spawn_shard_sweep(threads, D.ctxs, per_gpu, lo[(size_t)r], hi[(size_t)r] - lo[(size_t)r], jb, pl, D.payload.d(),
+                      D.out.d(), &rcs[(size_t)r * per_gpu], &cblock[(size_t)r * per_gpu]);
   }
   for (std::thread& t : threads) t.join();
   for (int r = 0; r < G; ++r)
@@ -337,15 +254,18 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
 
   // ---- 3. gather every block on the root GPU (one RCCL group), one download ---------------------------------------
   if (nd->use_rccl) {
+    ncclResult_t first = ncclSuccess;
     NODE_NCCL(nd, nd->rccl.GroupStart());
-    for (int r = 1; r < G; ++r) {
+    for (int r = 1; r < G && first == ncclSuccess; ++r) {
       const int64_t cnt = boff[(size_t)r + 1] - boff[(size_t)r];
       if (cnt <= 0) continue;
       NodeDev& D = nd->devs[(size_t)r];
-      NODE_NCCL(nd, nd->rccl.Recv(root.out.d() + boff[(size_t)r], (size_t)cnt, ncclDouble, r, nd->comms[0], root.cs));
-      NODE_NCCL(nd, nd->rccl.Send(D.out.p, (size_t)cnt, ncclDouble, 0, nd->comms[(size_t)r], D.cs));
+      first = nd->rccl.Recv(root.out.d() + boff[(size_t)r], (size_t)cnt, ncclDouble, r, nd->comms[0], root.cs);
+      if (first == ncclSuccess) first = nd->rccl.Send(D.out.p, (size_t)cnt, ncclDouble, 0, nd->comms[(size_t)r], D.cs);
     }
-    NODE_NCCL(nd, nd->rccl.GroupEnd());
+    const ncclResult_t ge = nd->rccl.GroupEnd();
+    if (first == ncclSuccess) first = ge;
+    if (first != ncclSuccess) return node_fail(nd, std::string("ncclSend/ncclRecv: ") + nd->rccl.GetErrorString(first));
     for (int r = 1; r < G; ++r) {
       NODE_HIP(nd, hipSetDevice(nd->devs[(size_t)r].device));
       NODE_HIP(nd, hipStreamSynchronize(nd->devs[(size_t)r].cs));
@@ -365,33 +285,10 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
   NODE_HIP(nd, hipMemcpyAsync(nd->pin_out.p, root.out.p, o_bytes, hipMemcpyDeviceToHost, root.cs));
   NODE_HIP(nd, hipStreamSynchronize(root.cs));
   const double* ho = nd->pin_out.d();
-  const int cM = cblock[0];
-  for (int r = 0; r < G; ++r) {
-    const int c_r = hi[(size_t)r] - lo[(size_t)r];
-    if (c_r <= 0) continue;
-    const BlockLayout bl(c_r, n, M);
-    const double* blk = ho + boff[(size_t)r];
-    const int g0 = lo[(size_t)r];
-    std::memcpy(means + (int64_t)g0 * M, blk + bl.means, (size_t)c_r * M * sizeof(double));
-    if (n > 0) std::memcpy(samples + (int64_t)g0 * n * M, blk + bl.draws, (size_t)c_r * n * M * sizeof(double));
-    if (vars) std::memcpy(vars + (int64_t)g0 * M, blk + bl.vars, (size_t)c_r * M * sizeof(double));
-    const int* hin = reinterpret_cast<const int*>(blk + bl.infos);
-    for (int s = 0; s < c_r; ++s) { // decode the pivots exactly as gpx_predict_sweep does
-      int it = hin[2 * s], ic = hin[2 * s + 1];
-      if (it > N) it = 0;
-      if (ic > cM) ic = 0;
-      const int code = it != 0 ? it : (ic != 0 ? -ic : 0);
-      const int gs = g0 + s;
-      if (infos) infos[gs] = code;
-      if (it != 0)
-        for (int a = 0; a < M; ++a) {
-          means[(int64_t)gs * M + a] = NAN;
-          if (vars) vars[(int64_t)gs * M + a] = NAN;
-        }
-      if (code != 0 && n > 0)
-        for (int64_t t = 0; t < (int64_t)n * M; ++t) samples[(int64_t)gs * n * M + t] = NAN;
-    }
-  }
+  for (int r = 0; r < G; ++r)
+    if (hi[(size_t)r] > lo[(size_t)r])
+      scatter_block(ho + boff[(size_t)r], hi[(size_t)r] - lo[(size_t)r], lo[(size_t)r], N, M, n, cblock[0], means, samples,
+                    infos, vars);
   nd->sweeps += 1;
   return 0;
 }

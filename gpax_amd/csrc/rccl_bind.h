@@ -1,0 +1,193 @@
+// rccl_bind.h — run-time binding of RCCL and the sharding helpers shared by the two multi-GPU launch models of the
+// predictive sweep: multi.hip (one process owns the node, gpx_node_*) and rank.hip (one process per GPU, gpx_rank_*).
+//
+// RCCL is bound with dlopen / dlsym (whichever librccl.so.1 the process already holds, else ROCm's), so libgpx has no
+// link-time and no HEADER dependency on it: the few types and enumerators used are restated here from the public
+// NCCL 2.x ABI (rccl.h: ncclComm_t opaque, ncclUniqueId = 128 opaque bytes passed BY VALUE to ncclCommInitRank,
+// ncclDouble = 8, ncclMax = 2, ncclSuccess = 0).  A ROCm install without the RCCL development package still builds
+// libgpx; a 1-GPU user never loads RCCL at all.
+#pragma once
+#include <dlfcn.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "common.h"
+
+namespace gpx {
+
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t; // ncclSuccess = 0
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclDouble = 8;
+constexpr ncclRedOp_t ncclMax = 2;
+struct ncclUniqueId {
+  char internal[GPX_UNIQUE_ID_BYTES];
+};
+
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+};
+
+inline bool load_rccl(RcclApi& r, std::string& err) {
+  if (r.handle) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (r.handle) break;
+  }
+  if (!r.handle) {
+    const char* de = dlerror();
+    err = std::string("cannot load RCCL (librccl.so.1): ") + (de ? de : "dlopen failed");
+    return false;
+  }
+#define GPX_SYM(field, name)                                            \
+  r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name)); \
+  if (!r.field) {                                                       \
+    err = std::string("RCCL symbol missing: ") + name;                  \
+    r.handle = nullptr;                                                 \
+    return false;                                                       \
+  }
+  GPX_SYM(CommInitAll, "ncclCommInitAll")
+  GPX_SYM(CommInitRank, "ncclCommInitRank")
+  GPX_SYM(GetUniqueId, "ncclGetUniqueId")
+  GPX_SYM(CommDestroy, "ncclCommDestroy")
+  GPX_SYM(GetErrorString, "ncclGetErrorString")
+  GPX_SYM(Broadcast, "ncclBroadcast")
+  GPX_SYM(AllReduce, "ncclAllReduce")
+  GPX_SYM(Send, "ncclSend")
+  GPX_SYM(Recv, "ncclRecv")
+  GPX_SYM(GroupStart, "ncclGroupStart")
+  GPX_SYM(GroupEnd, "ncclGroupEnd")
+  GPX_SYM(GetVersion, "ncclGetVersion")
+#undef GPX_SYM
+  return true;
+}
+
+// contiguous block [lo, hi) of part `r` out of `parts` over S items, sizes differing by at most 1
+inline void shard_range(int S, int r, int parts, int* lo, int* hi) {
+  const int base = S / parts, rem = S % parts;
+  *lo = r * base + (r < rem ? r : rem);
+  *hi = *lo + base + (r < rem ? 1 : 0);
+}
+
+// result block of c samples, in doubles: [means c*M | draws c*n*M | vars c*M | pivots: 2c ints in c doubles]
+struct BlockLayout {
+  int64_t means, draws, vars, infos, total;
+  BlockLayout(int c, int n, int M) {
+    means = 0;
+    draws = (int64_t)c * M;
+    vars = draws + (int64_t)c * n * M;
+    infos = vars + (int64_t)c * M;
+    total = infos + c;
+  }
+};
+
+// payload of one sharded sweep, in doubles: what the root hands to every GPU.  The node model keeps the theta table on
+// the host (same process); the rank model appends it (with_theta) because the other processes do not have it.
+struct PayloadLayout {
+  int64_t X, Xn, y, eps, ells, scales, noises, total;
+  PayloadLayout(int N, int d, int M, int yres_rows, int S, int n, int ne, bool with_theta) {
+    X = 0;
+    Xn = X + (int64_t)N * d;
+    y = Xn + (int64_t)M * d;
+    eps = y + (int64_t)yres_rows * N;
+    ells = eps + (int64_t)S * n * M;
+    scales = ells + (with_theta ? (int64_t)S * ne : 0);
+    noises = scales + (with_theta ? S : 0);
+    total = noises + (with_theta ? S : 0);
+  }
+};
+
+// Copy one gathered block (host image `blk` of c_r samples whose first global index is g0) into the caller's arrays,
+// decoding the pivots exactly as gpx_predict_sweep does: train-factor failure -> means / vars / draws NaN, covariance
+// failure -> draws NaN, infos = pivot (train) or -pivot (cov).
+inline void scatter_block(const double* blk, int c_r, int g0, int N, int M, int n, int cM, double* means, double* samples,
+                          int* infos, double* vars) {
+  const BlockLayout bl(c_r, n, M);
+  std::memcpy(means + (int64_t)g0 * M, blk + bl.means, (size_t)c_r * M * sizeof(double));
+  if (n > 0) std::memcpy(samples + (int64_t)g0 * n * M, blk + bl.draws, (size_t)c_r * n * M * sizeof(double));
+  if (vars) std::memcpy(vars + (int64_t)g0 * M, blk + bl.vars, (size_t)c_r * M * sizeof(double));
+  const int* hin = reinterpret_cast<const int*>(blk + bl.infos);
+  for (int s = 0; s < c_r; ++s) {
+    int it = hin[2 * s], ic = hin[2 * s + 1];
+    if (it > N) it = 0;
+    if (ic > cM) ic = 0;
+    const int code = it != 0 ? it : (ic != 0 ? -ic : 0);
+    const int gs = g0 + s;
+    if (infos) infos[gs] = code;
+    if (it != 0)
+      for (int a = 0; a < M; ++a) {
+        means[(int64_t)gs * M + a] = NAN;
+        if (vars) vars[(int64_t)gs * M + a] = NAN;
+      }
+    if (code != 0 && n > 0)
+      for (int64_t t = 0; t < (int64_t)n * M; ++t) samples[(int64_t)gs * n * M + t] = NAN;
+  }
+}
+
+} // namespace gpx
+
+#include <thread>
+#include <vector>
+
+namespace gpx {
+
+// What every GPU of a sharded sweep is told: sizes, flags and where the broadcast payload sits on ITS device.
+struct ShardJob {
+  int kind, N, d, M, n, yres_rows, noiseless, m_slice, ne;
+  double jitter;
+  bool want_vars;
+  const double *ells, *scales, *noises; // HOST theta tables of all S samples (indexed by global sample)
+};
+
+// The block of c_r samples starting at global sample g_lo on ONE GPU: split again over (up to) per_gpu of the contexts
+// in flight there, one host thread each (ctypes / the caller holds no lock; every context has its own streams).
+// `payload` / `blk`: the device copies of the inputs and of this GPU's result block.  rc / cov-block slots: per_gpu each.
+inline void spawn_shard_sweep(std::vector<std::thread>& threads, const std::vector<gpx_ctx*>& ctxs, int per_gpu, int g_lo,
+                              int c_r, const ShardJob& jb, const PayloadLayout& pl, const double* payload, double* blk,
+                              int* rc_slots, int* cb_slots) {
+  if (c_r <= 0) return;
+  const BlockLayout bl(c_r, jb.n, jb.M);
+  const int parts = per_gpu < c_r ? per_gpu : c_r;
+  for (int c = 0; c < parts; ++c) {
+    int slo, shi;
+    shard_range(c_r, c, parts, &slo, &shi);
+    gpx_ctx* ctx = ctxs[(size_t)c];
+    const int g0 = g_lo + slo; // first global sample of this context
+    const int cnt = shi - slo;
+    int* rc_slot = rc_slots + c;
+    int* cb_slot = cb_slots + c;
+    const ShardJob j = jb;
+    const PayloadLayout p = pl;
+    threads.emplace_back([=]() {
+      int rc = sweep_device_io(
+          ctx, j.kind, cnt, j.ells + (int64_t)g0 * j.ne, j.scales + g0, j.noises + g0, payload + p.X, j.N, j.d,
+          payload + p.y + (j.yres_rows == 1 ? 0 : (int64_t)g0 * j.N), j.yres_rows == 1 ? 1 : cnt, payload + p.Xn, j.M,
+          j.noiseless, j.jitter, j.n > 0 ? payload + p.eps + (int64_t)g0 * j.n * j.M : nullptr, j.n,
+          blk + bl.means + (int64_t)slo * j.M, j.n > 0 ? blk + bl.draws + (int64_t)slo * j.n * j.M : nullptr,
+          reinterpret_cast<int*>(blk + bl.infos) + 2 * slo, j.want_vars ? blk + bl.vars + (int64_t)slo * j.M : nullptr,
+          j.m_slice);
+      if (rc == 0) rc = gpx_synchronize(ctx);
+      *rc_slot = rc;
+      *cb_slot = ctx_cov_block(ctx);
+    });
+  }
+}
+
+} // namespace gpx

@@ -201,6 +201,41 @@ int gpx_predict_sweep_multi(gpx_node* node, int kind, const double* X, int N, in
                             const double* Xnew, int M, int noiseless, double jitter, const double* eps, int n,
                             double* means, double* samples, int* infos, double* vars, int m_slice);
 
+/* ---- the same sharded sweep with ONE PROCESS PER GPU (the launch model of torch.distributed.run / mpirun: RANK,
+ * LOCAL_RANK, WORLD_SIZE), without PyTorch.  Every process owns one GPU (`inflight` contexts on it) and one rank of an
+ * RCCL communicator (ncclCommInitRank; RCCL bound with dlopen).  Rank 0 creates the 128-byte unique id
+ * (gpx_rank_unique_id) and the launcher's rendezvous hands it to the other ranks (gpax_amd/launch.py).
+ * gpx_rank_predict_sweep is COLLECTIVE: every rank calls it with the same scalar arguments; the arrays are read
+ * (X, ells, scales, noises, yres, Xnew, eps) and written (means, samples, infos, vars) on rank 0 only, other ranks
+ * may pass NULL.  Data path: rank 0 H2D of [X | X_new | y_res | eps | theta table] -> ncclBroadcast -> every rank
+ * sweeps its contiguous block of the S samples -> ncclSend / ncclRecv of the result blocks to rank 0 -> D2H.
+ * Results equal gpx_predict_sweep's sample by sample.  Replaces the vmap of gpax/models/gp.py:392-395 when the
+ * caller is launched one process per GPU (chain_method / device placement of the reference: gp.py:173-174,201-203).
+ * file_dir != NULL / "": the "file" transport (a directory all ranks share) instead of RCCL — several ranks on one
+ * GPU in the tests (RCCL refuses duplicate devices), and bench.py's fallback when RCCL cannot initialise; unique_id
+ * is ignored then.
+ * gpx_rank_barrier: waits for this rank's own contexts, then for every rank.  gpx_rank_allreduce_max: v[0..n) <-
+ * elementwise max over ranks (n <= 64; max-over-ranks timing).  gpx_rank_bcast: count doubles from rank 0's host
+ * buffer to every rank's.  All three are collective. */
+#define GPX_UNIQUE_ID_BYTES 128
+typedef struct gpx_rank gpx_rank;
+int gpx_rank_unique_id(char* id /* GPX_UNIQUE_ID_BYTES */, char* errbuf, int errlen);
+int gpx_rank_init(int device, int rank, int nranks, const char* unique_id, const char* file_dir, int inflight,
+                  gpx_rank** out);
+void gpx_rank_destroy(gpx_rank* rk);
+const char* gpx_rank_last_error(const gpx_rank* rk);
+int gpx_rank_info(const gpx_rank* rk, int* rank, int* nranks, int* inflight, int* transport_rccl, int* rccl_version);
+int gpx_rank_barrier(gpx_rank* rk);
+int gpx_rank_allreduce_max(gpx_rank* rk, double* v, int n);
+int gpx_rank_bcast(gpx_rank* rk, double* buf, int64_t count);
+int gpx_rank_predict_sweep(gpx_rank* rk, int kind, const double* X, int N, int d, int S, const double* ells,
+                           const double* scales, const double* noises, const double* yres, int yres_rows,
+                           const double* Xnew, int M, int noiseless, double jitter, const double* eps, int n,
+                           double* means, double* samples, int* infos, double* vars, int want_vars, int m_slice);
+/* Host only (no device call): the contiguous block [lo, hi) of part `part` out of `parts` over S samples that both
+ * sharded sweeps use (sizes differ by at most one). */
+int gpx_shard_range(int S, int part, int parts, int* lo, int* hi);
+
 /* Sweep statistics since gpx_init: batches launched, samples processed, and the batch size B
  * chosen by the most recent sweep. */
 int gpx_sweep_stats(gpx_ctx* ctx, int64_t* batches, int64_t* samples, int* last_batch);

@@ -1,5 +1,6 @@
-"""bench.py --gpus N: started without a launcher it must run N ranks itself.
-CPU: the re-exec command line.  GPU: 2 ranks sharing the one GPU of the test box report n_gpus = 2."""
+"""bench.py --gpus N: started without a launcher it runs N ranks itself — one process per GPU, no PyTorch.
+CPU: what it would launch.  GPU: 2 ranks sharing the one GPU of the test box (file transport) go through the same
+collective code path as the RCCL run and report n_gpus = 2 with the C4 record."""
 import json
 import os
 import subprocess
@@ -11,35 +12,51 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _env():
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    return env
+    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GPX_RDZV_DIR")}
 
 
-def test_gpus_n_without_a_launcher_reexecutes_under_torch_distributed_run():
+def test_gpus_n_without_a_launcher_spawns_one_process_per_gpu_without_torch():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "1",
                           "--dry-launch"], capture_output=True, text=True, env=_env(), check=True)
-    cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
-    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
-    assert "--nproc-per-node=8" in cmd and "--dry-launch" not in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    i = cmd.index(os.path.join(ROOT, "bench.py"))
-    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "6", "--warmup", "1"]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert rec["nranks"] == 8 and "torch" not in json.dumps(rec["argv"])
+    assert rec["argv"][1] == os.path.join(ROOT, "bench.py")
+    assert rec["argv"][2:] == ["--gpus", "8", "--steps", "6", "--warmup", "1"]
+    assert rec["env_per_rank"]["WORLD_SIZE"] == "8" and rec["env_per_rank"]["MASTER_ADDR"] == "127.0.0.1"
+
+
+def test_bench_does_not_import_torch():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "import torch" not in src and "torch.distributed.run`" in src  # named as a launcher only
 
 
 def test_gpus_1_does_not_relaunch():
-    # with --gpus 1 and no launcher, bench.py goes straight to the engine (which needs the GPU): no subprocess
-    import bench
-    a = type("A", (), {"gpus": 1})()
-    assert bench.self_launch_command(a, ["--gpus", "1"])[4] == "--nproc-per-node=1"  # helper itself is N-agnostic
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-launch"],
+                         capture_output=True, text=True, env=_env(), check=True)
+    assert json.loads(out.stdout.strip().splitlines()[-1]) == {"launch": None}
 
 
 @pytest.mark.gpu
 def test_two_ranks_sharing_the_gpu_report_n_gpus_2():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend",
-                          "gloo", "--N", "2048", "--M", "256", "--steps", "4", "--warmup", "1", "--inflight", "1",
-                          "--no-cpu-baseline"], capture_output=True, text=True, env=_env(), timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--N", "2048",
+                          "--M", "256", "--steps", "4", "--warmup", "1", "--inflight", "1", "--c4-S", "12", "--c4-N",
+                          "1024"], capture_output=True, text=True, env=_env(), timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
-    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["value"] > 0
+    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["value"] > 0 and rec["nan_rows"] == 0
+    assert rec["multi_gpu_path"] == "rank-file" and rec["rccl_ranks"] == 0
     assert rec["roofline"]["frac"] > 0
+    c4 = rec["c4_sweep"]
+    assert c4["S"] == 12 and c4["identical_to_one_gpu"] and c4["speedup_vs_1"] > 0 and c4["ranks"] == 2
+
+
+@pytest.mark.gpu
+def test_one_rank_under_a_launcher_is_the_single_gpu_headline():
+    env = dict(_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--N", "2048", "--M", "256",
+                          "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["multi_gpu_path"] is None and rec["stages_frac_of_fp64_peak"]["potrf"] > 0

@@ -1,0 +1,189 @@
+"""CPU: the torch-free one-process-per-GPU plumbing (gpax_amd/launch.py) with world sizes 2 and 3 — the rendezvous
+store, the unique-id hand-over, the all-ranks agreement on the transport (RCCL fails on one rank => every rank falls
+back to the file transport together), the sharding rule of the library (gpx_shard_range, host only) and the
+spawn launcher.  The communicator itself needs a GPU: tests/test_gpu_rank.py."""
+import json
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeRank:
+    """Stands in for _lib.Rank: records how it was built."""
+
+    def __init__(self, dev, rank, world, uid, fdir, infl):
+        self.args = dict(device=dev, rank=rank, world=world, uid=uid, file_dir=fdir, inflight=infl)
+        self.closed = False
+
+    def close(self):
+        self.closed = True
+
+    def barrier(self):
+        pass
+
+
+def _worker(rank, world, rdzv, mode, q):
+    sys.path.insert(0, ROOT)
+    from gpax_amd import launch
+    env = launch.RankEnv(rank, world, rank, rdzv)
+
+    def make_uid():
+        if mode == "uid_fails":
+            raise RuntimeError("no librccl")
+        return bytes([7]) * 128
+
+    def make_rank(dev, r, w, uid, fdir, infl):
+        if mode == "rank1_fails" and r == 1 and fdir is None:
+            raise RuntimeError("ncclCommInitRank: unhandled system error")
+        return FakeRank(dev, r, w, uid, fdir, infl)
+
+    try:
+        rk = launch.init_rank(env, inflight=2, transport="rccl" if mode == "rccl_only" else "auto", timeout=30.0,
+                              make_rank=make_rank, make_uid=make_uid)
+        q.put((rank, "ok", rk.args))
+    except Exception as ex:
+        q.put((rank, "error", str(ex)))
+
+
+def _run(world, mode, tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, str(tmp_path / "rdzv"), mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+    return sorted(out)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_every_rank_gets_rank_0s_unique_id(world, tmp_path):
+    out = _run(world, "fine", tmp_path)
+    assert [o[1] for o in out] == ["ok"] * world
+    for r, _, args in out:
+        assert args["uid"] == bytes([7]) * 128 and args["file_dir"] is None
+        assert args["rank"] == r and args["world"] == world and args["device"] == r and args["inflight"] == 2
+
+
+@pytest.mark.parametrize("mode", ["rank1_fails", "uid_fails"])
+def test_a_failure_on_one_rank_moves_all_ranks_to_the_file_transport(mode, tmp_path):
+    out = _run(3, mode, tmp_path)
+    assert [o[1] for o in out] == ["ok"] * 3
+    dirs = {o[2]["file_dir"] for o in out}
+    assert len(dirs) == 1 and None not in dirs and os.path.isdir(dirs.pop())
+    assert all(o[2]["uid"] is None for o in out)
+
+
+def test_transport_rccl_does_not_fall_back(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    # rccl demanded, rank 1 fails: every rank raises instead of changing transport
+    procs = [ctx.Process(target=_worker_rccl_only, args=(r, 2, str(tmp_path / "rdzv"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(30)
+    assert [o[1] for o in out] == ["error", "error"] and "rank 1" in out[0][2]
+
+
+def _worker_rccl_only(rank, world, rdzv, q):
+    sys.path.insert(0, ROOT)
+    from gpax_amd import launch
+    env = launch.RankEnv(rank, world, rank, rdzv)
+
+    def make_rank(dev, r, w, uid, fdir, infl):
+        if r == 1:
+            raise RuntimeError("boom")
+        return FakeRank(dev, r, w, uid, fdir, infl)
+
+    try:
+        launch.init_rank(env, transport="rccl", timeout=30.0, make_rank=make_rank, make_uid=lambda: b"x" * 128)
+        q.put((rank, "ok", ""))
+    except Exception as ex:
+        q.put((rank, "error", str(ex)))
+
+
+def test_file_store_ignores_leftovers_of_an_earlier_launch(tmp_path):
+    from gpax_amd.launch import FileStore
+    old = FileStore(str(tmp_path))
+    old.set("uid", b"stale")
+    past = time.time() - 3600
+    os.utime(tmp_path / "uid", (past, past))
+    st = FileStore(str(tmp_path), fresh_after=time.time() - 300)
+    with pytest.raises(TimeoutError):
+        st.get("uid", timeout=0.2)
+    st.set("uid", b"fresh")
+    assert st.get("uid", timeout=1.0) == b"fresh"
+
+
+def test_rank_env_reads_the_launcher_variables():
+    from gpax_amd.launch import rank_env
+    assert rank_env({}) is None
+    e = rank_env({"RANK": "3", "WORLD_SIZE": "8", "LOCAL_RANK": "3", "MASTER_PORT": "29511"})
+    assert (e.rank, e.world, e.local_rank) == (3, 8, 3) and e.owns_dir and e.rdzv_dir.endswith(f"_{os.getppid()}_29511")
+    e = rank_env({"RANK": "1", "WORLD_SIZE": "2", "GPX_RDZV_DIR": "/x/y", "GPX_RDZV_ATTEMPT": "1"})
+    assert e.rdzv_dir == "/x/y" and not e.owns_dir and e.attempt == 1 and e.local_rank == 1
+
+
+def test_the_librarys_sharding_rule():
+    """gpx_shard_range is host-only code of libgpx: contiguous blocks, sizes differing by at most one, every sample once."""
+    from gpax_amd import _lib
+    for S in (0, 1, 7, 8, 1000):
+        for parts in (1, 2, 3, 8):
+            blocks = [_lib.shard_range(S, r, parts) for r in range(parts)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == S
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(parts - 1))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_spawn_ranks_sets_the_rank_environment_and_reports_failures(tmp_path):
+    from gpax_amd import launch
+    script = tmp_path / "probe.py"
+    script.write_text(
+        "import os, sys, json\n"
+        "r = os.environ['RANK']\n"
+        "open(os.path.join(sys.argv[1], 'r' + r), 'w').write(json.dumps({k: os.environ[k] for k in "
+        "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'GPX_RDZV_DIR', 'MASTER_ADDR')}))\n"
+        "sys.exit(3 if (len(sys.argv) > 2 and r == '1') else 0)\n")
+    assert launch.spawn_ranks(str(script), [str(tmp_path)], 3) == 0
+    recs = [json.loads((tmp_path / f"r{r}").read_text()) for r in range(3)]
+    assert [x["RANK"] for x in recs] == ["0", "1", "2"] and {x["WORLD_SIZE"] for x in recs} == {"3"}
+    assert len({x["GPX_RDZV_DIR"] for x in recs}) == 1 and recs[0]["MASTER_ADDR"] == "127.0.0.1"
+    assert not os.path.exists(recs[0]["GPX_RDZV_DIR"])  # the launcher removes its rendezvous directory
+    assert launch.spawn_ranks(str(script), [str(tmp_path), "fail"], 2) == 3
+
+
+def test_a_hung_initialisation_reexecutes_the_rank_with_the_file_transport(tmp_path):
+    """A peer that dies inside ncclCommInitRank leaves the others blocked in a C call nothing can interrupt: the
+    watchdog replaces the process (same PID, so the launcher keeps watching it) by a copy that skips RCCL."""
+    from gpax_amd import launch
+    script = tmp_path / "hang.py"
+    script.write_text(
+        "import os, sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from gpax_amd import launch\n"
+        "env = launch.rank_env()\n"
+        "class R:\n"
+        "    def __init__(self, fdir): self.fdir = fdir\n"
+        "    def close(self): pass\n"
+        "def make_rank(dev, r, w, uid, fdir, infl):\n"
+        "    if fdir is None:\n"
+        "        time.sleep(3600)  # 'ncclCommInitRank' never returns\n"
+        "    return R(fdir)\n"
+        "rk = launch.init_rank(env, timeout=1.5, reexec_on_hang=True, make_rank=make_rank, make_uid=lambda: b'u' * 128)\n"
+        "open(os.path.join(sys.argv[1], 'done%d' % env.rank), 'w').write('%s %d %s' % (os.environ.get('GPX_RANK_TRANSPORT'), "
+        "env.attempt, rk.fdir))\n")
+    assert launch.spawn_ranks(str(script), [str(tmp_path)], 2, timeout=120) == 0
+    for r in range(2):
+        transport, attempt, fdir = (tmp_path / f"done{r}").read_text().split()
+        assert transport == "file" and attempt == "1" and fdir.endswith(os.path.join("attempt1", "xfer"))

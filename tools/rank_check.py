@@ -1,0 +1,72 @@
+"""One process per GPU, torch-free: run under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE
+(`python -m torch.distributed.run --nproc-per-node N tools/rank_check.py`, or gpax_amd.launch.spawn_ranks as
+tests/test_gpu_rank.py does).  Every rank joins the library's communicator (gpx_rank_*), rank 0 runs the collective
+predictive sweep against the plain single-GPU sweep on its own device and requires bit-identical results.
+  --share-gpu   every rank on GPU 0 over the file transport (a 1-GPU box; RCCL refuses duplicate devices)
+Cases: blocks of unequal size, an empty block (S < ranks), per-sample residuals, predict_in_batches blocks, a non-PD
+theta, variances only (n = 0)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from bench_inputs import synthetic_problem, synthetic_theta_samples  # noqa: E402
+from gpax_amd import _lib, launch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--share-gpu", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2)
+    a = ap.parse_args()
+    env = launch.rank_env()
+    assert env is not None, "start me under a launcher (RANK / WORLD_SIZE)"
+    rk = launch.init_rank(env, device=0 if a.share_gpu else env.local_rank, inflight=a.inflight,
+                          transport="file" if a.share_gpu else None, timeout=120.0)
+    root = env.rank == 0
+    info = rk.info()
+    assert info["nranks"] == env.world and info["rank"] == env.rank
+    assert np.array_equal(rk.allreduce_max([float(env.rank), -float(env.rank)]), [env.world - 1.0, 0.0])
+    b = rk.bcast(np.arange(5.0) if root else np.zeros(5))
+    assert np.array_equal(b, np.arange(5.0))
+    eng = _lib.Engine(0 if a.share_gpu else env.local_rank) if root else None
+    cases = [  # N, d, M, S, n, kind, per-sample yres, m_slice, want_var, bad theta
+        (300, 3, 70, 4 * env.world + 1, 1, 0, True, 32, False, True),
+        (3100, 2, 130, 2 * env.world + 1, 2, 1, False, 0, True, False),
+        (300, 2, 40, max(1, env.world - 1), 1, 1, False, 0, False, False),  # an empty block on the last rank
+        (500, 2, 64, 3 * env.world, 0, 1, False, 0, True, False),           # variances only
+    ]
+    for ci, (N, d, M, S, n, kind, per_y, m_slice, want_var, bad) in enumerate(cases):
+        kw = {}
+        if root:
+            X, y, Xn, _ = synthetic_problem(N, d, M, seed=5 + ci)
+            th = synthetic_theta_samples(S, d, seed=6 + ci)
+            if bad:
+                th["k_scale"][S // 2] = -1.0  # not positive definite: NaN rows + info, never an abort
+            eps = np.random.default_rng(7 + ci).standard_normal((S, n, M)) if n else None
+            yres = np.stack([y + 0.01 * k for k in range(S)]) if per_y else y
+            kw = dict(X=X, ells=th["k_length"], scales=th["k_scale"], noises=th["noise"], yres=yres, Xnew=Xn, eps=eps)
+        got = rk.predict_sweep(kind, N, d, S, M, n, False, 1e-6, yres_rows=S if per_y else 1, want_var=want_var,
+                               m_slice=m_slice, **kw)
+        if root:
+            eng.set_train(X)
+            want = eng.predict_sweep(kind, th["k_length"], th["k_scale"], th["noise"], yres, Xn, False, 1e-6, eps,
+                                     want_var=want_var, m_slice=m_slice)
+            for g, w in zip(got, want):
+                np.testing.assert_array_equal(g, w)
+            if bad:
+                assert want[2][S // 2] != 0 and np.isnan(got[0][S // 2]).all()
+        else:
+            assert got is None
+    rk.barrier()
+    if root:
+        print(f"rank_check ok: {env.world} ranks, transport {info['transport']}, rccl {info['rccl_version']}, "
+              f"{len(cases)} cases bit-identical to the single-GPU sweep", flush=True)
+    launch.finalize(env, rk)
+
+
+if __name__ == "__main__":
+    main()

@@ -41,7 +41,7 @@ def main():
             import json
             import os
             d = json.load(open(sys.argv[3])) if os.path.exists(sys.argv[3]) else {}
-            d[cname] = {"dispatches": n, "avg_per_launch": avg, "sum": tot}
+            d[cname] = {"dispatches": n, "avg_per_launch": avg, "sum": tot, "avg_duration_us": dur / 1e3}
             json.dump(d, open(sys.argv[3], "w"), indent=1)
     text = "\n".join(lines) + "\n"
     if len(sys.argv) > 2:
