@@ -84,8 +84,16 @@ def Thompson(rng_key, model, X, n: int = 1, noiseless: bool = False, **kwargs) -
         if n > 1:
             tsample = tsample.mean(1).squeeze()
         return tsample
-    # VI models: the reference only defines this branch for viDKL (sample_from_posterior); here the
-    # draw comes from the MVN posterior at the point estimate
-    mean, cov = model.get_mvn_posterior(X, model.get_samples(), noiseless, **kwargs)
-    L = np.linalg.cholesky(cov + 1e-12 * np.eye(len(mean)))
-    return (mean + L @ rng.standard_normal(len(mean)))[None]
+    # VI models: the reference only defines this branch for viDKL (sample_from_posterior); here the draw comes from
+    # the MVN posterior at the point estimate, factored on the device: the exact models go through
+    # ExactGP._predict (gpx_posterior + gpx_mvn_draw: chol(cov) and mean + L eps, gp.py:279-293); a model with its own
+    # posterior (viSparseGP: Woodbury) hands its covariance to the device Cholesky (gpx_potrf)
+    from ..models.gp import ExactGP
+    params = model.get_samples()
+    if type(model).get_mvn_posterior is ExactGP.get_mvn_posterior:
+        _, draws = ExactGP._predict(model, rng, X, params, 1, noiseless, **kwargs)
+        return draws
+    mean, cov = model.get_mvn_posterior(X, params, noiseless, **kwargs)
+    eps = rng.standard_normal(len(mean))
+    L, info = model._engine().potrf(cov + 1e-12 * np.eye(len(mean)))
+    return (mean + L @ eps)[None] if info == 0 else np.full((1, len(mean)), np.nan)

@@ -739,6 +739,8 @@ void gpx_destroy(gpx_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->evP) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->evU) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->tile_counter_ev)
+      if (e) (void)hipEventDestroy(e);
     if (ctx->evR0) (void)hipEventDestroy(ctx->evR0);
     if (ctx->evR1) (void)hipEventDestroy(ctx->evR1);
     if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);

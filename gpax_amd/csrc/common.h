@@ -175,6 +175,8 @@ struct gpx_ctx {
   bool persist_scope_ok = true;
   gpx::DevBuf tile_counters;
   unsigned tile_counter_seq = 0;
+  std::vector<hipEvent_t> tile_counter_ev;      // per ring slot: recorded behind the last kernel that used it ...
+  std::vector<hipStream_t> tile_counter_stream; // ... and the stream it ran on
   int grid_pad8 = 0; // GPX_GRID_PAD8: grid.x of the big-tile GEMM padded to a multiple of 8, so that XCD x (workgroup id % 8) sees tile columns x, x + 8, ... in every tile row
   int tile_swizzle_min = 1024; // GPX_TILE_SWIZZLE_MIN: tiles a launch must have for the XCD-aware order
   int tile_swizzle = 0; // GPX_TILE_SWIZZLE: XCD-aware tile order of the big-tile GEMM (8x8-tile chunks per XCD), 0 = grid order

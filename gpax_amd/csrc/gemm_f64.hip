@@ -669,7 +669,16 @@ static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
     if (tm.total <= 0) return 0;
     // one counter per launch out of a ring: zeroed in stream order right before the launch that uses it
     if (ctx->tile_counters.ensure(GPX_TILE_COUNTERS * sizeof(int)) != hipSuccess) return bad_arg(ctx, "tile counters");
-    int* counter = ctx->tile_counters.i() + (ctx->tile_counter_seq++ % GPX_TILE_COUNTERS);
+    // A slot comes round again after GPX_TILE_COUNTERS launches — possibly on ANOTHER stream of this context, where
+    // stream order says nothing about the previous user: wait for the event that user recorded behind its kernel.
+    const unsigned slot = ctx->tile_counter_seq++ % GPX_TILE_COUNTERS;
+    if (ctx->tile_counter_ev.empty()) {
+      ctx->tile_counter_ev.assign(GPX_TILE_COUNTERS, nullptr);
+      ctx->tile_counter_stream.assign(GPX_TILE_COUNTERS, nullptr);
+    }
+    if (ctx->tile_counter_ev[slot] != nullptr && ctx->tile_counter_stream[slot] != ctx->s)
+      GPX_HIP(ctx, hipStreamWaitEvent(ctx->s, ctx->tile_counter_ev[slot], 0));
+    int* counter = ctx->tile_counters.i() + slot;
     GPX_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->s));
     // persist_slack: workgroup slots deliberately left empty (GPX_PERSIST_SLACK) so that a chain kernel that cannot share
     // a SIMD with two big-tile waves (potf2: 238 VGPRs) finds a CU with a single resident workgroup at once
@@ -678,6 +687,10 @@ static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
     const int grid = (tm.total < slots && !ctx->soft_reserve) ? tm.total : slots;
     gemm_nt128_persist_kernel<TAG, EPI><<<grid, 256, lds + 16, ctx->s>>>(g, tm, counter, ctx->soft_reserve ? 1 : 0);
     GPX_HIP(ctx, hipGetLastError());
+    if (ctx->tile_counter_ev[slot] == nullptr)
+      GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->tile_counter_ev[slot], hipEventDisableTiming));
+    GPX_HIP(ctx, hipEventRecord(ctx->tile_counter_ev[slot], ctx->s));
+    ctx->tile_counter_stream[slot] = ctx->s;
     return 0;
   }
   SwzMap sm;

@@ -585,6 +585,7 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS_BYTES));
     ctx->func_attr_mask |= ATTR_POTF2_COLUMN;
   }
+  if (!use_tile && dPre != nullptr) return bad_arg(ctx, "the column-by-column potf2 kernel has no pre-update");
   // Few workgroups (the single-theta pipeline, small batches): run on the reserved CUs through `rstream`, fenced
   // by events into the stream the chain lives on, so the block factorisation has a CU to itself.
   hipStream_t chain = ctx->s;
@@ -601,8 +602,6 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
       potf2_tile_kernel<true><<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs, dPre, Kpre);
     else if (use_tile)
       potf2_tile_kernel<false><<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs, dPre, Kpre);
-    else if (dPre != nullptr)
-      return bad_arg(ctx, "the column-by-column potf2 kernel has no pre-update");
     else
       potf2_inv_kernel<<<nb, 256, POTF2_LDS_BYTES, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
   }

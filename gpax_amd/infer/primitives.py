@@ -46,7 +46,20 @@ class _Tracer:
     def __init__(self):
         self.sites: List[Tuple[str, Tuple[int, ...], _dist.Distribution]] = []
         self.deterministic: Dict[str, float] = {}
-        self.plates: List[int] = []
+        self.plates: List[Tuple[int, int]] = []  # (size, dim) of the active plates, dim < 0 as NumPyro counts them
+
+
+def _plate_shape(plates) -> Tuple[int, ...]:
+    """Batch shape of a site under the active plates, by NumPyro's rule: a plate occupies the batch dimension `dim`
+    it names (negative, from the right) or else the first free one counting -1, -2, ... in the order the plates
+    were entered — so of two nested plates without `dim` the OUTER one is the last axis."""
+    taken = {}
+    for size, dim in plates:
+        taken[dim] = size
+    if not taken:
+        return ()
+    nd = -min(taken)
+    return tuple(taken.get(-nd + i, 1) for i in range(nd))
 
 
 def sample(name: str, fn, obs=None, **kwargs):
@@ -61,7 +74,7 @@ def sample(name: str, fn, obs=None, **kwargs):
     tr = _STACK[-1]
     if any(s[0] == name for s in tr.sites):
         raise ValueError(f"site {name!r} sampled twice")
-    shape = tuple(tr.plates)
+    shape = _plate_shape(tr.plates)
     tr.sites.append((name, shape, fn))
     med = np.full(shape, float(fn.median())) if shape else float(fn.median())
     return SiteValue(med, name)
@@ -75,14 +88,28 @@ def deterministic(name: str, value):
 
 
 class plate:
-    """numpyro.plate(name, size): sites sampled inside get a leading dimension of `size` (gp.py:238-239 'ard')."""
+    """numpyro.plate(name, size, dim=None): sites sampled inside get a batch dimension of `size` (gp.py:238-239
+    'ard'; nested with explicit dims in vgp.py:104-105: dim=-2 tasks, dim=-1 lengthscales)."""
 
-    def __init__(self, name: str, size: int, **kwargs):
-        self.name, self.size = name, int(size)
+    def __init__(self, name: str, size: int, subsample_size=None, dim=None):
+        if subsample_size is not None:
+            raise NotImplementedError("plate(subsample_size=...) has no MI355X path")
+        if dim is not None and int(dim) >= 0:
+            raise ValueError("plate dim must be negative (counted from the right), as in NumPyro")
+        self.name, self.size, self.dim = name, int(size), (None if dim is None else int(dim))
 
     def __enter__(self):
         if _STACK:
-            _STACK[-1].plates.append(self.size)
+            active = _STACK[-1].plates
+            used = {d for _, d in active}
+            dim = self.dim
+            if dim is None:
+                dim = -1
+                while dim in used:
+                    dim -= 1
+            elif dim in used:
+                raise ValueError(f"plate {self.name!r}: batch dimension {dim} is already taken by an enclosing plate")
+            active.append((self.size, dim))
         return self
 
     def __exit__(self, *exc):

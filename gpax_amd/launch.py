@@ -44,7 +44,7 @@ def rank_env(environ=None) -> Optional[RankEnv]:
     rank, world = int(e["RANK"]), int(e["WORLD_SIZE"])
     local = int(e.get("LOCAL_RANK", rank))
     d = e.get("GPX_RDZV_DIR")
-    owns = False
+    owns = e.get("GPX_RDZV_OWNS") == "1"
     if not d:
         # all ranks of one launch share their parent (the launcher's agent process) and its rendezvous port
         d = os.path.join(tempfile.gettempdir(), f"gpx_rdzv_{os.getppid()}_{e.get('MASTER_PORT', '0')}")
@@ -95,6 +95,8 @@ def _reexec_with_file_transport(env: RankEnv, why: str):
     os.environ["GPX_RANK_TRANSPORT"] = "file"
     os.environ["GPX_RDZV_ATTEMPT"] = str(env.attempt + 1)
     os.environ["GPX_RDZV_DIR"] = env.rdzv_dir
+    if env.owns_dir:
+        os.environ["GPX_RDZV_OWNS"] = "1"
     os.execv(sys.executable, [sys.executable] + sys.argv)
 
 
@@ -170,6 +172,31 @@ def init_rank(env: RankEnv, device: Optional[int] = None, inflight: Optional[int
         return rk
     finally:
         done.set()
+
+
+_default_rank = None
+_default_env: Optional[RankEnv] = None
+
+
+def default_rank():
+    """Process-wide `_lib.Rank` of this launch, created on first use from the launcher's environment (collective: every
+    rank of the launch must reach its first use).  A process started without a launcher is a world of one."""
+    global _default_rank, _default_env
+    if _default_rank is None:
+        env = rank_env()
+        if env is None:
+            env = RankEnv(0, 1, int(os.environ.get("GPX_DEVICE", "0")), tempfile.mkdtemp(prefix="gpx_rdzv_"), 0, True)
+        _default_env = env
+        _default_rank = init_rank(env)
+    return _default_rank
+
+
+def shutdown() -> None:
+    """Collective end of the process-wide rank (barrier, close, rendezvous directory removed)."""
+    global _default_rank, _default_env
+    if _default_rank is not None:
+        finalize(_default_env, _default_rank)
+        _default_rank = _default_env = None
 
 
 def finalize(env: RankEnv, rk=None) -> None:

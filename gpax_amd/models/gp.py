@@ -254,27 +254,46 @@ class ExactGP:
         return np.asarray(self.mean_fn(*args), dtype=np.float64).squeeze()
 
     def _dmean(self, X, theta, name) -> np.ndarray:
-        """d mean_fn(X, theta) / d theta[name] (N,): the user's mean_fn_grad, else complex-step differentiation
-        (f(x + ih).imag / h, h = 1e-30: no subtractive cancellation, exact to rounding for analytic NumPy
-        expressions), else central differences."""
+        """Jacobian d mean_fn(X, theta) / d theta[name], one row per element of the site (size, N): the user's
+        mean_fn_grad, else complex-step differentiation (f(x + ih).imag / h, h = 1e-30: no subtractive cancellation,
+        exact to rounding for analytic NumPy expressions), else central differences — element by element, so a
+        vector-valued site (a plate inside mean_fn_prior) gets its full Jacobian.  N here is the flattened size of
+        mean_fn's output ((T, N) -> T N for the task-batched models)."""
+        base = np.asarray(theta[name], dtype=np.float64)
+        size = max(1, base.size)
         if self.mean_fn_grad is not None:
-            return np.asarray(self.mean_fn_grad(X, theta)[name], dtype=np.float64).reshape(-1)
-        x0 = float(np.asarray(theta[name]).reshape(-1)[0])
-        try:
-            tc = dict(theta)
-            tc[name] = complex(x0, 1e-30)
-            with np.errstate(all="ignore"):
-                out = np.asarray(self.mean_fn(X.astype(np.complex128), tc))
-            if np.iscomplexobj(out):
-                dm = out.imag.squeeze() / 1e-30
-                if dm.shape == (X.shape[0],) and np.all(np.isfinite(dm)):
-                    return dm
-        except Exception:
-            pass
-        h = 1e-6 * max(1.0, abs(x0))
-        tp, tm = dict(theta), dict(theta)
-        tp[name], tm[name] = x0 + h, x0 - h
-        return (self._mean(X, tp) - self._mean(X, tm)) / (2 * h)
+            return np.asarray(self.mean_fn_grad(X, theta)[name], dtype=np.float64).reshape(size, -1)
+
+        def with_element(i, value, dtype):
+            if base.ndim == 0:
+                return value
+            arr = base.astype(dtype)
+            arr.reshape(-1)[i] = value
+            return arr
+
+        mshape = np.shape(self._mean(X, theta))  # (N,), or (T, N) for the task-batched models
+        J = np.empty((size, int(np.prod(mshape))))
+        for i in range(size):
+            x0 = float(base.reshape(-1)[i])
+            row = None
+            try:
+                tc = dict(theta)
+                tc[name] = with_element(i, complex(x0, 1e-30), np.complex128)
+                with np.errstate(all="ignore"):
+                    out = np.asarray(self.mean_fn(X.astype(np.complex128), tc))
+                if np.iscomplexobj(out):
+                    dm = out.imag.squeeze() / 1e-30
+                    if dm.shape == mshape and np.all(np.isfinite(dm)):
+                        row = dm
+            except Exception:
+                row = None
+            if row is None:
+                h = 1e-6 * max(1.0, abs(x0))
+                tp, tm = dict(theta), dict(theta)
+                tp[name], tm[name] = with_element(i, x0 + h, np.float64), with_element(i, x0 - h, np.float64)
+                row = (self._mean(X, tp) - self._mean(X, tm)) / (2 * h)
+            J[i] = np.asarray(row, dtype=np.float64).reshape(-1)
+        return J
 
     def _unpack(self, sites, u):
         theta, off = {}, 0
@@ -394,7 +413,7 @@ class ExactGP:
                         if gx.size != s.size:  # one lengthscale shared by all input dimensions (custom kernel_prior)
                             gx = np.array([gx.sum()])
                     else:  # mean-function parameter: d lml / d phi = sum_i alpha_i d m_i / d phi
-                        gx = np.array([float(np.sum(alpha * self._dmean(self.X_train, theta, s.name)))])
+                        gx = self._dmean(self.X_train, theta, s.name) @ np.asarray(alpha, dtype=np.float64).reshape(-1)
                     gu = (gx + d_.grad_log_prob(x)) * d_.dx_du(ui)
                     if jacobian:
                         gu = gu + dlj
@@ -667,28 +686,47 @@ class ExactGP:
         return means.mean(0), y_sampled
 
     def predict_distributed(self, rng_key, X_new: np.ndarray, samples: Optional[Dict[str, np.ndarray]] = None,
-                            n: int = 1, filter_nans: bool = False, noiseless: bool = False,
+                            n: int = 1, filter_nans: bool = False, noiseless: bool = False, comm=None,
                             **kwargs: float) -> Optional[Tuple[np.ndarray, np.ndarray]]:
-        """predict() with the posterior samples sharded over the ranks of an initialised torch.distributed
-        group (one process per GPU, `python -m torch.distributed.run`; backend nccl = RCCL over xGMI).
+        """predict() with the posterior samples sharded over the processes of a one-process-per-GPU launch
+        (`python -m torch.distributed.run`, mpirun, gpax_amd.launch.spawn_ranks: RANK / LOCAL_RANK / WORLD_SIZE).
         A collective call: every rank enters it with a model of the same configuration; only rank 0 needs the
-        fitted state / arguments — they are broadcast, each rank sweeps its contiguous block of samples on its
-        own GPU, and rank 0 returns (y_mean, y_sampled); the other ranks return None (gp.py:351-399's vmap axis
-        is the only axis of the path that shards)."""
-        from ..parallel import Communicator, predict_sharded
-        comm = Communicator()
+        fitted state / arguments.  Rank 0 returns (y_mean, y_sampled), the other ranks None (gp.py:351-399's vmap
+        axis is the only axis of the path that shards).
+        comm: None — the process-wide `_lib.Rank` of this launch (gpax_amd.launch.default_rank(): the library's own
+        RCCL communicator, ncclBroadcast of the inputs and ncclSend / ncclRecv gather of the results over xGMI; no
+        other runtime involved); a `_lib.Rank`; or any object with the protocol of gpax_amd.parallel (rank, world,
+        bcast, gather_rows) for callers living in another runtime's process group."""
+        from .. import launch
         jitter = float(kwargs.get("jitter", 1e-6))
+        if comm is None:
+            comm = launch.default_rank()
+        root = comm.rank == 0
         mean_shift = None
-        if comm.rank == 0:
+        ells = scales = noises = yres = eps = None
+        if root:
             X_new = self._set_data(X_new)
             if samples is None:
                 samples = self.get_samples(chain_dim=False)
             ells, scales, noises, yres, eps, mean_shift = self._sweep_inputs(rng_key, X_new, samples, n)
-            args = (self.X_train, yres, X_new, {"k_length": ells, "k_scale": scales, "noise": noises}, eps)
+        if isinstance(comm, _lib.Rank):
+            # sizes travel first (16 doubles), then ONE collective sweep inside the library
+            hdr = np.zeros(16)
+            if root:
+                yres2 = np.atleast_2d(yres)
+                hdr[:9] = [self.X_train.shape[0], self.X_train.shape[1], ells.shape[0], X_new.shape[0], n,
+                           self._kind, 1.0 if noiseless else 0.0, jitter, yres2.shape[0]]
+            hdr = comm.bcast(hdr)
+            N, d, S, M, n_, kind, nl, jit, rows = (int(hdr[0]), int(hdr[1]), int(hdr[2]), int(hdr[3]), int(hdr[4]),
+                                                   int(hdr[5]), bool(hdr[6]), float(hdr[7]), int(hdr[8]))
+            res = comm.predict_sweep(kind, N, d, S, M, n_, nl, jit, yres_rows=rows, X=self.X_train if root else None,
+                                     ells=ells, scales=scales, noises=noises, yres=yres, Xnew=X_new if root else None,
+                                     eps=eps)
         else:
-            args = (None, None, None, None, None)
-        engines = _lib.get_sweep_engines(self._device)
-        res = predict_sharded(engines, self._kind, *args, noiseless, jitter, comm)
+            from ..parallel import predict_sharded
+            args = (self.X_train, yres, X_new, {"k_length": ells, "k_scale": scales, "noise": noises}, eps) if root \
+                else (None, None, None, None, None)
+            res = predict_sharded(_lib.get_sweep_engines(self._device), self._kind, *args, noiseless, jitter, comm)
         if res is None:
             return None
         means, y_sampled, infos = res

@@ -54,18 +54,47 @@ class vExactGP(ExactGP):
     # -- sample sites (vgp.py:98-120) -------------------------------------------------------------------
     def _sites(self):
         T = self._tasks
+        sites = self._task_kernel_sites(T) + self._task_noise_sites(T)
+        for name, d in self._mean_prior_dict().items():
+            sites.append(_Site(name, (), d))
+        return sites
+
+    def _task_kernel_sites(self, T):
+        """vgp.py:69-72: a `kernel_prior` callable replaces the default sites; the kernel is vmapped over the task axis
+        (vgp.py:84), so every value it returns must carry the T tasks on its first axis."""
+        if self.kernel_prior is not None:
+            self._det = {}
+            sites, returned, det = self._traced(self.kernel_prior, "kernel_prior")
+            have = set(returned) if isinstance(returned, dict) else set()
+            need = {"k_length", "k_scale"} | ({"period"} if self.kernel_name == "Periodic" else set())
+            if not need <= have:
+                raise ValueError(f"kernel_prior must return {sorted(need)} (kernels.py:44-117)")
+            if det:
+                raise NotImplementedError("vExactGP kernel_prior: deterministic sites have no per-task MI355X path")
+            for sx in sites:
+                ok = {"k_length": [(T, self.kernel_dim), (T, 1), (T,)]}.get(sx.name, [(T,), (T, 1)])
+                if tuple(sx.shape) not in ok:
+                    raise ValueError(f"vExactGP kernel_prior: site {sx.name!r} has shape {tuple(sx.shape)}; with {T} tasks "
+                                     f"it must be one of {ok} (the kernel is vmapped over the task axis, vgp.py:84)")
+            return sites
         # The reference draws k_length from LogNormal(0, 1) unconditionally and hands `lengthscale_prior_dist`
         # to k_scale (vgp.py:111-113); mirrored as is.
         scale_dist = self.lengthscale_prior_dist if self.lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
-        noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
         sites = [_Site("k_length", (T, self.kernel_dim), dist.LogNormal(0.0, 1.0)),
                  _Site("k_scale", (T,), scale_dist)]
         if self.kernel_name == "Periodic":
             sites.append(_Site("period", (T,), dist.LogNormal(0.0, 1.0)))
-        sites.append(_Site("noise", (T,), noise_dist))  # plate "noise_plate", vgp.py:89-96
-        for name, d in self._mean_prior_dict().items():
-            sites.append(_Site(name, (), d))
         return sites
+
+    def _task_noise_sites(self, T):
+        if self.noise_prior is not None:  # vgp.py:74-75
+            sites, _, _ = self._traced(self.noise_prior, "noise_prior")
+            if len(sites) != 1 or sites[0].name != "noise" or tuple(sites[0].shape) not in [(T,), (T, 1)]:
+                raise ValueError(f"vExactGP noise_prior must sample exactly one site 'noise' of shape ({T},): one "
+                                 "noise variance per task (vgp.py:74-75, 84)")
+            return sites
+        noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
+        return [_Site("noise", (T,), noise_dist)]  # plate "noise_plate", vgp.py:89-96
 
     def _ells(self, theta) -> np.ndarray:
         """(T, n_ell): per-task lengthscales (+ period)."""

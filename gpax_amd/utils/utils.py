@@ -63,15 +63,11 @@ def split_in_batches(X_new: np.ndarray, batch_size: int = 100, dim: int = 0):
 
 
 def split_dict(data: Dict[str, np.ndarray], chunk_size: int) -> List[Dict[str, np.ndarray]]:
-    """gpax/utils/utils.py:54-81"""
-    N = len(next(iter(data.values())))
-    num_chunks = int(np.ceil(N / chunk_size))
-    result = []
-    for i in range(num_chunks):
-        start_idx = i * chunk_size
-        end_idx = min((i + 1) * chunk_size, N)
-        result.append({key: value[start_idx:end_idx] for key, value in data.items()})
-    return result
+    """Cut every array of a samples dictionary into consecutive pieces of `chunk_size` rows (the last one may be
+    shorter) — one dictionary per piece.  Behaviour of gpax/utils/utils.py:54-81."""
+    rows = len(next(iter(data.values())))
+    cuts = range(0, rows, int(chunk_size))
+    return [{name: arr[lo:lo + chunk_size] for name, arr in data.items()} for lo in cuts]
 
 
 def random_sample_dict(data: Dict[str, np.ndarray], num_samples: int, rng_key) -> Dict[str, np.ndarray]:
@@ -82,44 +78,50 @@ def random_sample_dict(data: Dict[str, np.ndarray], num_samples: int, rng_key) -
 
 
 def preprocess_sparse_image(sparse_image: np.ndarray):
-    """gpax/utils/utils.py:150-168: zeros = missing pixels.  Returns (X_train (N,D), y (N,),
-    X_full (prod(shape), D)) in the image dtype."""
-    sparse_image = np.asarray(sparse_image)
-    dtype = sparse_image.dtype
-    non_zero_indices = np.nonzero(sparse_image)
-    gp_input = np.column_stack(non_zero_indices)
-    targets = sparse_image[non_zero_indices]
-    full_indices = np.array(np.meshgrid(*[np.arange(dim) for dim in sparse_image.shape])).T.reshape(
-        -1, sparse_image.ndim)
-    return gp_input.astype(dtype), targets.astype(dtype), full_indices.astype(dtype)
+    """Zeros mark missing pixels (behaviour of gpax/utils/utils.py:150-168).  Returns, in the image dtype:
+    X_train (N, D) — coordinates of the measured pixels in row-major order; y (N,) — their values;
+    X_full (prod(shape), D) — every pixel coordinate.  For images (D = 2) X_full is row-major too, so a prediction on
+    it reshapes straight back to the image; for D >= 3 the reference's transposed 'xy' meshgrid enumerates the axes
+    slow -> fast as D-1, ..., 2, 0, 1, and that order is kept."""
+    img = np.asarray(sparse_image)
+    measured = img != 0
+    coords = np.argwhere(measured)
+    slow_to_fast = list(range(img.ndim - 1, 1, -1)) + list(range(min(img.ndim, 2)))
+    counters = np.indices([img.shape[ax] for ax in slow_to_fast]).reshape(img.ndim, -1)
+    grid = np.empty((counters.shape[1], img.ndim), dtype=img.dtype)
+    for pos, ax in enumerate(slow_to_fast):
+        grid[:, ax] = counters[pos]
+    return coords.astype(img.dtype), img[measured].astype(img.dtype), grid
 
 
 def initialize_inducing_points(X, ratio=0.1, method='uniform', key=None):
-    """gpax/utils/utils.py:171-212.  'uniform' uses evenly spaced indices (the reference's int8
-    index dtype overflows beyond 128 points, utils.py:191; full-width integers here)."""
-    if not 0 < ratio < 1:
-        raise ValueError("The 'ratio' value must be between 0 and 1")
+    """int(N * ratio) inducing inputs out of X (behaviour of gpax/utils/utils.py:171-212): 'uniform' = evenly spaced
+    rows (the reference's int8 index dtype overflows beyond 128 points, utils.py:191; full-width integers here),
+    'random' = a draw without replacement (needs `key`), 'kmeans' = cluster centres (scikit-learn)."""
     X = np.asarray(X)
-    n_samples = X.shape[0]
-    n_inducing = int(n_samples * ratio)
-    if method == 'uniform':
-        indices = np.linspace(0, n_samples - 1, n_inducing).astype(np.int64)
-        inducing_points = X[indices]
-    elif method == 'random':
+    if not (0 < ratio < 1):
+        raise ValueError("The 'ratio' value must be between 0 and 1")
+    count = int(X.shape[0] * ratio)
+
+    def evenly_spaced():
+        return X[np.linspace(0, X.shape[0] - 1, count).astype(np.int64)]
+
+    def random_rows():
         if key is None:
             raise ValueError("A JAX random key must be provided for random selection")
-        indices = rng_from_key(key).choice(n_samples, size=(n_inducing,), replace=False)
-        inducing_points = X[indices]
-    elif method == 'kmeans':
+        return X[rng_from_key(key).choice(X.shape[0], size=(count,), replace=False)]
+
+    def cluster_centres():
         try:
             from sklearn.cluster import KMeans
         except ImportError as e:  # pragma: no cover
             raise ImportError("You need to install `scikit-learn` to be able to use this feature.") from e
-        kmeans = KMeans(n_clusters=n_inducing, random_state=0, n_init=10).fit(X)
-        inducing_points = np.asarray(kmeans.cluster_centers_)
-    else:
+        return np.asarray(KMeans(n_clusters=count, random_state=0, n_init=10).fit(X).cluster_centers_)
+
+    pick = {'uniform': evenly_spaced, 'random': random_rows, 'kmeans': cluster_centres}.get(method)
+    if pick is None:
         raise ValueError("Method must be 'uniform', 'random', or 'kmeans'")
-    return inducing_points
+    return pick()
 
 
 def set_fn(func):

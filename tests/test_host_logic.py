@@ -501,3 +501,65 @@ def test_sample_from_prior_is_mvn_sample_of_the_prior_draws():
         eps = rng.standard_normal(25)
         K = ref.RBFKernel(X, X, theta, theta["noise"], jitter=1e-5)
         np.testing.assert_allclose(out[i], ref.mvn_sample(np.zeros(25), K, eps[None])[0], rtol=1e-9, atol=1e-12)
+
+
+def test_nested_plates_follow_numpyros_dimension_rule():
+    """without `dim` the OUTER plate is the LAST axis (first free dim counting from -1); explicit dims win."""
+    from gpax_amd import dist, plate, sample
+    from gpax_amd.infer.primitives import trace_sites
+
+    def auto():
+        with plate("a", 3):
+            with plate("b", 2):
+                return {"x": sample("x", dist.Normal(0.0, 1.0))}
+
+    def explicit():
+        with plate("tasks", 3, dim=-2):
+            with plate("ard", 2, dim=-1):
+                return {"x": sample("x", dist.Normal(0.0, 1.0))}
+
+    def gap():
+        with plate("only", 4, dim=-2):
+            return {"x": sample("x", dist.Normal(0.0, 1.0))}
+
+    assert trace_sites(auto, "t")[0][0][1] == (2, 3)
+    assert trace_sites(explicit, "t")[0][0][1] == (3, 2)
+    assert trace_sites(gap, "t")[0][0][1] == (4, 1)
+    with pytest.raises(ValueError):
+        with plate("p", 2, dim=0):
+            pass
+
+
+def test_vector_valued_mean_function_parameters_get_their_full_jacobian():
+    """a plate inside mean_fn_prior makes a site with several entries; d lml / d entry_i = J_i . alpha."""
+    from gpax_amd import ExactGP, dist, plate, sample
+    from tests.oracle_engine import OracleEngine
+    from gpax_amd import _lib
+    _lib.set_engine(OracleEngine())
+
+    def mean_fn(x, p):
+        return p["w"][0] * x[:, 0] + p["w"][1] * x[:, 0] ** 2 + p["b"]
+
+    def mean_prior():
+        with plate("coeffs", 2):
+            w = sample("w", dist.Normal(0.0, 2.0))
+        return {"w": w, "b": sample("b", dist.Normal(0.0, 1.0))}
+
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1, 1, (25, 1))
+    y = 0.7 * X[:, 0] - 0.4 * X[:, 0] ** 2 + 0.2 + 0.05 * rng.standard_normal(25)
+    m = ExactGP(1, "RBF", mean_fn=mean_fn, mean_fn_prior=mean_prior)
+    m.X_train, m.y_train = m._set_data(X, y)
+    sites = m._sites()
+    assert {s.name: tuple(s.shape) for s in sites}["w"] == (2,)
+    u = rng.standard_normal(sum(s.size for s in sites)) * 0.3
+    val, grad = m._log_joint(sites, u, 1e-6, True)
+    num = np.zeros_like(u)
+    for i in range(u.size):
+        e = np.zeros_like(u)
+        e[i] = 1e-6
+        num[i] = (m._log_joint(sites, u + e, 1e-6, True)[0] - m._log_joint(sites, u - e, 1e-6, True)[0]) / 2e-6
+    np.testing.assert_allclose(grad, num, rtol=2e-6, atol=1e-7)
+    J = m._dmean(m.X_train, m._unpack(sites, u), "w")
+    np.testing.assert_allclose(J, np.stack([X[:, 0], X[:, 0] ** 2]), rtol=1e-12)
+    _lib.set_engine(None)

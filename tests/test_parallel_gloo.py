@@ -1,6 +1,8 @@
-"""CPU, world_size = 2 and 3 (gloo): the sample-sharded sweep gathers exactly the single-process
-result.  The engine here is the checker-backed stand-in (no GPU in this container); on the GPU box
-the same code path runs with the real engine under the nccl (RCCL) backend."""
+"""CPU, world_size = 2 and 3 (gloo): the sample-sharded sweep over a caller-supplied communicator
+(gpax_amd.parallel.predict_sharded; the torch.distributed implementation of the protocol lives OUTSIDE the product,
+tools/torch_comm.py) gathers exactly the single-process result.  The engine here is the checker-backed stand-in (no GPU
+in this container).  The product's own multi-process path — _lib.Rank, RCCL inside the library, no torch — is covered by
+tests/test_launch.py (CPU: rendezvous / agreement / launcher) and tests/test_gpu_rank.py (GPU)."""
 import os
 import socket
 
@@ -44,7 +46,8 @@ def _worker(rank, world, port, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from gpax_amd.parallel import Communicator, predict_sharded
+    from gpax_amd.parallel import predict_sharded
+    from tools.torch_comm import Communicator
     from tests.oracle_engine import OracleEngine
 
     comm = Communicator()
@@ -83,17 +86,18 @@ def _model_worker(rank, world, port, outdir):
     from gpax_amd import ExactGP, _lib
     from gpax_amd.utils import get_keys
     from tests.oracle_engine import OracleEngine
+    from tools.torch_comm import Communicator
 
     _lib.set_engine(OracleEngine())
     m = ExactGP(2, "Matern", mean_fn=lambda x: 0.3 * x[:, 0])
     if rank == 0:  # only rank 0 holds data and samples
         X, y, Xn, samples, _ = _problem()
         m.X_train, m.y_train = m._set_data(X, y)
-        res = m.predict_distributed(get_keys()[1], Xn, samples, n=2)
+        res = m.predict_distributed(get_keys()[1], Xn, samples, n=2, comm=Communicator())
         single = m.predict(get_keys()[1], Xn, samples, n=2)
         np.savez(os.path.join(outdir, "model.npz"), ym=res[0], ys=res[1], ym1=single[0], ys1=single[1])
     else:
-        assert m.predict_distributed(None, None) is None
+        assert m.predict_distributed(None, None, comm=Communicator()) is None
     dist.barrier()
     dist.destroy_process_group()
 

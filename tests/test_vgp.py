@@ -189,3 +189,39 @@ def test_mean_function_with_prior():
     y_mean, y_sampled = m.predict(get_keys()[1], X, n=2)
     assert y_mean.shape == (3, 8) and y_sampled.shape == (15, 2, 3, 8)
     assert np.sqrt(np.mean((y_mean - y) ** 2)) < 2.0
+
+
+def test_custom_kernel_and_noise_priors_are_used_not_ignored():
+    """vExactGP(kernel_prior=..., noise_prior=...) must sample under THOSE priors (vgp.py:69-75), per task."""
+    import gpax_amd
+    from gpax_amd import dist, plate, sample
+    from gpax_amd.models.vgp import vExactGP
+
+    T, d = 3, 2
+
+    def kprior():
+        with plate("tasks", T, dim=-2):
+            with plate("ard", d, dim=-1):
+                length = sample("k_length", dist.Uniform(0.5, 2.0))
+        with plate("tasks2", T):
+            scale = sample("k_scale", dist.HalfNormal(3.0))
+        return {"k_length": length, "k_scale": scale}
+
+    def nprior():
+        with plate("noise_plate", T):
+            return sample("noise", dist.HalfNormal(0.1))
+
+    m = vExactGP(d, "RBF", kernel_prior=kprior, noise_prior=nprior)
+    m.X_train = np.zeros((T, 5, d))
+    sites = {s.name: s for s in m._sites()}
+    assert tuple(sites["k_length"].shape) == (T, d) and isinstance(sites["k_length"].dist, dist.Uniform)
+    assert tuple(sites["k_scale"].shape) == (T,) and isinstance(sites["k_scale"].dist, dist.HalfNormal)
+    assert tuple(sites["noise"].shape) == (T,) and isinstance(sites["noise"].dist, dist.HalfNormal)
+
+    def scalar_prior():  # no task axis: the vmapped kernel could not consume it
+        return {"k_length": sample("k_length", dist.LogNormal(0, 1)), "k_scale": sample("k_scale", dist.LogNormal(0, 1))}
+
+    bad = vExactGP(d, "RBF", kernel_prior=scalar_prior)
+    bad.X_train = np.zeros((T, 5, d))
+    with pytest.raises(ValueError, match="tasks"):
+        bad._sites()

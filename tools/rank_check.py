@@ -61,6 +61,22 @@ def main():
                 assert want[2][S // 2] != 0 and np.isnan(got[0][S // 2]).all()
         else:
             assert got is None
+    # the model API: ExactGP.predict_distributed over this communicator against ExactGP.predict on rank 0 alone
+    from gpax_amd import ExactGP
+    from gpax_amd.utils import get_keys
+    _lib.set_engine(None)
+    m = ExactGP(2, "Matern", mean_fn=lambda x: 0.3 * x[:, 0])
+    m._device = 0 if a.share_gpu else env.local_rank
+    if root:
+        X, y, Xn, _ = synthetic_problem(400, 2, 50, seed=9)
+        th = synthetic_theta_samples(2 * env.world + 1, 2, seed=10)
+        m.X_train, m.y_train = m._set_data(X, y)
+        got = m.predict_distributed(get_keys()[1], Xn, dict(th), n=2, comm=rk)
+        want = m.predict(get_keys()[1], Xn, dict(th), n=2)
+        np.testing.assert_array_equal(got[0], want[0])
+        np.testing.assert_array_equal(got[1], want[1])
+    else:
+        assert m.predict_distributed(None, None, comm=rk) is None
     rk.barrier()
     if root:
         print(f"rank_check ok: {env.world} ranks, transport {info['transport']}, rccl {info['rccl_version']}, "
