@@ -699,6 +699,8 @@ int gpx_init(int device, gpx_ctx** out) {
       GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evS2, hipEventDisableTiming));
       GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evU2, hipEventDisableTiming));
     }
+    if (const char* e = getenv("GPX_PANEL_KERNEL")) ctx->panel_mode = atoi(e);
+    if (const char* e = getenv("GPX_PANEL_MAX_FAR")) ctx->panel_max_far = atoi(e);
     if (const char* e = getenv("GPX_EARLY_DIAG")) ctx->early_diag = atoi(e); // 0 off, 1 everywhere, 2 in the tail
     if (const char* e = getenv("GPX_TAIL_TILES")) ctx->tail_tiles = atoi(e);
     if (const char* e = getenv("GPX_TAIL_OUTER_TILES")) ctx->tail_outer_tiles = atoi(e);
@@ -739,6 +741,7 @@ void gpx_destroy(gpx_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->evP) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->evU) (void)hipEventDestroy(e);
+    ctx->panel_sync.release();
     for (hipEvent_t e : ctx->tile_counter_ev)
       if (e) (void)hipEventDestroy(e);
     if (ctx->evR0) (void)hipEventDestroy(ctx->evR0);
@@ -1213,6 +1216,12 @@ int gpx_profile_read_bytes(gpx_ctx* ctx, int cls, double* total_bytes) {
 int gpx_debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n, int* xcd_by_bx, int cap) {
   if (tiles_m < 1 || tiles_n < 1 || cap < 0 || (cap > 0 && !xcd_by_bx)) return -1;
   return gpx::debug_tile_order(lower, ti_off, tj_off, tiles_m, tiles_n, xcd_by_bx, cap);
+}
+
+int gpx_panel_stats(gpx_ctx* ctx, int64_t* launches, int* ran, int* failed) {
+  if (!ctx || ctx->device < 0) return -1;
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  return panel_stats(ctx, launches, ran, failed);
 }
 
 int gpx_time_stage(gpx_ctx* ctx, int stage, int reps, double* elapsed_ms) {

@@ -182,6 +182,14 @@ struct gpx_ctx {
   int tile_swizzle = 0; // GPX_TILE_SWIZZLE: XCD-aware tile order of the big-tile GEMM (8x8-tile chunks per XCD), 0 = grid order
   int tail_outer_tiles = 0; // GPX_TAIL_OUTER_TILES: outer block width in the tail (0 / >= outer_tiles: same as the head)
   int tail_tiles = 72; // GPX_TAIL_TILES: an outer block is in the chain-bound tail when fewer tile rows than this remain (0: no tail)
+  // cooperative panel-chain kernel (panel.hip): GPX_PANEL_KERNEL = 0 off (default: measured slower than the launches at
+  // every size, profiles/r03/panel_kernel.md), 1 in the chain-bound tail (single-sample factorisations), 2 everywhere
+  int panel_mode = 0;
+  int panel_max_far = 16; // GPX_PANEL_MAX_FAR: tile rows below an outer block up to which its chain runs cooperatively
+  int panel_ok = -1; // -1: dispatch rule not probed yet; 0 / 1: result of panel_probe on this device
+  gpx::DevBuf panel_sync;
+  int panel_epoch = 0;
+  int64_t panel_launches = 0;
   int early_diag = 0; // GPX_EARLY_DIAG=1 switches it on: measured slower (profiles/r02/chain_experiments.md), default off
   std::vector<hipEvent_t> evP, evU; // per-outer-block panel / next-panel-update events
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -365,6 +373,11 @@ int mfma_peak(gpx_ctx* ctx, double* tflops);
 int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo,
                      int info_base, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0,
                      const double* dPre = nullptr, int Kpre = 0);
+
+// panel.hip
+int panel_probe(gpx_ctx* ctx);
+int launch_panel_chain(gpx_ctx* ctx, double* dA, int64_t lda, int nrows, int ob, int oe, double* dLinv, int* dInfo);
+int panel_stats(gpx_ctx* ctx, int64_t* launches, int* ran, int* failed);
 
 // linalg.hip
 int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,

@@ -262,7 +262,20 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     const int gs = gfirst[(size_t)k], ge = glast[(size_t)k];
     // P(k) on the panel stream (it follows U1(k-1) there, in stream order)
     ctx->s = span;
-    rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs, first_queued, early_at(k), u1b_pending);
+    // The chain of a tail block as ONE cooperative kernel (panel.hip): the dependencies between the diagonal-block
+    // factorisations, TRSMs and inner updates are flags in device memory instead of 12 dependent launches.  Same tile
+    // bodies, same fma chains: bit-identical to the launches.  Single-sample factorisations only (a batch is B times
+    // more work per launch and never chain-bound), and not combined with the early-diagonal / split-U1 experiments.
+    // Only where few tile rows lie below the block (panel_max_far): the cooperative kernel lives on ONE XCD (32 CUs), so
+    // the rows below the block — whose TRSMs and updates the launches spread over the whole chip — must be few.
+    bool coop = ctx->panel_mode > 0 && bs.batch == 1 && (ctx->panel_mode >= 2 || in_tail(k)) && !first_queued &&
+                !early_at(k) && !u1b_pending && oe - ob <= 8 && dInfo != nullptr &&
+                (nblk + extra_tiles - oe) <= ctx->panel_max_far;
+    if (coop && ctx->panel_ok < 0) ctx->panel_ok = panel_probe(ctx);
+    if (coop && ctx->panel_ok == 1)
+      rc = launch_panel_chain(ctx, dA, lda, nblk + extra_tiles, ob, oe, dLinv, dInfo);
+    else
+      rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs, first_queued, early_at(k), u1b_pending);
     first_queued = false;
     u1b_pending = false;
     if (rc < 0) break;

@@ -44,7 +44,8 @@ typedef struct gpx_ctx gpx_ctx;
 #define GPX_PROF_GEMM_OTHER 1    /* every other MFMA GEMM launch */
 #define GPX_PROF_POTF2 2         /* diagonal-block factor+inverse */
 #define GPX_PROF_GRAM 3          /* Gram builds */
-#define GPX_PROF_NCLASS 4
+#define GPX_PROF_PANEL 4         /* cooperative panel-chain kernel (potf2 + TRSM + inner updates of one outer block) */
+#define GPX_PROF_NCLASS 5
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
 
@@ -256,6 +257,10 @@ int gpx_profile_read_bytes(gpx_ctx* ctx, int cls, double* total_bytes);
  * only tiles on or below the diagonal.  Writes (xcd, by, bx) triples in workgroup order, up to `cap` of them, and
  * returns the number of tiles the launch computes (-1: shape not handled, the launch falls back to grid order). */
 int gpx_debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n, int* xcd_by_bx, int cap);
+
+/* Diagnostic: launches of the cooperative panel-chain kernel (csrc/panel.hip) issued by this context, launches that ran
+ * on the device, and the device-side fail flag (a spin time-out; such a factorisation reports a failed pivot). */
+int gpx_panel_stats(gpx_ctx* ctx, int64_t* launches, int* ran, int* failed);
 
 /* Device-only timed repetitions (inputs resident in HBM; used by bench.py so that `value`
  * excludes PCIe).  Each call runs `reps` passes of the named stage at the theta/Xnew last set

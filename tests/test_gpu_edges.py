@@ -172,11 +172,16 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
                 # U1 split: only the next diagonal column stays on the chain, the rest runs on the q stream
                 dict(GPX_U1_SPLIT="2"), dict(GPX_U1_SPLIT="1", GPX_TAIL_TILES="12"), dict(GPX_U1_SPLIT="2", GPX_LAZY_GROUP="3"),
                 dict(GPX_U1_SPLIT="2", GPX_OUTER_TILES="2", GPX_LAZY_GROUP="1"), dict(GPX_U1_SPLIT="2", GPX_SPLIT_FAR="1"), dict(GPX_GRID_PAD8="1"),
-                dict(GPX_TILE_SWIZZLE="3", GPX_TILE_SWIZZLE_MIN="64"), dict(GPX_FAR_AFTER_U1="0"), dict(GPX_FAR_AFTER_U1="100", GPX_LAZY_GROUP="1")]
+                dict(GPX_TILE_SWIZZLE="3", GPX_TILE_SWIZZLE_MIN="64"), dict(GPX_FAR_AFTER_U1="0"), dict(GPX_FAR_AFTER_U1="100", GPX_LAZY_GROUP="1"),
+                # the panel chain of an outer block as launches (0) / as one cooperative kernel in the tail (1, default:
+                # the whole matrix is "tail" at this size) / everywhere (2), with other outer blockings
+                dict(GPX_PANEL_KERNEL="0"), dict(GPX_PANEL_KERNEL="2"), dict(GPX_PANEL_KERNEL="2", GPX_PANEL_MAX_FAR="1000"), dict(GPX_PANEL_KERNEL="0", GPX_OUTER_TILES="2"),
+                dict(GPX_PANEL_KERNEL="2", GPX_OUTER_TILES="2"), dict(GPX_PANEL_KERNEL="2", GPX_OUTER_TILES="8", GPX_LAZY_GROUP="1"),
+                dict(GPX_PANEL_KERNEL="1", GPX_TAIL_TILES="12", GPX_LAZY_GROUP="2"), dict(GPX_PANEL_KERNEL="2", GPX_OUTER_TILES="1")]
     for env in variants:
         for k in ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_EARLY_DIAG", "GPX_PERSIST_GEMM", "GPX_CU_RESERVE",
                   "GPX_PERSIST_SCOPE", "GPX_CU_RESERVE_SOFT", "GPX_PERSIST_SLACK", "GPX_TAIL_TILES", "GPX_TILE_SWIZZLE", "GPX_TILE_SWIZZLE_MIN",
-                  "GPX_TAIL_OUTER_TILES", "GPX_SPLIT_FAR", "GPX_U1_SPLIT", "GPX_GRID_PAD8", "GPX_FAR_AFTER_U1"):
+                  "GPX_TAIL_OUTER_TILES", "GPX_SPLIT_FAR", "GPX_U1_SPLIT", "GPX_GRID_PAD8", "GPX_FAR_AFTER_U1", "GPX_PANEL_KERNEL", "GPX_PANEL_MAX_FAR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -223,3 +228,41 @@ def test_blocked_diagonal_tile_factor_is_bit_identical_to_the_column_version(mon
     assert [i for _, i in res["blocked"]] == [0, 0, 0, 151]
     L = res["blocked"][2][0]
     assert np.abs(np.tril(L) @ np.tril(L).T - mats[2]).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_cooperative_panel_chain_kernel_runs_and_changes_no_bit(monkeypatch):
+    """panel.hip: in the chain-bound tail of a single-sample factorisation the panel chain of an outer block (potf2 ->
+    TRSM -> inner update, 12 dependent launches) is ONE kernel whose workgroups hand tiles over through flags in
+    device memory.  Same tile bodies => the factor, the ride-along solve, the gradient and the draws equal the
+    launched chain's bit for bit; the kernel really runs (stats) and no spin ever times out."""
+    import numpy as np
+    from bench_inputs import synthetic_problem
+    from gpax_amd import _lib
+
+    N, d, M = 9300, 2, 700  # 73 tile rows + 6 ride-along: head blocks (launches) and tail blocks (cooperative) in one factor
+    X, y, Xn, p = synthetic_problem(N, d, M, seed=17)
+    eps = np.random.default_rng(1).standard_normal((1, M))
+    outs, stats = [], []
+    monkeypatch.setenv("GPX_PANEL_MAX_FAR", "1000")  # every block below the threshold: the far-row roles get exercised
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("GPX_PANEL_KERNEL", mode)
+        e = _lib.Engine(0)
+        e.set_train(X)
+        lml, info = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+        assert info == 0
+        mean, cov, var = e.posterior(Xn, p["noise"], 1e-6, want_cov=True, want_var=True)
+        draws, dinfo = e.mvn_draw(eps)
+        sweep = e.predict_sweep(1, p["k_length"][None], [p["k_scale"]], [p["noise"]], y, Xn, False, 1e-6, eps[None])
+        lml2, _ = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+        grad = e.lml_grad()
+        outs.append((lml, mean, cov, var, draws, sweep[0], sweep[1], grad[0], grad[1], grad[2], grad[3]))
+        stats.append(e.panel_stats())
+        e.close()
+    assert stats[0] == {"launches": 0, "ran": 0, "failed": 0}
+    for st in stats[1:]:
+        assert st["launches"] > 0 and st["ran"] == st["launches"] and st["failed"] == 0, st
+    assert stats[2]["launches"] > stats[1]["launches"]  # mode 2 also covers the head blocks
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b))

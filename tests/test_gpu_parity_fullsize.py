@@ -5,6 +5,8 @@
     C4  RBF     N =  8192, d = 3, M = 1024   one theta as C2; the S = 1000 sweep once (determinism + 4 spot samples)
     C3  Matern  N = 16384, d = 2, M = 1024   lml, alpha, posterior, draws (one host factorisation, ~1-2 min)
     C5  Matern  512 x 512 image, N ~ 16384   exact viGP: SVI steps + predict_in_batches over all 262 144 pixels
+    C5  Matern  same image, M_ind = 2039     viSparseGP: VFE bound, its gradient (central differences of the oracle),
+                                             Woodbury posterior on a pixel subset, predict over all 262 144 pixels
 
 Tolerances are SURVEY.md §8c's: |d lml| <= 1e-10 |lml|, |d mean| <= 1e-8 |mean|, |d cov|_F <= 1e-8 |k_pp|_F,
 draws 1e-8 — two orders inside the north-star bar (1e-6)."""
@@ -137,3 +139,91 @@ def test_c5_exact_vigp_on_the_512x512_image():
     e_mean, e_var = ref.vigp_predict(X, y, X_full[idx], p, noiseless=True, kernel="Matern", jitter=JIT, route="chol")
     assert relerr(mean[idx], e_mean) < 1e-8
     assert np.linalg.norm(var[idx] - e_var) / np.linalg.norm(e_var) < 1e-6  # k_ss - |V|^2 cancels ~1e3 : 1 here
+
+
+def _c5_sparse_problem():
+    from gpax_amd.utils import get_keys, initialize_inducing_points, preprocess_sparse_image
+    img, sparse = synthetic_sparse_image(512, 512, 0.0625, seed=3)
+    X, y, X_full = preprocess_sparse_image(sparse)
+    Xu = initialize_inducing_points(X, 0.125, "random", get_keys(0)[0])  # sparse_gp.py:151-154: ratio 0.125 -> M_ind = 2039
+    assert 15000 < X.shape[0] < 18000 and Xu.shape == (int(X.shape[0] * 0.125), 2) and Xu.shape[0] > 2000
+    return img, X, y - y.mean(), y.mean(), X_full, Xu
+
+
+def test_c5_visparsegp_bound_and_posterior_at_m2048_vs_oracle(engine):
+    """BASELINE.json configs[4], the viSparseGP leg at ITS size: the VFE bound of
+    gpax/models/sparse_gp.py:62-114 and the Woodbury posterior of sparse_gp.py:173-223 on the 512 x 512 image
+    (N = 16 316 measured pixels, 'random' inducing points at ratio 0.125 -> M_ind = 2039, Matern), device against
+    oracle.  Conditioning: Kuu carries only the 1e-6 jitter; at this theta cond(Kuu) = 5.7e6 and a 0.1 % change of
+    the jitter moves the oracle's own bound by 3e-7 relative, so 1e-9 on the bound and 1e-7 on the posterior is what
+    fp64 can promise here (the north-star bar is 1e-6)."""
+    img, X, y, ybar, X_full, Xu = _c5_sparse_problem()
+    p = {"k_length": np.array([25.0, 25.0]), "k_scale": 1.0, "noise": 1e-2}
+    engine.set_train(X)
+    bound, info, _ = engine.sgp_bound(1, p["k_length"], p["k_scale"], p["noise"], JIT, Xu, y, want_grad=False)
+    assert info == 0
+    e_bound = ref.sparse_bound(X, y, Xu, p, kernel="Matern", jitter=JIT)
+    print(f"C5 sparse bound: device {bound:.9f} oracle {e_bound:.9f} rel {abs(bound - e_bound) / abs(e_bound):.2e}")
+    assert abs(bound - e_bound) <= 1e-9 * abs(e_bound)
+    # the bound never exceeds the exact log marginal likelihood of the same theta (device, exact GP)
+    lml, info2 = engine.factor(1, p["k_length"], p["k_scale"], p["noise"], JIT, y)
+    assert info2 == 0 and bound <= lml
+    # Woodbury posterior on a pixel subset, with and without observation noise on the prediction
+    idx = np.random.default_rng(5).choice(512 * 512, 300, replace=False)
+    for noiseless in (False, True):
+        noise_p = 0.0 if noiseless else p["noise"]
+        mean, cov, var, info3 = engine.sgp_posterior(1, p["k_length"], p["k_scale"], p["noise"], JIT, Xu, y, X_full[idx],
+                                                     noise_p, want_cov=True, want_var=True)
+        assert info3 == 0
+        e_mean, e_cov = ref.sparse_posterior(X, y, Xu, X_full[idx], p, noiseless, kernel="Matern", jitter=JIT)
+        print(f"C5 sparse posterior (noiseless={noiseless}): mean rel {relerr(mean, e_mean):.2e}, "
+              f"cov max abs {np.abs(cov - e_cov).max():.2e}, var max abs {np.abs(var - np.diag(e_cov)).max():.2e}")
+        assert relerr(mean, e_mean) <= 1e-7
+        assert np.abs(cov - e_cov).max() <= 1e-7 * p["k_scale"]
+        assert np.abs(var - np.diag(e_cov)).max() <= 1e-7 * p["k_scale"]
+    # the whole image through the model API (predict_in_batches -> device-sized slices), against the subset above
+    from gpax_amd import _lib, viSparseGP
+    _lib.set_engine(None)
+    m = viSparseGP(2, "Matern")
+    m.X_train, m.y_train = m._set_data(X, y)
+    m._data_version += 1
+    m.Xu = Xu
+    theta = {"k_length": p["k_length"], "k_scale": np.float64(p["k_scale"]), "noise": np.float64(p["noise"])}
+    mean_all, var_all = m.predict_in_batches(0, X_full, batch_size=1000, samples=theta, noiseless=True)
+    assert mean_all.shape == (512 * 512,) and np.isfinite(mean_all).all() and np.all(var_all > 0)
+    assert relerr(mean_all[idx], e_mean) <= 1e-7  # e_mean: the noiseless pass, computed last above
+    rmse = np.sqrt(np.mean((mean_all.reshape(512, 512) + ybar - img) ** 2))
+    assert rmse < 0.05, rmse
+
+
+def test_c5_visparsegp_gradient_at_m2048_vs_central_differences_of_the_oracle(engine):
+    """d bound / d (k_length[0], noise, one inducing coordinate) at C5's size against central differences of the
+    oracle's sparse_bound (six host evaluations).  jitter = 1e-4 keeps cond(Kuu) ~ 6e4 so that a difference quotient
+    of the oracle carries ~7 digits (the same choice as the small-size gradient test, test_gpu_sparse.py)."""
+    img, X, y, ybar, X_full, Xu = _c5_sparse_problem()
+    p = {"k_length": np.array([25.0, 25.0]), "k_scale": 1.0, "noise": 1e-2}
+    jit = 1e-4
+    engine.set_train(X)
+    bound, info, g = engine.sgp_bound(1, p["k_length"], p["k_scale"], p["noise"], jit, Xu, y)
+    assert info == 0 and np.isfinite(g["Xu"]).all() and np.isfinite(g["yres"]).all()
+
+    def f(ell, noise, xu):
+        return ref.sparse_bound(X, y, xu, {"k_length": ell, "k_scale": 1.0, "noise": noise}, kernel="Matern", jitter=jit)
+
+    ell0 = p["k_length"]
+    h = 1e-4 * ell0[0]
+    fd = (f(ell0 + np.array([h, 0.0]), 1e-2, Xu) - f(ell0 - np.array([h, 0.0]), 1e-2, Xu)) / (2 * h)
+    print(f"C5 sparse d/d ell0: device {g['k_length'][0]:.6e} fd {fd:.6e}")
+    assert abs(fd - g["k_length"][0]) <= 1e-4 * max(abs(g["k_length"][0]), abs(g["k_length"][1]))
+    h = 1e-6
+    fd = (f(ell0, 1e-2 + h, Xu) - f(ell0, 1e-2 - h, Xu)) / (2 * h)
+    print(f"C5 sparse d/d noise: device {g['noise']:.6e} fd {fd:.6e}")
+    assert abs(fd - g["noise"]) <= 1e-4 * abs(g["noise"])
+    a_ = int(np.argmax(np.abs(g["Xu"][:, 0])))  # the inducing point the bound is most sensitive to
+    h = 1e-3
+    xp, xm = Xu.copy(), Xu.copy()
+    xp[a_, 0] += h
+    xm[a_, 0] -= h
+    fd = (f(ell0, 1e-2, xp) - f(ell0, 1e-2, xm)) / (2 * h)
+    print(f"C5 sparse d/d Xu[{a_},0]: device {g['Xu'][a_, 0]:.6e} fd {fd:.6e}")
+    assert abs(fd - g["Xu"][a_, 0]) <= 1e-3 * np.abs(g["Xu"]).max()
