@@ -231,6 +231,31 @@ class ExactGP:
             theta.setdefault(k, v)
         return theta
 
+    _chains_over_devices = True  # _log_joint_batch honours its `eng` argument (subclasses that do not set this False)
+
+    def _chain_devices(self, chain_method: str, device, num_chains: int):
+        """GPU ordinals the chains of a concurrent NUTS run are dealt over: `device` "all" / a list, or — for
+        chain_method='parallel' with no device given — every visible GPU; one device otherwise."""
+        if not self._chains_over_devices or not isinstance(_lib.get_engine(self._device), _lib.Engine):
+            return [None]
+        if device == "all" or (device is None and chain_method == "parallel"):
+            devs = list(range(_lib.visible_device_count()))
+        elif isinstance(device, (list, tuple)):
+            devs = [int(v) for v in device]
+        else:
+            return [None]
+        devs = devs[:num_chains]
+        return devs if len(devs) > 1 else [None]
+
+    def _engine_on(self, dev: int) -> _lib.Engine:
+        """A context of its own on GPU `dev` holding this model's training set (one per group of chains)."""
+        eng = _lib.Engine(int(dev))
+        self._prepare_engine(eng)
+        return eng
+
+    def _prepare_engine(self, eng) -> None:
+        eng.set_train(self.X_train)
+
     def _engine(self) -> _lib.Engine:
         """The shared context of this model's device with X_train resident.  Residency is keyed on (model, data
         version): `_data_version` is bumped by every fit() / _set_training_data(), so an X array mutated in place
@@ -465,10 +490,25 @@ class ExactGP:
         concurrent = chain_method != "sequential" and num_chains > 1
         results = [None] * num_chains
         errors = []
-        lockstep = _Lockstep(num_chains, lambda us: self._log_joint_batch(sites, us, jitter, jacobian=True)) \
-            if concurrent else None
+        # chain_method='parallel' places the chains on separate devices in the reference (NumPyro pmaps them over
+        # jax.local_devices(), gp.py:173-174,214): here chain c runs on GPU devices[c % G], the chains of one GPU
+        # advancing in lockstep as one batched device pass; 'vectorized' keeps every chain on one GPU.  Chains are
+        # independent and each chain's arithmetic does not depend on its batch, so the draws equal the sequential ones.
+        devices = self._chain_devices(chain_method, device, num_chains) if concurrent else [None]
+        locksteps, group_engines = {}, []
+        if concurrent:
+            for g_, dev in enumerate(devices):
+                members = [c for c in range(num_chains) if c % len(devices) == g_]
+                eng_g = None if len(devices) == 1 else self._engine_on(dev)
+                if eng_g is not None:
+                    group_engines.append(eng_g)
+                ls = _Lockstep(len(members),
+                               lambda us, e=eng_g: self._log_joint_batch(sites, us, jitter, jacobian=True, eng=e))
+                for c in members:
+                    locksteps[c] = ls
 
         def run_chain(c):
+            lockstep = locksteps.get(c)
             try:
                 crng = chain_rngs[c]
 
@@ -504,6 +544,8 @@ class ExactGP:
                 t.start()
             for t in ts:
                 t.join()
+            for e_ in group_engines:
+                e_.close()
         else:
             for c in range(num_chains):
                 run_chain(c)

@@ -52,6 +52,9 @@ class VarNoiseGP(ExactGP):
         noise_lengthscale_prior_dist: prior of k_noise_length (default LogNormal(0, 1))
     """
 
+    _chains_over_devices = False  # two device passes per leapfrog on the shared context (set_diag state): one GPU
+
+
     def __init__(self, input_dim: int, kernel: str, noise_kernel: str = 'RBF', mean_fn: Optional[Callable] = None,
                  kernel_prior=None, mean_fn_prior=None, noise_kernel_prior=None,
                  lengthscale_prior_dist: Optional[dist.Distribution] = None, noise_mean_fn: Optional[Callable] = None,

@@ -60,6 +60,10 @@ class MeasuredNoiseGP(ExactGP):
             eng._diag_key = key
         return eng
 
+    def _prepare_engine(self, eng) -> None:
+        super()._prepare_engine(eng)
+        eng.set_diag(self.measured_noise if self._use_measured else None)
+
     def fit(self, rng_key, X: np.ndarray, y: np.ndarray, measured_noise: np.ndarray, num_warmup: int = 2000,
             num_samples: int = 2000, num_chains: int = 1, chain_method: str = "sequential", progress_bar: bool = True,
             print_summary: bool = True, device=None, **kwargs: float) -> None:

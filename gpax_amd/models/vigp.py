@@ -15,6 +15,7 @@ import numpy as np
 from ..infer import dist
 from ..infer.svi import fit_delta, fit_normal
 from ..utils.utils import rng_from_key, split_in_batches
+from .. import _lib
 from .gp import ExactGP, _Progress
 
 
@@ -84,34 +85,88 @@ class viGP(ExactGP):
     def predict_in_batches(self, rng_key, X_new: np.ndarray, batch_size: int = 100,
                            samples: Optional[Dict[str, np.ndarray]] = None, predict_fn=None, noiseless: bool = False,
                            device=None, **kwargs: float) -> Tuple[np.ndarray, np.ndarray]:
-        """predict() over slices of X_new (vigp.py:129-151).  K is factored once for all slices."""
+        """predict() over slices of X_new (vigp.py:129-151).  K is factored once for all slices.
+        `device`: a GPU ordinal, or "all" / a list of ordinals: the slices are dealt in contiguous blocks over those
+        GPUs (one host thread and one context each; every GPU factors K(theta) itself — 30 ms at N = 16384, less than
+        moving the 2 GB factor over xGMI).  Slice by slice the values are those of one GPU."""
         X_new = self._set_data(X_new)
+        if isinstance(device, int):
+            self._device = device
         if samples is None:
             samples = self.get_samples()
         jitter = float(kwargs.get("jitter", 1e-6))
-        info = 0
-        if predict_fn is None:
-            _, info = self._factor_at(samples, jitter)
-            predict_fn = lambda xi: self._posterior_mean_var(xi, samples, noiseless, jitter)
-        y_pred, y_var = [], []
-        for Xi in split_in_batches(X_new, batch_size, dim=0):
-            m, v = predict_fn(Xi)
-            y_pred.append(m)
-            y_var.append(v)
+        slices = split_in_batches(X_new, batch_size, dim=0)
+        devs = self._slice_devices(device, len(slices)) if predict_fn is None else [None]
+        if len(devs) > 1:
+            y_pred, y_var, info = self._predict_slices_on(devs, slices, samples, noiseless, jitter)
+        else:
+            info = 0
+            if predict_fn is None:
+                _, info = self._factor_at(samples, jitter)
+                predict_fn = lambda xi: self._posterior_mean_var(xi, samples, noiseless, jitter)
+            y_pred, y_var = [], []
+            for Xi in slices:
+                m, v = predict_fn(Xi)
+                y_pred.append(m)
+                y_var.append(v)
         y_pred, y_var = np.concatenate(y_pred, 0), np.concatenate(y_var, 0)
         if info != 0:  # K(theta) not positive definite: NaN like predict() and the reference's inverse route
             y_pred, y_var = np.full_like(y_pred, np.nan), np.full_like(y_var, np.nan)
         return y_pred, y_var
 
-    def _factor_at(self, params, jitter):
+    def _slice_devices(self, device, nslices: int):
+        if not isinstance(_lib.get_engine(self._device), _lib.Engine):
+            return [None]  # an injected engine (CPU tests)
+        if device == "all":
+            devs = list(range(_lib.visible_device_count()))
+        elif isinstance(device, (list, tuple)):
+            devs = [int(v) for v in device]
+        else:
+            return [None]
+        devs = devs[:max(1, nslices)]
+        return devs if len(devs) > 1 else [None]
+
+    def _predict_slices_on(self, devs, slices, samples, noiseless, jitter):
+        """Contiguous blocks of the slices on the GPUs `devs`: per GPU a context of its own, X_train uploaded, K(theta)
+        factored once, then its slices one after the other (vigp.py:129-151 re-inverts K for every slice)."""
+        import threading
+        G = len(devs)
+        bounds = [_lib.shard_range(len(slices), g, G) for g in range(G)]
+        out_m, out_v = [None] * len(slices), [None] * len(slices)
+        infos, errors = [0] * G, []
+
+        def work(g):
+            eng = None
+            try:
+                eng = self._engine_on(devs[g])
+                _, infos[g] = self._factor_at(samples, jitter, eng=eng)
+                for i in range(*bounds[g]):
+                    out_m[i], out_v[i] = self._posterior_mean_var(slices[i], samples, noiseless, jitter, eng=eng)
+            except Exception as ex:  # surface worker failures in the caller
+                errors.append(ex)
+            finally:
+                if eng is not None:
+                    eng.close()
+
+        ts = [threading.Thread(target=work, args=(g,)) for g in range(G)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errors:
+            raise errors[0]
+        return out_m, out_v, max(infos, key=abs)
+
+    def _factor_at(self, params, jitter, eng=None):
         noise = self._scalar(params["noise"])
         y_residual = self.y_train - self._mean(self.X_train, params)
-        return self._engine().factor(self._kind, self._ell(params), self._scalar(params["k_scale"]), noise, jitter,
-                                     y_residual)
+        eng = self._engine() if eng is None else eng
+        return eng.factor(self._kind, self._ell(params), self._scalar(params["k_scale"]), noise, jitter, y_residual)
 
-    def _posterior_mean_var(self, X_new, params, noiseless, jitter):
+    def _posterior_mean_var(self, X_new, params, noiseless, jitter, eng=None):
         noise_p = self._scalar(params["noise"]) * (1 - int(bool(noiseless)))
-        mean, _, var = self._engine().posterior(X_new, noise_p, jitter, want_cov=False, want_var=True)
+        eng = self._engine() if eng is None else eng
+        mean, _, var = eng.posterior(X_new, noise_p, jitter, want_cov=False, want_var=True)
         if self.mean_fn is not None:
             mean = mean + self._mean(X_new, params)
         return mean, var
