@@ -689,7 +689,11 @@ int gpx_init(int device, gpx_ctx** out) {
     GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evB, hipEventDisableTiming));
     if (const char* e = getenv("GPX_U1_SPLIT")) ctx->u1_split = atoi(e);
     if (const char* e = getenv("GPX_FAR_AFTER_U1")) ctx->far_after_u1 = atoi(e);
-    if (const char* e = getenv("GPX_POTF2")) ctx->potf2_column = (e[0] == 'c');
+    if (const char* e = getenv("GPX_POTF2")) { // "chain" (default) | "tile": the four-phase kernel of round 2 | "column": round 1
+      const std::string v(e);
+      ctx->potf2_column = (v == "column");
+      ctx->potf2_chain = !(v == "tile" || v == "column");
+    }
     if (const char* e = getenv("GPX_POTF2_DIAG")) ctx->potf2_diag_blocked = (e[0] == 'b');
     if (const char* e = getenv("GPX_GEMM_SMALL")) ctx->gemm_small = (e[0] != '0');
     if (const char* e = getenv("GPX_SMALL_TILES_MAX")) ctx->small_tiles_max = atof(e);

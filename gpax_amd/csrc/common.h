@@ -155,6 +155,7 @@ struct gpx_ctx {
   // GPX_SPLIT_FAR: the trailing updates of the Cholesky are issued as two launches — even and odd tile rows — on two
   // streams, so that the partly filled last round of one fills with the other's workgroups (linalg.hip)
   bool potf2_diag_blocked = false; // GPX_POTF2_DIAG=blocked: the 16 x 16 diagonal tiles factored four columns per LDS round trip (bit-identical, slower)
+  bool potf2_chain = true;        // GPX_POTF2=tile: the four-phase kernel of round 2 instead of the wave-specialised one (potf2_chain.h)
   bool potf2_column = false;      // GPX_POTF2=column: the column-by-column diagonal-block kernel of round 1
   bool gemm_small = true;         // GPX_GEMM_SMALL=0: no latency shapes
   double small_tiles_max = 400.0; // GPX_SMALL_TILES_MAX: launches with fewer 128x128 tiles take the latency shapes

@@ -17,6 +17,7 @@
 // A non-positive pivot makes sqrt() produce NaN (propagates, like JAX) and sets *info.
 #include "common.h"
 #include "potf2_tile.h"
+#include "potf2_chain.h"
 
 #include <cstdlib>
 
@@ -186,6 +187,17 @@ __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t l
   potf2_tile_body<BLK>(A, lda, Linv, info, info_base, Ppre, Kpre, lds);
 }
 
+// the wave-specialised form (potf2_chain.h): default; bit-identical to potf2_tile_kernel<false>
+__global__ __launch_bounds__(256, 1) void potf2_chain_kernel(double* A, int64_t lda, double* Linv, int* info, int info_base,
+                                                             int64_t a_bs, int64_t linv_bs) {
+  A += (int64_t)blockIdx.x * a_bs; // one workgroup per batch entry
+  Linv += (int64_t)blockIdx.x * linv_bs;
+  if (info != nullptr) info += blockIdx.x;
+  __builtin_amdgcn_s_setprio(3);
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  potf2_chain_body(A, lda, Linv, info, info_base, lds);
+}
+
 } // namespace gpx
 
 namespace gpx {
@@ -214,7 +226,9 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
   {
     // algorithmic flops: factor n^3/3 + triangular inverse n^3/3
     ProfScope ps(ctx, GPX_PROF_POTF2, nb * 2.0 * PB * (double)PB * PB / 3.0);
-    if (use_tile && ctx->potf2_diag_blocked)
+    if (use_tile && ctx->potf2_chain && !ctx->potf2_diag_blocked && dPre == nullptr)
+      potf2_chain_kernel<<<nb, 256, POTF2_CHAIN_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
+    else if (use_tile && ctx->potf2_diag_blocked)
       potf2_tile_kernel<true><<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs, dPre, Kpre);
     else if (use_tile)
       potf2_tile_kernel<false><<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs, dPre, Kpre);

@@ -231,6 +231,51 @@ def test_blocked_diagonal_tile_factor_is_bit_identical_to_the_column_version(mon
 
 
 @pytest.mark.gpu
+def test_wave_specialised_diagonal_block_kernel_is_bit_identical_to_the_four_phase_kernel(monkeypatch):
+    """potf2_chain.h (default): wave 0 runs only the dependent chain diag16 -> L(p+1,p) -> D(p+1), waves 1-3 own all tiles
+    and do every other TRSM / update beside it.  Tile for tile the MFMA sequences of potf2_tile_body (GPX_POTF2=tile):
+    factors, block inverses (through the solves they feed), log-likelihood, gradient, posterior and the pivot report agree
+    bit for bit — batched launches and a matrix that is not positive definite included."""
+    import numpy as np
+    from bench_inputs import synthetic_problem, synthetic_theta_samples
+    from gpax_amd import _lib
+
+    rng = np.random.default_rng(5)
+    mats = []
+    for n in (16, 100, 128, 200, 640, 1100):
+        B = rng.standard_normal((n, n + 8))
+        mats.append(B @ B.T / n + 0.3 * np.eye(n))
+    bad = mats[3].copy()
+    bad[150, 150] = -1.0  # pivot 151 fails
+    mats.append(bad)
+    X, y, Xn, p = synthetic_problem(900, 2, 70, seed=3)
+    th = synthetic_theta_samples(5, 2, seed=4)
+    eps = np.random.default_rng(1).standard_normal((5, 1, 70))
+    res = {}
+    for mode in ("tile", "chain"):
+        monkeypatch.setenv("GPX_POTF2", mode)
+        e = _lib.Engine(0)
+        out = [e.potrf(A) for A in mats]
+        e.set_train(X)
+        lml, info = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+        grad = e.lml_grad()
+        sweep = e.predict_sweep(1, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps)  # batched potf2
+        res[mode] = (out, lml, info, grad, sweep)
+        e.close()
+    for (L0, i0), (L1, i1) in zip(res["tile"][0], res["chain"][0]):
+        assert i0 == i1
+        assert np.array_equal(L0, L1, equal_nan=True)
+    assert [i for _, i in res["chain"][0]] == [0, 0, 0, 0, 0, 0, 151]
+    assert res["tile"][1] == res["chain"][1] and res["tile"][2] == res["chain"][2] == 0
+    for a, b in zip(res["tile"][3], res["chain"][3]):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    for a, b in zip(res["tile"][4], res["chain"][4]):
+        np.testing.assert_array_equal(a, b)
+    L = res["chain"][0][4][0]
+    assert np.abs(np.tril(L) @ np.tril(L).T - mats[4]).max() < 1e-12
+
+
+@pytest.mark.gpu
 def test_cooperative_panel_chain_kernel_runs_and_changes_no_bit(monkeypatch):
     """panel.hip: in the chain-bound tail of a single-sample factorisation the panel chain of an outer block (potf2 ->
     TRSM -> inner update, 12 dependent launches) is ONE kernel whose workgroups hand tiles over through flags in

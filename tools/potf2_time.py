@@ -5,7 +5,7 @@ sys.path.insert(0, os.getcwd())
 from gpax_amd import _lib
 eng = _lib.Engine(0)
 rng = np.random.default_rng(0)
-for n in (128, 256):
+for n in (128, 256, 2048):
     A = rng.standard_normal((n, n)); A = A @ A.T + n * np.eye(n)
     for _ in range(3):
         eng.potrf(A)

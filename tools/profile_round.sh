@@ -1,13 +1,13 @@
 #!/bin/bash
 # Regenerate the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03
 #   kernel-trace + stats of the default bench command, separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*), the C4
 #   sweep (S = 1000) with its own kernel trace, and the round's bench line; summarised on the box (the rocpd sqlite
 #   databases stay in /tmp; only .md / .json summaries come back under gpurun_out/prof — copy them to profiles/<round>).
 # NOTE (round 1): a single pass with five TCC_* derived counters on `bench.py --steps 1` did not finish within 10
 # minutes on this pool — keep L2 counters out of this script.  --pmc passes carry --kernel-trace only (gpurun refuses
 # --pmc together with the hip / hsa / memory trace domains).
-RND=${1:-r02}
+RND=${1:-r03}
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/prof
@@ -53,7 +53,12 @@ else:
     for n, c, s, a in rows:
         print(f"| `{n}` | {c} | {s / 1e6:.3f} | {a / 1e3:.1f} |")
 PY
-bash tools/asan_smoke.sh > $O/sanitizer_smoke.log 2>&1; grep -v Woption-ignored $O/sanitizer_smoke.log | tail -4
+# C5: viSparseGP / viGP on the 512 x 512 image (flop model in the tool's docstring)
+python tools/c5_bench.py > $O/c5_sparse.json 2> $O/c5_sparse.err
+# the N > 1 code path of bench.py on this 1-GPU box: one rank over RCCL (the collective sweep incl. the C4 record), and two
+# ranks sharing the GPU over the file transport (control flow only: the two ranks halve the GPU between them)
+python bench.py --force-rank-path --steps 12 --warmup 3 > $O/bench_rank1_rccl.json 2> $O/bench_rank1_rccl.err
+python bench.py --gpus 2 --share-gpu --steps 8 --warmup 2 --c4-S 200 > $O/bench_2ranks_shared_gpu.json 2> $O/bench_2ranks_shared_gpu.err
 python bench.py > $O/bench_$RND.json 2> $O/bench_$RND.err
 cut -c1-400 $O/bench_$RND.json
 ls -la $O
