@@ -18,6 +18,11 @@
 //            S2 <- C(p+1,p+1) for the chain                         own row-p residual tiles -> X(p,c) -> Xrow
 // LDS: Lcol[8] | Xrow[8] | Dinv[2] (by panel parity: the workers still read Dinv[p & 1] as X(p,p) while the chain
 // writes the next one) | Dg | S1 | S2 = 21 tiles of 16 x 17 doubles = 45.7 KB.
+// Measured (profiles/r03/potf2_chain_time.txt): 49.5 -> 33.5 us per launch.  Of the ~28 us inside the kernel ~21 are the eight
+// diagonal tiles.  A diag16 with the pivot one step ahead (the owner of S[j+1][j+1] publishes it next to column j, every
+// lane forms d_{j+1} = fma(-c, c ip2_j, s) itself and refines its reciprocal beside the updates, taking the reciprocal
+// out of the per-column chain; bit-identical) was built and measured SLOWER — 40.3 us: two more LDS reads and seven more
+// fp64 operations per column step on every lane cost more than the five dependent ones they hide — and removed.
 // Arithmetic: tile for tile the MFMA sequences of potf2_tile_body (k ascending, the same operands, the same signs), so
 // L, L^-1 and the pivots are bit-identical to it (tests/test_gpu_edges.py).
 #pragma once
