@@ -19,8 +19,13 @@ requires all 87 printed numbers to agree within their two decimals plus the Mont
 requires the negative log joint at the printed viGP state to sit within 0.04 of the printed loss, and shows that plausible
 restatement errors (no 1/2 in the RBF exponent, RBF or Matern-3/2 for Matern-5/2, a Matern-5/2 without its quadratic term,
 another noise prior, measured variances left out) fail.  That pins kernel formulas, noise / jitter / measured-noise placement, priors and
-the likelihood (its constants included) to the reference statistically — k_length to 1 - 5 %, the log joint to 0.3 %.  The posterior / draw arithmetic
-(get_mvn_posterior, MVN sampling) and everything bit-level remain UNPINNED by reference-generated numbers.  Beyond that, this restatement follows the
+the likelihood (its constants included) to the reference statistically — k_length to 1 - 5 %, the log joint to 0.3 %.
+The PREDICTIVE leg (get_mvn_posterior's mean and marginal variance, pooled over posterior samples, and the acquisition arithmetic on top)
+is pinned the same way through the seven posterior tables examples/gpax_GPBO.ipynb cell 22 printed for its Bayesian-optimisation
+loop — each step's data contain the argmax of UCB over predict() of the step before: tests/test_reference_gpbo_loop.py runs that loop
+exactly with this file's kernel functions and reproduces the tables (steps 4 - 7 within the path envelope the reference's own Monte-Carlo
+error leaves).  Covariances off the diagonal, MVN sampling given eps, the sparse (VFE) bound / posterior and everything bit-level remain
+UNPINNED by reference-generated numbers.  Beyond that, this restatement follows the
 reference line by line (file:line cited per function, paths relative to the reference checkout) and is cross-checked
 independently (tests/test_oracle.py): direct-formula Gram in mpmath at 50 digits, scipy.stats.multivariate_normal for
 the log-density, explicit-inverse vs Cholesky route for the posterior, central finite differences for the gradient,
