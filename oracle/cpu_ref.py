@@ -525,10 +525,3 @@ def acq_moments_from_samples(y_sampled, n):
     """acquisition.py:28-32: pooled moments of the (S, n, M) predictive draws of an MCMC model."""
     y_sampled = y_sampled.reshape(n * y_sampled.shape[0], -1)
     return y_sampled.mean(0), y_sampled.var(0)
-
-
-# ------------------------------------------------------------------------------------------
-# synthetic workloads of BASELINE.md §3: defined in bench_inputs.py (shared by bench.py and the tests; the
-# workload generator is not part of the checker).  Re-exported here for the tests that grew up calling ref.*.
-# ------------------------------------------------------------------------------------------
-from bench_inputs import synthetic_problem, synthetic_theta_samples  # noqa: E402,F401

@@ -9,6 +9,7 @@ from gpax_amd.acquisition import EI, POI, UCB, UE, Thompson, compute_penalty, ei
 from gpax_amd.models import ExactGP, viGP
 from gpax_amd.utils import get_keys
 from oracle import cpu_ref as ref
+import bench_inputs
 from tests.oracle_engine import OracleEngine
 
 
@@ -51,7 +52,7 @@ def test_penalties():
 
 @pytest.mark.parametrize("acq", [EI, UCB, POI, UE])
 def test_wrappers_with_mcmc_and_vi_models(acq):
-    X, y, Xn, _ = ref.synthetic_problem(20, 1, 9, seed=2)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(20, 1, 9, seed=2)
     m = ExactGP(1, "RBF")
     m.fit(get_keys()[0], X, y, num_warmup=15, num_samples=15, progress_bar=False, print_summary=False)
     a = acq(get_keys()[1], m, Xn[:, 0], n=2)
@@ -72,7 +73,7 @@ def test_wrappers_with_mcmc_and_vi_models(acq):
 
 
 def test_thompson_shapes():
-    X, y, Xn, _ = ref.synthetic_problem(20, 1, 9, seed=2)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(20, 1, 9, seed=2)
     m = ExactGP(1, "RBF")
     m.fit(get_keys()[0], X, y, num_warmup=15, num_samples=15, progress_bar=False, print_summary=False)
     t = Thompson(get_keys()[1], m, Xn)

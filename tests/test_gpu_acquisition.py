@@ -8,6 +8,7 @@ from gpax_amd.acquisition import EI, POI, UCB, UE
 from gpax_amd.models import ExactGP, viGP
 from gpax_amd.utils.utils import rng_from_key
 from oracle import cpu_ref as ref
+import bench_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -22,8 +23,8 @@ def real_engine(engine):
 @pytest.mark.parametrize("kernel", ["RBF", "Matern"])
 def test_mcmc_model_acquisition_on_hip_predict_matches_the_oracle_chain(kernel):
     N, d, M, S, n = 600, 2, 90, 12, 3
-    X, y, Xn, _ = ref.synthetic_problem(N, d, M, seed=6)
-    th = ref.synthetic_theta_samples(S, d, seed=7)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(N, d, M, seed=6)
+    th = bench_inputs.synthetic_theta_samples(S, d, seed=7)
     m = ExactGP(d, kernel)
     m.X_train, m.y_train = m._set_data(X, y)
     m._samples = {k: v[None] for k, v in th.items()}  # as after fit(): (chains, S, ...)
@@ -45,7 +46,7 @@ def test_mcmc_model_acquisition_on_hip_predict_matches_the_oracle_chain(kernel):
 
 def test_vi_model_acquisition_on_hip_posterior_matches_the_oracle():
     N, d, M = 500, 2, 70
-    X, y, Xn, p = ref.synthetic_problem(N, d, M, seed=8)
+    X, y, Xn, p = bench_inputs.synthetic_problem(N, d, M, seed=8)
     m = viGP(d, "Matern")
     m.X_train, m.y_train = m._set_data(X, y)
     m.kernel_params = {"auto_loc": None}

@@ -5,6 +5,8 @@ import pytest
 
 from oracle import cpu_ref as ref
 
+import bench_inputs
+
 pytestmark = pytest.mark.gpu
 
 
@@ -89,8 +91,8 @@ def test_maximum_input_dimension(engine, kind, name):
 
 def test_means_only_sweep_and_single_sample(engine):
     N, d, M = 90, 2, 21
-    X, y, Xn, p = ref.synthetic_problem(N, d, M, seed=4)
-    th = ref.synthetic_theta_samples(1, d, seed=5)
+    X, y, Xn, p = bench_inputs.synthetic_problem(N, d, M, seed=4)
+    th = bench_inputs.synthetic_theta_samples(1, d, seed=5)
     engine.set_train(X)
     means, draws, infos = engine.predict_sweep(1, th["k_length"], th["k_scale"], th["noise"], y, Xn, True, 1e-6, None)
     assert means.shape == (1, M) and draws.shape == (1, 0, M) and infos[0] == 0
@@ -124,7 +126,7 @@ def test_degenerate_hyperparameters_give_nan_rows_not_crashes(engine):
 
 
 def test_bad_arguments_are_errors_not_crashes(engine):
-    X, y, Xn, p = ref.synthetic_problem(20, 2, 5, seed=1)
+    X, y, Xn, p = bench_inputs.synthetic_problem(20, 2, 5, seed=1)
     engine.set_train(X)
     with pytest.raises(NotImplementedError):
         from gpax_amd import _lib

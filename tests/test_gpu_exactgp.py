@@ -4,6 +4,8 @@ import pytest
 
 from oracle import cpu_ref as ref
 
+import bench_inputs
+
 pytestmark = pytest.mark.gpu
 
 KINDS = [(0, "RBF"), (1, "Matern")]
@@ -16,7 +18,7 @@ def relerr(a, b):
 @pytest.mark.parametrize("kind,name", KINDS)
 @pytest.mark.parametrize("N,d", [(8, 1), (64, 1), (127, 2), (128, 2), (300, 3), (1100, 2)])
 def test_lml_matches_oracle(engine, kind, name, N, d):
-    X, y, _, params = ref.synthetic_problem(N, d, 4, seed=N + d)
+    X, y, _, params = bench_inputs.synthetic_problem(N, d, 4, seed=N + d)
     engine.set_train(X)
     lml, info = engine.factor(kind, params["k_length"], params["k_scale"], params["noise"], 1e-6, y)
     assert info == 0
@@ -27,7 +29,7 @@ def test_lml_matches_oracle(engine, kind, name, N, d):
 @pytest.mark.parametrize("kind,name", KINDS)
 @pytest.mark.parametrize("N,d", [(50, 1), (200, 2), (391, 3)])
 def test_lml_grad_matches_oracle(engine, kind, name, N, d):
-    X, y, _, params = ref.synthetic_problem(N, d, 4, seed=3 * N + d)
+    X, y, _, params = bench_inputs.synthetic_problem(N, d, 4, seed=3 * N + d)
     engine.set_train(X)
     lml, info = engine.factor(kind, params["k_length"], params["k_scale"], params["noise"], 1e-6, y)
     g_ell, g_scale, g_noise, alpha = engine.lml_grad()
@@ -43,7 +45,7 @@ def test_lml_grad_matches_oracle(engine, kind, name, N, d):
 @pytest.mark.parametrize("N,d,M", [(8, 1, 5), (100, 2, 33), (256, 2, 128), (700, 3, 260)])
 @pytest.mark.parametrize("noiseless", [False, True])
 def test_posterior_matches_oracle_inverse_route(engine, kind, name, N, d, M, noiseless):
-    X, y, Xnew, params = ref.synthetic_problem(N, d, M, seed=N + M)
+    X, y, Xnew, params = bench_inputs.synthetic_problem(N, d, M, seed=N + M)
     engine.set_train(X)
     engine.factor(kind, params["k_length"], params["k_scale"], params["noise"], 1e-6, y)
     noise_p = 0.0 if noiseless else params["noise"]
@@ -60,7 +62,7 @@ def test_posterior_matches_oracle_inverse_route(engine, kind, name, N, d, M, noi
 @pytest.mark.parametrize("kind,name", KINDS)
 def test_draw_given_eps_matches_oracle(engine, kind, name):
     N, d, M, n = 150, 2, 70, 5
-    X, y, Xnew, params = ref.synthetic_problem(N, d, M, seed=11)
+    X, y, Xnew, params = bench_inputs.synthetic_problem(N, d, M, seed=11)
     eps = np.random.default_rng(2).standard_normal((n, M))
     engine.set_train(X)
     engine.factor(kind, params["k_length"], params["k_scale"], params["noise"], 1e-6, y)
@@ -73,7 +75,7 @@ def test_draw_given_eps_matches_oracle(engine, kind, name):
 
 def test_noiseless_invariants(engine):
     # gpax/tests/test_gp.py:155-170: same call twice bit-identical; mean(noiseless) == mean(noisy)
-    X, y, Xnew, params = ref.synthetic_problem(90, 1, 40, seed=4)
+    X, y, Xnew, params = bench_inputs.synthetic_problem(90, 1, 40, seed=4)
     engine.set_train(X)
     engine.factor(0, params["k_length"], params["k_scale"], params["noise"], 1e-6, y)
     m1, c1, _ = engine.posterior(Xnew, params["noise"], 1e-6)
@@ -87,7 +89,7 @@ def test_noiseless_invariants(engine):
 
 def test_non_pd_theta_gives_nan_not_crash(engine):
     # gpax/tests/test_gp.py:196-206 feeds N(0,1) "samples": negative variances must not crash
-    X, y, Xnew, params = ref.synthetic_problem(60, 1, 20, seed=8)
+    X, y, Xnew, params = bench_inputs.synthetic_problem(60, 1, 20, seed=8)
     engine.set_train(X)
     lml, info = engine.factor(0, [1.0], -0.7, 0.1, 1e-6, y)
     assert info > 0 and np.isnan(lml)
@@ -96,8 +98,8 @@ def test_non_pd_theta_gives_nan_not_crash(engine):
 @pytest.mark.parametrize("kind,name", KINDS)
 def test_predict_sweep_matches_oracle(engine, kind, name):
     N, d, M, S, n = 200, 3, 90, 6, 2
-    X, y, Xnew, _ = ref.synthetic_problem(N, d, M, seed=21)
-    samples = ref.synthetic_theta_samples(S, d, seed=1)
+    X, y, Xnew, _ = bench_inputs.synthetic_problem(N, d, M, seed=21)
+    samples = bench_inputs.synthetic_theta_samples(S, d, seed=1)
     eps = np.random.default_rng(2).standard_normal((S, n, M))
     engine.set_train(X)
     means, draws, infos = engine.predict_sweep(kind, samples["k_length"], samples["k_scale"], samples["noise"], y,
@@ -110,8 +112,8 @@ def test_predict_sweep_matches_oracle(engine, kind, name):
 
 def test_predict_sweep_bad_sample_is_nan_filled(engine):
     N, d, M, S, n = 80, 1, 30, 3, 1
-    X, y, Xnew, _ = ref.synthetic_problem(N, d, M, seed=5)
-    samples = ref.synthetic_theta_samples(S, d, seed=1)
+    X, y, Xnew, _ = bench_inputs.synthetic_problem(N, d, M, seed=5)
+    samples = bench_inputs.synthetic_theta_samples(S, d, seed=1)
     samples["k_scale"][1] = -1.0
     eps = np.random.default_rng(2).standard_normal((S, n, M))
     engine.set_train(X)
@@ -125,7 +127,7 @@ def test_full_size_roundtrip_properties(engine):
     """C2-size (N=4096) size-independent checks: K alpha = y through the factor, and the
     posterior at the training points reproduces the closed form mean = K_f (K_f + s I)^-1 y."""
     N, d = 4096, 2
-    X, y, _, params = ref.synthetic_problem(N, d, 4, seed=0)
+    X, y, _, params = bench_inputs.synthetic_problem(N, d, 4, seed=0)
     engine.set_train(X)
     lml, info = engine.factor(0, params["k_length"], params["k_scale"], params["noise"], 1e-6, y)
     assert info == 0 and np.isfinite(lml)
@@ -149,8 +151,8 @@ def test_batched_sweep_is_independent_of_batch_size(engine, kind, name, strided,
     # the vmap over samples runs as a grid dimension (B samples per launch): every sample's arithmetic is the
     # single-sample arithmetic, so results must be BIT-identical for any B, including ragged last batches
     N, d, M, S, n = 300, 2, 70, 11, 2
-    X, y, Xnew, params = ref.synthetic_problem(N, d, M, seed=21)
-    th = ref.synthetic_theta_samples(S, d, seed=22)
+    X, y, Xnew, params = bench_inputs.synthetic_problem(N, d, M, seed=21)
+    th = bench_inputs.synthetic_theta_samples(S, d, seed=22)
     rng = np.random.default_rng(23)
     eps = rng.standard_normal((S, n, M))
     yres = y[None, :] + 0.01 * rng.standard_normal((S, N)) if strided else y
@@ -185,7 +187,7 @@ def test_batched_sweep_is_independent_of_batch_size(engine, kind, name, strided,
 def test_fit_batch_equals_single_fit_steps(engine, kind, name, N, d):
     # gpx_fit_batch = B x (gpx_factor + gpx_lml_grad) with the chain as a grid dimension: bit-identical entries
     B = 5
-    X, y, _, params = ref.synthetic_problem(N, d, 4, seed=5 * N + d)
+    X, y, _, params = bench_inputs.synthetic_problem(N, d, 4, seed=5 * N + d)
     rng = np.random.default_rng(N)
     ne = d + (1 if kind == 2 else 0)
     ells = np.tile(np.concatenate([np.broadcast_to(params["k_length"], (d,)), [2.3]])[:ne], (B, 1)) * rng.uniform(0.8, 1.25, (B, ne))
@@ -217,8 +219,8 @@ def test_sliced_sweep_equals_slice_by_slice_sweeps(engine, kind, name, M, ms):
     # predict_in_batches semantics inside one sweep: covariance blocks of `ms` test points share ONE factorisation
     # per sample; every block must equal the sweep run on that slice of X_new alone
     N, d, S, n = 260, 2, 7, 2
-    X, y, Xn, params = ref.synthetic_problem(N, d, M, seed=M + ms)
-    th = ref.synthetic_theta_samples(S, d, seed=3)
+    X, y, Xn, params = bench_inputs.synthetic_problem(N, d, M, seed=M + ms)
+    th = bench_inputs.synthetic_theta_samples(S, d, seed=3)
     rng = np.random.default_rng(4)
     eps = rng.standard_normal((S, n, M))
     yres = y[None, :] + 0.01 * rng.standard_normal((S, N))

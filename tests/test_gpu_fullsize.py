@@ -6,6 +6,8 @@ import pytest
 
 from oracle import cpu_ref as ref
 
+import bench_inputs
+
 pytestmark = pytest.mark.gpu
 
 
@@ -15,7 +17,7 @@ def relerr(a, b):
 
 def test_c3_matern_n16384_roundtrip(engine):
     N, d = 16384, 2
-    X, y, Xn, p = ref.synthetic_problem(N, d, 1024, seed=0)
+    X, y, Xn, p = bench_inputs.synthetic_problem(N, d, 1024, seed=0)
     engine.set_train(X)
     lml, info = engine.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
     assert info == 0 and np.isfinite(lml)
@@ -45,8 +47,8 @@ def test_c3_matern_n16384_roundtrip(engine):
 
 def test_c4_sweep_n8192_d3_properties(engine):
     N, d, M, S = 8192, 3, 1024, 3
-    X, y, Xn, _ = ref.synthetic_problem(N, d, M, seed=0)
-    th = ref.synthetic_theta_samples(S, d, seed=1)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(N, d, M, seed=0)
+    th = bench_inputs.synthetic_theta_samples(S, d, seed=1)
     eps = np.random.default_rng(2).standard_normal((S, 1, M))
     engine.set_train(X)
     m1, d1, i1 = engine.predict_sweep(0, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps)

@@ -5,13 +5,15 @@ import pytest
 
 from oracle import cpu_ref as ref
 
+import bench_inputs
+
 pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("kind,name", [(0, "RBF"), (1, "Matern")])
 @pytest.mark.parametrize("N,d", [(50, 1), (260, 2)])
 def test_gradient_wrt_per_point_diagonal(engine, kind, name, N, d):
-    X, y, _, params = ref.synthetic_problem(N, d, 4, seed=2 * N + d)
+    X, y, _, params = bench_inputs.synthetic_problem(N, d, 4, seed=2 * N + d)
     rng = np.random.default_rng(N)
     lv = rng.normal(-2.0, 0.5, N)
     p = {"k_length": np.broadcast_to(params["k_length"], (d,)).copy(), "k_scale": params["k_scale"], "noise": 0.0}
@@ -43,8 +45,8 @@ def test_gradient_wrt_per_point_diagonal(engine, kind, name, N, d):
 @pytest.mark.parametrize("kind,name", [(0, "RBF"), (1, "Matern")])
 def test_sweep_with_per_sample_predicted_variance(engine, kind, name, monkeypatch):
     N, d, M, S, n = 180, 2, 33, 7, 2
-    X, y, Xn, params = ref.synthetic_problem(N, d, M, seed=31)
-    th = ref.synthetic_theta_samples(S, d, seed=32)
+    X, y, Xn, params = bench_inputs.synthetic_problem(N, d, M, seed=31)
+    th = bench_inputs.synthetic_theta_samples(S, d, seed=32)
     rng = np.random.default_rng(33)
     pv = rng.uniform(0.01, 0.5, (S, M))
     eps = rng.standard_normal((S, n, M))

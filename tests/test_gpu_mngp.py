@@ -5,13 +5,15 @@ import pytest
 
 from oracle import cpu_ref as ref
 
+import bench_inputs
+
 pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("kind,name", [(0, "RBF"), (1, "Matern"), (2, "Periodic")])
 @pytest.mark.parametrize("N,d", [(60, 1), (300, 2)])
 def test_lml_and_gradient_with_measured_noise(engine, kind, name, N, d):
-    X, y, _, params = ref.synthetic_problem(N, d, 4, seed=N + d)
+    X, y, _, params = bench_inputs.synthetic_problem(N, d, 4, seed=N + d)
     rng = np.random.default_rng(N)
     v = rng.uniform(0.01, 0.4, N)
     p = {"k_length": np.broadcast_to(params["k_length"], (d,)).copy(), "k_scale": params["k_scale"], "noise": 0.0}
@@ -51,8 +53,8 @@ def test_lml_and_gradient_with_measured_noise(engine, kind, name, N, d):
 
 def test_sweep_variance_output(engine):
     N, d, M, S = 200, 2, 45, 6
-    X, y, Xn, params = ref.synthetic_problem(N, d, M, seed=9)
-    th = ref.synthetic_theta_samples(S, d, seed=10)
+    X, y, Xn, params = bench_inputs.synthetic_problem(N, d, M, seed=9)
+    th = bench_inputs.synthetic_theta_samples(S, d, seed=10)
     engine.set_train(X)
     for noiseless in (False, True):
         means, _, infos, vars_ = engine.predict_sweep(1, th["k_length"], th["k_scale"], th["noise"], y, Xn, noiseless, 1e-6,

@@ -8,6 +8,7 @@ from gpax_amd.kernels import MaternKernel, RBFKernel
 from gpax_amd.models import ExactGP, viGP
 from gpax_amd.utils import get_keys
 from oracle import cpu_ref as ref
+import bench_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -28,7 +29,7 @@ def test_kernel_callables_on_gpu():
 
 
 def test_c1_exactgp_n512_fit_predict():
-    X, y, Xn, p = ref.synthetic_problem(512, 1, 100, seed=0)
+    X, y, Xn, p = bench_inputs.synthetic_problem(512, 1, 100, seed=0)
     m = ExactGP(1, "RBF")
     m.fit(get_keys()[0], X, y, num_warmup=60, num_samples=60, progress_bar=False, print_summary=False)
     s = m.get_samples()
@@ -48,7 +49,7 @@ def test_c1_exactgp_n512_fit_predict():
 
 
 def test_log_joint_gradient_matches_finite_differences_on_gpu():
-    X, y, _, _ = ref.synthetic_problem(150, 2, 4, seed=2)
+    X, y, _, _ = bench_inputs.synthetic_problem(150, 2, 4, seed=2)
     m = ExactGP(2, "Matern", noise_prior_dist=dist.HalfNormal(0.5))
     m.X_train, m.y_train = m._set_data(X, y)
     sites = m._sites()
@@ -65,7 +66,7 @@ def test_log_joint_gradient_matches_finite_differences_on_gpu():
 
 @pytest.mark.parametrize("guide", ["delta", "normal"])
 def test_vigp_on_gpu(guide):
-    X, y, Xn, _ = ref.synthetic_problem(300, 2, 50, seed=4)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(300, 2, 50, seed=4)
     m = viGP(2, "Matern", guide=guide)
     m.fit(get_keys()[0], X, y, num_steps=100, step_size=0.05, progress_bar=False, print_summary=False)
     s = m.get_samples()
@@ -81,7 +82,7 @@ def test_vigp_on_gpu(guide):
 
 
 def test_get_mvn_posterior_on_gpu_matches_reference_inverse_route():
-    X, y, Xn, p = ref.synthetic_problem(200, 2, 30, seed=6)
+    X, y, Xn, p = bench_inputs.synthetic_problem(200, 2, 30, seed=6)
     m = ExactGP(2, "RBF")
     m.X_train, m.y_train = m._set_data(X, y)
     params = {"k_length": p["k_length"], "k_scale": np.array([p["k_scale"]]), "noise": np.array([p["noise"]])}
@@ -121,7 +122,7 @@ def test_visparsegp_on_gpu(guide):
 
 def test_parallel_chains_on_gpu_match_sequential():
     import time
-    X, y, _, _ = ref.synthetic_problem(256, 1, 4, seed=1)
+    X, y, _, _ = bench_inputs.synthetic_problem(256, 1, 4, seed=1)
     out, dt = [], []
     for method in ["sequential", "parallel"]:
         m = ExactGP(1, "RBF")
@@ -138,7 +139,7 @@ def test_parallel_chains_on_gpu_match_sequential():
 def test_predict_with_threefry_keys_on_gpu():
     # utils.threefry keys: predict's eps are split(key, S) -> normal(key_s, (n, M)), as the reference draws them
     from gpax_amd.utils import threefry as tf
-    X, y, Xn, _ = ref.synthetic_problem(120, 1, 9, seed=2)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(120, 1, 9, seed=2)
     k1, k2 = tf.get_keys(0)
     m = ExactGP(1, "Matern")
     m.fit(k1, X, y, num_warmup=20, num_samples=12, progress_bar=False, print_summary=False)
@@ -171,7 +172,7 @@ def test_sample_from_prior_on_gpu_matches_the_oracle_mvn_sample():
 
 
 def test_model_log_joint_on_gpu():
-    X, y, _, p = ref.synthetic_problem(700, 2, 4, seed=4)
+    X, y, _, p = bench_inputs.synthetic_problem(700, 2, 4, seed=4)
     m = ExactGP(2, "Matern")
     params = {"k_length": p["k_length"], "k_scale": p["k_scale"], "noise": p["noise"]}
     prior = m.model(X, None, params=params)

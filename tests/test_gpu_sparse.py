@@ -6,6 +6,8 @@ import pytest
 
 from oracle import cpu_ref as ref
 
+import bench_inputs
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 KINDS = [(0, "RBF"), (1, "Matern")]
@@ -35,7 +37,7 @@ def test_sparse_bound_and_posterior_golden(engine, kind, name):
 @pytest.mark.parametrize("kind,name", KINDS)
 @pytest.mark.parametrize("N,d,Mi", [(150, 1, 12), (400, 2, 40), (700, 3, 150)])
 def test_sparse_gradient_matches_finite_differences_of_oracle(engine, kind, name, N, d, Mi):
-    X, y, _, p = ref.synthetic_problem(N, d, 4, seed=N + Mi)
+    X, y, _, p = bench_inputs.synthetic_problem(N, d, 4, seed=N + Mi)
     rng = np.random.default_rng(1)
     Xu = X[rng.choice(N, Mi, replace=False)] + 0.05 * rng.standard_normal((Mi, d))
     engine.set_train(X)

@@ -11,6 +11,7 @@ from gpax_amd.models import ExactGP, viGP, viSparseGP
 from gpax_amd.utils import (get_keys, initialize_inducing_points, preprocess_sparse_image, random_sample_dict,
                             split_dict, split_in_batches)
 from oracle import cpu_ref as ref
+import bench_inputs
 from tests.oracle_engine import OracleEngine
 
 
@@ -80,7 +81,7 @@ def test_unsupported_inputs_raise_clearly():
 
 @pytest.mark.parametrize("noiseless", [False, True])
 def test_get_mvn_posterior_matches_oracle_and_invariants(noiseless):
-    X, y, Xn, p = ref.synthetic_problem(40, 2, 12, seed=3)
+    X, y, Xn, p = bench_inputs.synthetic_problem(40, 2, 12, seed=3)
     m = ExactGP(2, "RBF")
     m.X_train, m.y_train = m._set_data(X, y)
     params = {"k_length": np.array([[1.0, 1.25]]), "k_scale": np.array([1.3]), "noise": np.array([0.1])}
@@ -112,8 +113,8 @@ def test_predict_shapes_negative_variances_do_not_crash():
 
 
 def test_predict_in_batches_equals_predict_on_means():
-    X, y, Xn, _ = ref.synthetic_problem(30, 1, 8, seed=5)
-    samples = ref.synthetic_theta_samples(6, 1)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(30, 1, 8, seed=5)
+    samples = bench_inputs.synthetic_theta_samples(6, 1)
     m = ExactGP(1, "Matern")
     m.X_train, m.y_train = m._set_data(X, y)
     key = get_keys()[1]
@@ -125,7 +126,7 @@ def test_predict_in_batches_equals_predict_on_means():
 
 
 def test_predict_with_mean_function_and_prior():
-    X, y, Xn, _ = ref.synthetic_problem(30, 1, 8, seed=6)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(30, 1, 8, seed=6)
     y = y + 2.0 * X[:, 0]
     mean_fn = lambda x, p: p["a"] * x[:, 0]
     m = ExactGP(1, "RBF", mean_fn=mean_fn, mean_fn_prior={"a": dist.Normal(2.0, 0.5)})
@@ -155,7 +156,7 @@ def test_sample_from_prior_shape():
 
 @pytest.mark.parametrize("guide", ["delta", "normal"])
 def test_vigp_fit_predict(guide):
-    X, y, Xn, p = ref.synthetic_problem(40, 1, 10, seed=8)
+    X, y, Xn, p = bench_inputs.synthetic_problem(40, 1, 10, seed=8)
     m = viGP(1, "Matern", guide=guide)
     m.fit(get_keys()[0], X, y, num_steps=60, step_size=0.05, progress_bar=False, print_summary=(guide == "delta"))
     assert m.svi is not None
@@ -178,7 +179,7 @@ def test_vigp_fit_predict(guide):
 
 
 def test_vigp_same_key_identical_and_guides_differ():
-    X, y, Xn, _ = ref.synthetic_problem(25, 1, 5, seed=9)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(25, 1, 5, seed=9)
     res = []
     for guide in ["delta", "delta", "normal"]:
         m = viGP(1, "RBF", guide=guide)
@@ -237,7 +238,7 @@ def test_utils_match_reference_behaviour():
 @pytest.mark.parametrize("guide", ["delta", "normal"])
 def test_visparsegp_fit_predict(guide):
     # gpax/tests/test_sparsegp.py:26-64: Xu is an array, is optimised, posterior shapes
-    X, y, Xn, _ = ref.synthetic_problem(24, 1, 7, seed=4)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(24, 1, 7, seed=4)
     key = get_keys()[0]
     m1 = viSparseGP(1, "Matern", guide=guide)
     m1.fit(key, X, y, inducing_points_ratio=0.2, num_steps=1, progress_bar=False, print_summary=False)
@@ -296,7 +297,7 @@ def test_periodic_kernel_model_surface():
 def test_predict_in_batches_equals_slice_by_slice_predict():
     # gp.py:325-349: predict per slice of X_new with the SAME key; the default path runs them as covariance blocks of
     # one sweep (one factorisation per sample) and must return exactly what the slice-by-slice loop returns
-    X, y, Xn, p = ref.synthetic_problem(40, 2, 23, seed=3)
+    X, y, Xn, p = bench_inputs.synthetic_problem(40, 2, 23, seed=3)
     rng = np.random.default_rng(0)
     samples = {"k_length": np.exp(0.2 * rng.standard_normal((6, 2))), "k_scale": np.exp(0.2 * rng.standard_normal(6)),
                "noise": 0.1 * np.exp(0.2 * rng.standard_normal(6))}
@@ -316,7 +317,7 @@ def test_predict_in_batches_equals_slice_by_slice_predict():
 
 
 def test_predict_in_batches_groups_of_slices_give_the_same_values(monkeypatch):
-    X, y, Xn, p = ref.synthetic_problem(30, 1, 47, seed=5)
+    X, y, Xn, p = bench_inputs.synthetic_problem(30, 1, 47, seed=5)
     rng = np.random.default_rng(1)
     samples = {"k_length": np.exp(0.2 * rng.standard_normal((4, 1))), "k_scale": np.exp(0.2 * rng.standard_normal(4)),
                "noise": 0.1 * np.exp(0.2 * rng.standard_normal(4))}
@@ -477,7 +478,7 @@ def test_mean_fn_prior_callable_and_exact_mean_gradient():
 
 def test_model_returns_the_log_joint():
     """ExactGP.model (gp.py:137-164) = priors + MVN likelihood; evaluated at given params, y = None: priors only."""
-    X, y, _, p = ref.synthetic_problem(30, 2, 4, seed=2)
+    X, y, _, p = bench_inputs.synthetic_problem(30, 2, 4, seed=2)
     m = ExactGP(2, "Matern", noise_prior_dist=dist.HalfNormal(0.5))
     params = {"k_length": np.array([1.0, 1.25]), "k_scale": 1.3, "noise": 0.1}
     lp = dist.LogNormal(0, 1).log_prob(np.array([1.0, 1.25])).sum() + dist.LogNormal(0, 1).log_prob(np.array([1.3]))[0] \

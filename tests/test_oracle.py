@@ -12,6 +12,8 @@ import scipy.stats
 
 from oracle import cpu_ref as ref
 
+import bench_inputs
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -63,7 +65,7 @@ def test_matern_diagonal_uses_sqrt_eps():
 
 @pytest.mark.parametrize("name", ["RBF", "Matern"])
 def test_lml_vs_scipy_multivariate_normal(name):
-    X, y, _, p = ref.synthetic_problem(120, 2, 4, seed=3)
+    X, y, _, p = bench_inputs.synthetic_problem(120, 2, 4, seed=3)
     K = ref.get_kernel(name)(X, X, p, p["noise"], jitter=1e-6)
     expect = scipy.stats.multivariate_normal(mean=np.zeros(120), cov=K, allow_singular=False).logpdf(y)
     got = ref.exactgp_log_likelihood(X, y, p, kernel=name)
@@ -72,7 +74,7 @@ def test_lml_vs_scipy_multivariate_normal(name):
 
 @pytest.mark.parametrize("name", ["RBF", "Matern"])
 def test_gradient_vs_central_differences(name):
-    X, y, _, p = ref.synthetic_problem(80, 2, 4, seed=5)
+    X, y, _, p = bench_inputs.synthetic_problem(80, 2, 4, seed=5)
     g_ell, g_s, g_n, alpha = ref.exactgp_log_likelihood_grad(X, y, p, kernel=name)
     base = np.concatenate([p["k_length"], [p["k_scale"], p["noise"]]])
 
@@ -94,7 +96,7 @@ def test_gradient_vs_central_differences(name):
 @pytest.mark.parametrize("name", ["RBF", "Matern"])
 @pytest.mark.parametrize("noiseless", [False, True])
 def test_posterior_inverse_route_equals_cholesky_route(name, noiseless):
-    X, y, Xn, p = ref.synthetic_problem(256, 2, 100, seed=7)
+    X, y, Xn, p = bench_inputs.synthetic_problem(256, 2, 100, seed=7)
     m1, c1 = ref.get_mvn_posterior(X, y, Xn, p, noiseless, kernel=name, route="inv")
     m2, c2 = ref.get_mvn_posterior(X, y, Xn, p, noiseless, kernel=name, route="chol")
     assert np.linalg.norm(m1 - m2) <= 1e-11 * np.linalg.norm(m1)
@@ -102,7 +104,7 @@ def test_posterior_inverse_route_equals_cholesky_route(name, noiseless):
 
 
 def test_posterior_with_mean_function():
-    X, y, Xn, p = ref.synthetic_problem(60, 1, 25, seed=2)
+    X, y, Xn, p = bench_inputs.synthetic_problem(60, 1, 25, seed=2)
     p = dict(p, a=0.7)
     mean_fn = lambda x, prm: prm["a"] * x[:, 0]
     m, c = ref.get_mvn_posterior(X, y + 0.7 * X[:, 0], Xn, p, mean_fn=mean_fn, mean_fn_has_params=True)
@@ -119,7 +121,7 @@ def test_lowrank_mvn_vs_dense():
 
 
 def test_sparse_posterior_tends_to_exact_when_inducing_equals_train():
-    X, y, Xn, p = ref.synthetic_problem(40, 1, 15, seed=1)
+    X, y, Xn, p = bench_inputs.synthetic_problem(40, 1, 15, seed=1)
     m_s, c_s = ref.sparse_posterior(X, y, X.copy(), Xn, p, kernel="RBF", jitter=1e-8)
     m_e, c_e = ref.get_mvn_posterior(X, y, Xn, p, kernel="RBF", jitter=1e-6)
     np.testing.assert_allclose(m_s, m_e, rtol=1e-4, atol=1e-5)
@@ -163,7 +165,7 @@ def test_utils_restatement():
 def test_full_pass_equals_the_separate_restatements():
     """exactgp_full_pass (one factorisation; used by the full-size GPU parity tests) is the arithmetic of
     exactgp_log_likelihood + get_mvn_posterior(route='chol') + mvn_sample, bit for bit."""
-    X, y, Xn, p = ref.synthetic_problem(150, 2, 40, seed=11)
+    X, y, Xn, p = bench_inputs.synthetic_problem(150, 2, 40, seed=11)
     eps = np.random.default_rng(0).standard_normal((3, 40))
     for name in ("RBF", "Matern"):
         lml, mean, cov, draws, alpha = ref.exactgp_full_pass(X, y, Xn, p, eps, False, kernel=name)

@@ -32,10 +32,11 @@ def _free_port():
 
 def _problem():
     from oracle import cpu_ref as ref
+    import bench_inputs
 
     N, d, M, S, n = 60, 2, 17, 5, 2
-    X, y, Xn, _ = ref.synthetic_problem(N, d, M, seed=3)
-    samples = ref.synthetic_theta_samples(S, d, seed=1)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(N, d, M, seed=3)
+    samples = bench_inputs.synthetic_theta_samples(S, d, seed=1)
     eps = np.random.default_rng(2).standard_normal((S, n, M))
     return X, y, Xn, samples, eps
 

@@ -5,11 +5,11 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 from gpax_amd import ExactGP, _lib
 from gpax_amd.utils import get_keys
-import bench_inputs as ref  # BASELINE.md 3 workloads
+import bench_inputs  # BASELINE.md 3 workloads
 S = int(os.environ.get("S", "1000"))
 N, d, M = 8192, 3, 1024
-X, y, Xn, p = ref.synthetic_problem(N, d, M, seed=0)
-th = ref.synthetic_theta_samples(S, d, seed=1)
+X, y, Xn, p = bench_inputs.synthetic_problem(N, d, M, seed=0)
+th = bench_inputs.synthetic_theta_samples(S, d, seed=1)
 m = ExactGP(d, "Matern")
 m.X_train, m.y_train = m._set_data(X, y)
 samples = {"k_length": th["k_length"], "k_scale": th["k_scale"], "noise": th["noise"]}

@@ -5,12 +5,12 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 from gpax_amd import ExactGP, viGP
 from gpax_amd.utils import get_keys
-import bench_inputs as ref  # BASELINE.md 3 workloads
+import bench_inputs  # BASELINE.md 3 workloads
 out = []
 for name, kernel, N, nuts, svi in [("C2", "RBF", 4096, (20, 20), 100), ("C3", "Matern", 16384, (5, 5), 30)]:
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         continue
-    X, y, Xn, p = ref.synthetic_problem(N, 2, 1024, seed=0)
+    X, y, Xn, p = bench_inputs.synthetic_problem(N, 2, 1024, seed=0)
     k1, k2 = get_keys()
     m = ExactGP(2, kernel)
     t0 = time.perf_counter()

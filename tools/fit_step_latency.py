@@ -4,9 +4,10 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 from gpax_amd import _lib
 from oracle import cpu_ref as ref
+import bench_inputs
 eng = _lib.Engine(0)
 for N, d in [(128, 1), (256, 1), (512, 1), (1024, 2), (2048, 2), (4096, 2)]:
-    X, y, Xn, p = ref.synthetic_problem(N, d, 16, seed=0)
+    X, y, Xn, p = bench_inputs.synthetic_problem(N, d, 16, seed=0)
     eng.set_train(X)
     eng.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
     eng.lml_grad()

@@ -9,6 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpax_amd import _lib  # noqa: E402
 from oracle import cpu_ref as ref  # noqa: E402  (synthetic inputs only)
+import bench_inputs
 
 
 def main():
@@ -30,7 +31,7 @@ def main():
     for N in sizes:
         d, M = 2, 1024
         kind = 0 if N <= 4096 else 1
-        X, y, Xnew, p = ref.synthetic_problem(N, d, M, seed=0)
+        X, y, Xnew, p = bench_inputs.synthetic_problem(N, d, M, seed=0)
         eng.set_train(X)
         t0 = time.time()
         lml, info = eng.factor(kind, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)

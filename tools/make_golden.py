@@ -13,6 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import cpu_ref as ref  # noqa: E402
+import bench_inputs
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -46,7 +47,7 @@ def lml_cases():
     cid = 0
     for name in ["RBF", "Matern"]:
         for (N, d) in [(64, 1), (200, 2), (512, 3)]:
-            X, y, _, p = ref.synthetic_problem(N, d, 4, seed=N + d)
+            X, y, _, p = bench_inputs.synthetic_problem(N, d, 4, seed=N + d)
             for k in range(2):
                 rng = np.random.default_rng(7 * N + k)
                 p2 = {"k_length": p["k_length"] * np.exp(0.3 * rng.standard_normal(d)),
@@ -70,7 +71,7 @@ def posterior_cases():
     cid = 0
     for name in ["RBF", "Matern"]:
         for (N, d, M) in [(50, 1, 20), (128, 2, 64), (300, 3, 70)]:
-            X, y, Xn, p = ref.synthetic_problem(N, d, M, seed=N + M)
+            X, y, Xn, p = bench_inputs.synthetic_problem(N, d, M, seed=N + M)
             for noiseless in [0, 1]:
                 for jitter in [1e-6, 1e-5]:
                     mean, cov = ref.get_mvn_posterior(X, y, Xn, p, bool(noiseless), kernel=name, jitter=jitter,
@@ -89,8 +90,8 @@ def posterior_cases():
 
 def sweep_case():
     N, d, M, S, n = 200, 3, 48, 16, 2
-    X, y, Xn, _ = ref.synthetic_problem(N, d, M, seed=21)
-    samples = ref.synthetic_theta_samples(S, d, seed=1)
+    X, y, Xn, _ = bench_inputs.synthetic_problem(N, d, M, seed=21)
+    samples = bench_inputs.synthetic_theta_samples(S, d, seed=1)
     eps = np.random.default_rng(2).standard_normal((S, n, M))
     out = {"X": X, "y": y, "Xn": Xn, "eps": eps, **{f"s_{k}": v for k, v in samples.items()}}
     for name in ["RBF", "Matern"]:
@@ -102,7 +103,7 @@ def sweep_case():
 def sparse_cases():
     out = {}
     N, d, M, Mi = 300, 2, 40, 30
-    X, y, Xn, p = ref.synthetic_problem(N, d, M, seed=9)
+    X, y, Xn, p = bench_inputs.synthetic_problem(N, d, M, seed=9)
     Xu = X[np.random.default_rng(3).choice(N, Mi, replace=False)]
     out.update({"X": X, "y": y, "Xn": Xn, "Xu": Xu,
                 "theta": np.concatenate([p["k_length"], [p["k_scale"], p["noise"]]])})

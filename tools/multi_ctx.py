@@ -4,13 +4,14 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 from gpax_amd import _lib
 from oracle import cpu_ref as ref
+import bench_inputs
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 M = 1024
 kind = 1
-X, y, Xn, p = ref.synthetic_problem(N, d, M, seed=0)
+X, y, Xn, p = bench_inputs.synthetic_problem(N, d, M, seed=0)
 K = 24
-th = ref.synthetic_theta_samples(K + 4, d, seed=1)
+th = bench_inputs.synthetic_theta_samples(K + 4, d, seed=1)
 def setup():
     e = _lib.Engine(0); e.set_train(X); e.factor(kind, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
     e.posterior(Xn, p["noise"], 1e-6, want_cov=True); e.mvn_draw(np.zeros((1, M)))

@@ -6,9 +6,10 @@ sys.path.insert(0, os.getcwd())
 from gpax_amd import ExactGP
 from gpax_amd.utils import get_keys
 from oracle import cpu_ref as ref
+import bench_inputs
 for N, M, bs, S in [(1024, 10000, 1000, 200), (4096, 8000, 1000, 60), (8192, 8000, 1000, 30)]:
-    X, y, Xn, p = ref.synthetic_problem(N, 2, M, seed=0)
-    th = ref.synthetic_theta_samples(S, 2, seed=1)
+    X, y, Xn, p = bench_inputs.synthetic_problem(N, 2, M, seed=0)
+    th = bench_inputs.synthetic_theta_samples(S, 2, seed=1)
     m = ExactGP(2, "Matern")
     m.X_train, m.y_train = m._set_data(X, y)
     key = get_keys()[1]

@@ -4,6 +4,7 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 from gpax_amd import _lib
 from oracle import cpu_ref as ref
+import bench_inputs
 kind = 1
 S = int(os.environ.get("S", "1024"))
 ctxs = [int(c) for c in os.environ.get("CTX", "1,3,6,8,12").split(",")]
@@ -12,8 +13,8 @@ SIZES = [(256, 1, 100), (512, 1, 100), (1024, 2, 256), (2048, 2, 1024), (4096, 2
 if os.environ.get("SIZES"):  # e.g. SIZES=512,1,100
     SIZES = [tuple(int(v) for v in os.environ["SIZES"].split(","))]
 for N, d, M in SIZES:
-    X, y, Xn, p = ref.synthetic_problem(N, d, M, seed=0)
-    th = ref.synthetic_theta_samples(S, d, seed=1)
+    X, y, Xn, p = bench_inputs.synthetic_problem(N, d, M, seed=0)
+    th = bench_inputs.synthetic_theta_samples(S, d, seed=1)
     eps = np.random.default_rng(2).standard_normal((S, 1, M))
     for n in ctxs:
         _lib.concurrent_sweep(engs[:n], X, kind, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps)  # warm (allocations)

@@ -5,6 +5,7 @@ sys.path.insert(0, os.getcwd())
 from gpax_amd import ExactGP, _lib
 from gpax_amd.utils import get_keys
 from oracle import cpu_ref as ref
+import bench_inputs
 
 
 def vram_used():
@@ -22,8 +23,8 @@ t_first, t_last = {}, {}
 print(f"start: VRAM used {vram_used():.0f} MiB", flush=True)
 for rnd in range(int(os.environ.get("ROUNDS", "40"))):
     for (N, d, M) in sizes:
-        X, y, Xn, p = ref.synthetic_problem(N, d, M, seed=N)
-        th = ref.synthetic_theta_samples(64, d, seed=1)
+        X, y, Xn, p = bench_inputs.synthetic_problem(N, d, M, seed=N)
+        th = bench_inputs.synthetic_theta_samples(64, d, seed=1)
         eps = rng.standard_normal((64, 1, M))
         t0 = time.perf_counter()
         eng.set_train(X)

@@ -4,10 +4,11 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 from gpax_amd import _lib
 from oracle import cpu_ref as ref
+import bench_inputs
 N, d, M = 16384, 2, 1024
-X, y, Xn, p = ref.synthetic_problem(N, d, M, seed=0)
+X, y, Xn, p = bench_inputs.synthetic_problem(N, d, M, seed=0)
 K = 12
-th = ref.synthetic_theta_samples(2 * K + 4, d, seed=1)
+th = bench_inputs.synthetic_theta_samples(2 * K + 4, d, seed=1)
 def setup():
     e = _lib.Engine(0); e.set_train(X); e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
     e.posterior(Xn, p["noise"], 1e-6, want_cov=True); e.mvn_draw(np.zeros((1, M)))
