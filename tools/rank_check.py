@@ -38,12 +38,15 @@ def main():
         (3100, 2, 130, 2 * env.world + 1, 2, 1, False, 0, True, False),
         (300, 2, 40, max(1, env.world - 1), 1, 1, False, 0, False, False),  # an empty block on the last rank
         (500, 2, 64, 3 * env.world, 0, 1, False, 0, True, False),           # variances only
+        (260, 2, 48, 2 * env.world + 1, 1, 2, False, 0, False, False),      # periodic kernel: d + 1 values per theta
     ]
     for ci, (N, d, M, S, n, kind, per_y, m_slice, want_var, bad) in enumerate(cases):
         kw = {}
         if root:
             X, y, Xn, _ = synthetic_problem(N, d, M, seed=5 + ci)
             th = synthetic_theta_samples(S, d, seed=6 + ci)
+            if kind == 2:  # packed (lengthscales.., period)
+                th["k_length"] = np.concatenate([th["k_length"], np.full((S, 1), 2.5) + 0.1 * np.arange(S)[:, None]], axis=1)
             if bad:
                 th["k_scale"][S // 2] = -1.0  # not positive definite: NaN rows + info, never an abort
             eps = np.random.default_rng(7 + ci).standard_normal((S, n, M)) if n else None
