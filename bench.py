@@ -339,7 +339,9 @@ def multi_rank(a, env):
     root = rank == 0
     if world != a.gpus and root:
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
-    device = 0 if a.share_gpu else env.local_rank
+    # LOCAL_RANK names the GPU; a launcher that narrows HIP_VISIBLE_DEVICES per rank leaves one visible device (ordinal 0)
+    n_vis = max(1, _lib.visible_device_count())
+    device = 0 if a.share_gpu else (env.local_rank if env.local_rank < n_vis else env.local_rank % n_vis)
     transport = a.transport or ("file" if a.share_gpu else None)
     K, W = a.steps, a.warmup
     n_fl = max(1, min(a.inflight, max(1, K // 2)))

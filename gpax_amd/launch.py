@@ -110,6 +110,13 @@ def init_rank(env: RankEnv, device: Optional[int] = None, inflight: Optional[int
     file transport instead of exiting (launch-script use: bench.py).
     make_rank(device, rank, world, unique_id, file_dir, inflight) / make_uid(): injection points for the tests.
     """
+    if device is None:  # LOCAL_RANK names the GPU, unless the launcher narrowed the visible devices per rank
+        device = env.local_rank
+        if make_rank is None:
+            from . import _lib as _l
+            n_vis = max(1, _l.visible_device_count())
+            device = device if device < n_vis else device % n_vis
+    device = int(device)
     if make_rank is None or make_uid is None:
         from . import _lib
         make_rank = make_rank or (lambda dev, r, w, uid, fdir, infl: _lib.Rank(dev, r, w, unique_id=uid, file_dir=fdir,
@@ -118,7 +125,7 @@ def init_rank(env: RankEnv, device: Optional[int] = None, inflight: Optional[int
     transport = (transport or os.environ.get("GPX_RANK_TRANSPORT") or "auto").lower()
     if transport not in ("auto", "rccl", "file"):
         raise ValueError(f"transport {transport!r}")
-    device = env.local_rank if device is None else int(device)
+
     t_start = time.time()
     store = FileStore(os.path.join(env.rdzv_dir, f"attempt{env.attempt}"), fresh_after=t_start - 300.0)
     xfer_dir = os.path.join(store.dir, "xfer")
