@@ -19,8 +19,9 @@ gpax_amd/launch.py) and the timed region is ONE collective gpx_rank_predict_swee
 rank 0's H2D of the inputs, ncclBroadcast over xGMI, every rank's block of K samples, ncclSend / ncclRecv gather, D2H
 on rank 0 — bracketed by a barrier on both sides (gpx_rank_barrier: own contexts synchronised + all-reduce), time =
 max over ranks (gpx_rank_allreduce_max).  A second record, `c4_sweep`, times BASELINE.json configs[3] (S = 1000,
-N = 8192, d = 3) the same way and against rank 0 alone.  `multi_gpu_path` says which transport ran ("rank-rccl";
-"rank-file" = the library's file transport, the fallback when RCCL cannot initialise).
+N = 8192, d = 3) the same way and against rank 0 alone; a third, `node_sweep`, times both sweeps under the other launch
+model (ONE process owning all N GPUs, gpx_predict_sweep_multi) from a child process of rank 0.  `multi_gpu_path` says
+which transport ran ("rank-rccl"; "rank-file" = the library's file transport, the fallback when RCCL cannot initialise).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -54,6 +55,10 @@ def parse():
                     "rank communicator (default: $GPX_RANK_TRANSPORT or auto = RCCL, file on failure)")
     ap.add_argument("--c4-S", type=int, default=1000, help="N > 1: samples of the C4 record (0: skip it)")
     ap.add_argument("--c4-N", type=int, default=8192)
+    ap.add_argument("--node-record", action="store_true", help="internal: time the ONE-process node sweep "
+                    "(gpx_predict_sweep_multi over --gpus devices) and print its record; rank 0 of an N > 1 run "
+                    "starts this as a child process")
+    ap.add_argument("--no-node-record", action="store_true", help="N > 1: skip the node-sweep record")
     ap.add_argument("--force-rank-path", action="store_true", help="run the N > 1 code path whatever the world size "
                     "(1 rank over RCCL on a 1-GPU box)")
     ap.add_argument("--init-timeout", type=float, default=120.0, help="N > 1: seconds before a hung RCCL "
@@ -330,6 +335,73 @@ def single_gpu(a, device=0):
     print(json.dumps(out), flush=True)
 
 
+def node_record(a):
+    """The OTHER launch model of the same sharded sweep, for the record of an N > 1 run: ONE process owning all N GPUs
+    (gpx_node_* / gpx_predict_sweep_multi: ncclCommInitAll, ncclBroadcast, per-GPU host threads, ncclSend / ncclRecv
+    gather; gpax/models/gp.py:392-395).  Same C3 sweep (S = N * K theta samples, host arrays in and out) and the C4
+    sweep.  Prints one JSON object."""
+    from bench_inputs import synthetic_problem, synthetic_theta_samples
+    from gpax_amd import _lib
+
+    G, K, W = a.gpus, a.steps, a.warmup
+    kind = _lib.kernel_kind(a.kernel)
+    devices = [0] * G if a.share_gpu else list(range(G))
+    t0 = time.perf_counter()
+    node = _lib.Node(devices, inflight=max(1, min(a.inflight, max(1, K // 2))))
+    rec = {"model": "one process, all GPUs (gpx_predict_sweep_multi)", "ngpu": G, "init_s": time.perf_counter() - t0}
+    rec.update({k: v for k, v in node.info().items() if k in ("transport", "rccl_version", "inflight")})
+    X, y, Xnew, _ = synthetic_problem(a.N, a.d, a.M, seed=0)
+    th = synthetic_theta_samples(G * (K + W), a.d, seed=1)
+    eps = np.random.default_rng(2).standard_normal((G * (K + W), 1, a.M))
+
+    def sweep(lo, hi):
+        return node.predict_sweep(X, kind, th["k_length"][lo:hi], th["k_scale"][lo:hi], th["noise"][lo:hi], y, Xnew, False,
+                                  1e-6, eps[lo:hi])
+
+    if W > 0:
+        sweep(0, G * W)
+    t0 = time.perf_counter()
+    res = sweep(G * W, G * (W + K))
+    dt = time.perf_counter() - t0
+    rec.update({"c3_seconds": dt, "c3_posteriors_per_s": G * K / dt, "c3_ms_per_step": dt / K * 1e3,
+                "c3_nan_rows": int(np.isnan(res[1]).any(axis=(1, 2)).sum())})
+    if a.c4_S > 0:
+        N4, d4, M4, S4 = a.c4_N, 3, 1024, a.c4_S
+        X4, y4, Xn4, _ = synthetic_problem(N4, d4, M4, seed=0)
+        th4 = synthetic_theta_samples(S4, d4, seed=1)
+        eps4 = np.random.default_rng(2).standard_normal((S4, 1, M4))
+        w = min(S4, 24 * G)
+        node.predict_sweep(X4, kind, th4["k_length"][:w], th4["k_scale"][:w], th4["noise"][:w], y4, Xn4, False, 1e-6, eps4[:w])
+        t0 = time.perf_counter()
+        r4 = node.predict_sweep(X4, kind, th4["k_length"], th4["k_scale"], th4["noise"], y4, Xn4, False, 1e-6, eps4)
+        dt4 = time.perf_counter() - t0
+        rec.update({"c4_S": S4, "c4_seconds": dt4, "c4_posteriors_per_s": S4 / dt4,
+                    "c4_nan_rows": int(np.isnan(r4[1]).any(axis=(1, 2)).sum()),
+                    "c4_checksum": float(np.nansum(r4[0]) + np.nansum(r4[1]))})
+    node.close()
+    print(json.dumps(rec), flush=True)
+
+
+def run_node_record(a):
+    """Rank 0 of an N > 1 run: the node-sweep record from a CHILD process with a time limit, so that a communicator that
+    cannot be formed there (or hangs) costs this run a note, not its result."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--node-record", "--gpus", str(a.gpus), "--steps", str(a.steps),
+           "--warmup", str(a.warmup), "--N", str(a.N), "--d", str(a.d), "--M", str(a.M), "--kernel", a.kernel,
+           "--inflight", str(a.inflight), "--c4-S", str(a.c4_S), "--c4-N", str(a.c4_N)] + (["--share-gpu"] if a.share_gpu else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GPX_RDZV_DIR", "GPX_RANK_TRANSPORT")}
+    if a.share_gpu:
+        env["GPX_NODE_TRANSPORT"] = "memcpy"  # RCCL refuses one device listed twice
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if out.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": f"exit code {out.returncode}", "stderr_tail": out.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within 300 s (child stopped)"}
+
+
 def multi_rank(a, env):
     """N > 1: one process per GPU over the library's own communicator (module docstring)."""
     from bench_inputs import synthetic_problem, synthetic_theta_samples
@@ -430,7 +502,20 @@ def multi_rank(a, env):
         out.update(device_record(eng, a, lml))
         if c4 is not None:
             out["c4_sweep"] = c4
+        if not a.no_node_record:
+            # the same sweeps under the other launch model (one process, all GPUs); the ranks idle meanwhile — on the
+            # host (they poll the rendezvous store below), not inside an RCCL collective that would spin on their GPUs
+            out["node_sweep"] = run_node_record(a)
+            ns = out["node_sweep"]
+            if "c3_posteriors_per_s" in ns:
+                ns["c3_vs_rank_collective"] = ns["c3_posteriors_per_s"] / out["value"]
         print(json.dumps(out), flush=True)
+    # rank 0's solo phase (device record, node-sweep record) is over: everybody meets again
+    store = launch.FileStore(os.path.join(env.rdzv_dir, f"bench{env.attempt}"))
+    if root:
+        store.set("solo_done", b"1")
+    else:
+        store.get("solo_done", timeout=1800.0)
     launch.finalize(env, rk)
 
 
@@ -439,6 +524,9 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL across processes needs here
     from gpax_amd import launch
 
+    if a.node_record:
+        node_record(a)
+        return
     env = launch.rank_env()
     if env is None and a.gpus > 1:
         # started plainly: launch the N ranks ourselves (one process per GPU; no torch anywhere)

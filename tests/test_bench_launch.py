@@ -49,6 +49,9 @@ def test_two_ranks_sharing_the_gpu_report_n_gpus_2():
     assert rec["roofline"]["frac"] > 0
     c4 = rec["c4_sweep"]
     assert c4["S"] == 12 and c4["identical_to_one_gpu"] and c4["speedup_vs_1"] > 0 and c4["ranks"] == 2
+    ns = rec["node_sweep"]  # the one-process launch model of the same sweeps, from a child process of rank 0
+    assert ns["ngpu"] == 2 and ns["transport"] == "memcpy" and ns["c3_posteriors_per_s"] > 0 and ns["c3_nan_rows"] == 0
+    assert ns["c4_S"] == 12 and ns["c4_nan_rows"] == 0
 
 
 @pytest.mark.gpu
