@@ -157,6 +157,7 @@ struct gpx_ctx {
   bool potf2_diag_blocked = false; // GPX_POTF2_DIAG=blocked: the 16 x 16 diagonal tiles factored four columns per LDS round trip (bit-identical, slower)
   bool potf2_chain = true;        // GPX_POTF2=tile: the four-phase kernel of round 2 instead of the wave-specialised one (potf2_chain.h)
   bool potf2_column = false;      // GPX_POTF2=column: the column-by-column diagonal-block kernel of round 1
+  int small_bk = 16;              // GPX_SMALL_BK=32: k-step of the latency shapes (experiment)
   bool gemm_small = true;         // GPX_GEMM_SMALL=0: no latency shapes
   double small_tiles_max = 400.0; // GPX_SMALL_TILES_MAX: launches with fewer 128x128 tiles take the latency shapes
   int far_after_u1 = 40; // GPX_FAR_AFTER_U1: tile rows below which the (single-sample) far update waits for U1 of the same block (0: never)

@@ -303,7 +303,8 @@ static TileMap make_tile_map(const GemmArgs& g, int tiles_m, int tiles_n) {
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a function: every context sets it once
 // for each variant it launches (a process may hold contexts on several GPUs; contexts are also driven from
 // different host threads, so the "done" bits live in the context, not in a function-local static).
-enum : unsigned { ATTR_SMALL_22 = 0, ATTR_SMALL_24 = 1, ATTR_BIG_BASE = 2 /* + 3 * TAG + EPI */, ATTR_PERSIST_BASE = 8, ATTR_SWZ_BASE = 14 };
+enum : unsigned { ATTR_SMALL_22 = 0, ATTR_SMALL_24 = 1, ATTR_BIG_BASE = 2 /* + 3 * TAG + EPI */, ATTR_PERSIST_BASE = 8, ATTR_SWZ_BASE = 14,
+                  ATTR_SMALL_22_BK32 = 20, ATTR_SMALL_24_BK32 = 21 };
 
 template <int TAG, int MT, int NT, int BK, bool DBUF>
 static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int tiles_n, int splits) {
@@ -311,7 +312,7 @@ static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int til
   g.nsplit = splits > 0 ? splits : 1;
   if (g.batch < 1) g.batch = 1;
   constexpr size_t lds = gemm_lds_bytes<MT, NT, BK, DBUF>();
-  constexpr unsigned bit = 1u << ((NT == 2) ? ATTR_SMALL_22 : ATTR_SMALL_24);
+  constexpr unsigned bit = 1u << (BK == 32 ? ((NT == 2) ? ATTR_SMALL_22_BK32 : ATTR_SMALL_24_BK32) : ((NT == 2) ? ATTR_SMALL_22 : ATTR_SMALL_24));
   if (!(ctx->func_attr_mask & bit)) {
     GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<TAG, MT, NT, BK, DBUF>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -436,9 +437,13 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
       // 32x128 strip, single LDS buffer: 22 KB and < 80 VGPRs, i.e. it fits in what two resident trailing-update
       // workgroups leave free on a CU (32 KB, 80 registers per SIMD) and is placed at once; the round-1 64x128 shape
       // (52 KB, 125 VGPRs) had to wait for a trailing workgroup to retire — half a tile time (~50 us) per panel step
-      if (tiles_n == 1) return launch_variant<0, 1, 4, 16, false>(ctx, g, tiles_m, tiles_n, splits);
+      if (tiles_n == 1)
+        return (ctx->small_bk == 32 && g.K % 32 == 0) ? launch_variant<0, 1, 4, 32, false>(ctx, g, tiles_m, tiles_n, splits)
+                                                      : launch_variant<0, 1, 4, 16, false>(ctx, g, tiles_m, tiles_n, splits);
     } else {
-      return launch_variant<0, 2, 2, 16, false>(ctx, g, tiles_m, tiles_n, splits);
+      return (ctx->small_bk == 32 && g.K % 32 == 0 && !g.ktri && !g.kupper && g.kchunk % 32 == 0)
+                 ? launch_variant<0, 2, 2, 32, false>(ctx, g, tiles_m, tiles_n, splits)
+                 : launch_variant<0, 2, 2, 16, false>(ctx, g, tiles_m, tiles_n, splits);
     }
   }
   return launch_big<0>(ctx, g, tiles_m, tiles_n, splits);

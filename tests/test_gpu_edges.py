@@ -177,13 +177,14 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
                 dict(GPX_TILE_SWIZZLE="3", GPX_TILE_SWIZZLE_MIN="64"), dict(GPX_FAR_AFTER_U1="0"), dict(GPX_FAR_AFTER_U1="100", GPX_LAZY_GROUP="1"),
                 # the panel chain of an outer block as launches (0) / as one cooperative kernel in the tail (1, default:
                 # the whole matrix is "tail" at this size) / everywhere (2), with other outer blockings
-                dict(GPX_PANEL_KERNEL="0"), dict(GPX_PANEL_KERNEL="2"), dict(GPX_PANEL_KERNEL="2", GPX_PANEL_MAX_FAR="1000"), dict(GPX_PANEL_KERNEL="0", GPX_OUTER_TILES="2"),
+                dict(GPX_PANEL_KERNEL="0"), dict(GPX_PANEL_KERNEL="2"), dict(GPX_PANEL_KERNEL="2", GPX_PANEL_MAX_FAR="1000"),
+                dict(GPX_SMALL_BK="32"), dict(GPX_SMALL_BK="32", GPX_LAZY_GROUP="3"), dict(GPX_PANEL_KERNEL="0", GPX_OUTER_TILES="2"),
                 dict(GPX_PANEL_KERNEL="2", GPX_OUTER_TILES="2"), dict(GPX_PANEL_KERNEL="2", GPX_OUTER_TILES="8", GPX_LAZY_GROUP="1"),
                 dict(GPX_PANEL_KERNEL="1", GPX_TAIL_TILES="12", GPX_LAZY_GROUP="2"), dict(GPX_PANEL_KERNEL="2", GPX_OUTER_TILES="1")]
     for env in variants:
         for k in ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_EARLY_DIAG", "GPX_PERSIST_GEMM", "GPX_CU_RESERVE",
                   "GPX_PERSIST_SCOPE", "GPX_CU_RESERVE_SOFT", "GPX_PERSIST_SLACK", "GPX_TAIL_TILES", "GPX_TILE_SWIZZLE", "GPX_TILE_SWIZZLE_MIN",
-                  "GPX_TAIL_OUTER_TILES", "GPX_SPLIT_FAR", "GPX_U1_SPLIT", "GPX_GRID_PAD8", "GPX_FAR_AFTER_U1", "GPX_PANEL_KERNEL", "GPX_PANEL_MAX_FAR"):
+                  "GPX_TAIL_OUTER_TILES", "GPX_SPLIT_FAR", "GPX_U1_SPLIT", "GPX_GRID_PAD8", "GPX_FAR_AFTER_U1", "GPX_PANEL_KERNEL", "GPX_PANEL_MAX_FAR", "GPX_SMALL_BK"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
