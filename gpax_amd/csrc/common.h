@@ -157,7 +157,14 @@ struct gpx_ctx {
   bool potf2_diag_blocked = false; // GPX_POTF2_DIAG=blocked: the 16 x 16 diagonal tiles factored four columns per LDS round trip (bit-identical, slower)
   bool potf2_chain = true;        // GPX_POTF2=tile: the four-phase kernel of round 2 instead of the wave-specialised one (potf2_chain.h)
   bool potf2_column = false;      // GPX_POTF2=column: the column-by-column diagonal-block kernel of round 1
-  int small_bk = 16;              // GPX_SMALL_BK=32: k-step of the latency shapes (experiment)
+  // k-step of the latency shapes: GPX_SMALL_BK = 16 | 32 forces it; default 0 = per driver call (small_bk_now): 32 for
+  // SINGLE-SAMPLE sweeps over matrices of up to GPX_SMALL_BK_ROWS tile rows — nothing saturates the chip there and the
+  // fatter k-step halves the barriers of every chain launch (potrf -2 ... -5 % at N = 512 ... 4096) — 16 otherwise (34 /
+  // 42 KB of LDS no longer fit beside two resident trailing-update workgroups: +2 % at N = 16384; batched small-N
+  // sweeps lose 3 - 6 % of their occupancy-bound throughput).  Never changes a bit.
+  int small_bk = 0;
+  int small_bk_rows = 40;
+  int small_bk_now = 16;
   bool gemm_small = true;         // GPX_GEMM_SMALL=0: no latency shapes
   double small_tiles_max = 400.0; // GPX_SMALL_TILES_MAX: launches with fewer 128x128 tiles take the latency shapes
   int far_after_u1 = 40; // GPX_FAR_AFTER_U1: tile rows below which the (single-sample) far update waits for U1 of the same block (0: never)

@@ -438,10 +438,10 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
       // workgroups leave free on a CU (32 KB, 80 registers per SIMD) and is placed at once; the round-1 64x128 shape
       // (52 KB, 125 VGPRs) had to wait for a trailing workgroup to retire — half a tile time (~50 us) per panel step
       if (tiles_n == 1)
-        return (ctx->small_bk == 32 && g.K % 32 == 0) ? launch_variant<0, 1, 4, 32, false>(ctx, g, tiles_m, tiles_n, splits)
+        return (ctx->small_bk_now == 32 && g.K % 32 == 0) ? launch_variant<0, 1, 4, 32, false>(ctx, g, tiles_m, tiles_n, splits)
                                                       : launch_variant<0, 1, 4, 16, false>(ctx, g, tiles_m, tiles_n, splits);
     } else {
-      return (ctx->small_bk == 32 && g.K % 32 == 0 && !g.ktri && !g.kupper && g.kchunk % 32 == 0)
+      return (ctx->small_bk_now == 32 && g.K % 32 == 0 && !g.ktri && !g.kupper && g.kchunk % 32 == 0)
                  ? launch_variant<0, 2, 2, 32, false>(ctx, g, tiles_m, tiles_n, splits)
                  : launch_variant<0, 2, 2, 16, false>(ctx, g, tiles_m, tiles_n, splits);
     }

@@ -205,6 +205,7 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
                 int* dInfo, int batch, int64_t a_bs, int64_t linv_bs) {
   const BatchStrides bs{batch > 1 ? batch : 1, a_bs, linv_bs};
   const int nblk = np / TILE;
+  ctx->small_bk_now = ctx->small_bk != 0 ? ctx->small_bk : ((bs.batch == 1 && nblk + extra_tiles <= ctx->small_bk_rows) ? 32 : 16);
   const int OT = ctx->outer_tiles;
   const int G = ctx->lazy_group > 0 ? ctx->lazy_group : 1;
   // Outer block boundaries.  Head blocks are OT tiles wide; a block that would leave fewer than `tail_tiles` tile rows
@@ -392,6 +393,7 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
                   int64_t ldl, const double* dLinv, int nblk, int upper_rows, int batch,
                   int64_t b_bs, int64_t l_bs, int64_t linv_bs) {
   if (batch < 1) batch = 1;
+  ctx->small_bk_now = ctx->small_bk != 0 ? ctx->small_bk : ((batch == 1 && (rows_t > nblk ? rows_t : nblk) <= ctx->small_bk_rows) ? 32 : 16);
   const int OT = ctx->outer_tiles;
   const int nouter = (nblk + OT - 1) / OT;
   GPX_TRY(ensure_events(ctx, nouter));
