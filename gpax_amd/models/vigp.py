@@ -95,8 +95,22 @@ class viGP(ExactGP):
         if samples is None:
             samples = self.get_samples()
         jitter = float(kwargs.get("jitter", 1e-6))
+        devs = [None]
+        if predict_fn is None:
+            # mean and variance of a test point do not depend on which other points share its slice (row-wise solves,
+            # and the same fma chains in every tile shape): the slices the reference needs to bound its M x M covariance
+            # (vigp.py:129-151) only cost launches here.  Device-sized slices: up to ~4 GB of k_pX rows at a time, and at
+            # least one slice per GPU when several are asked for — identical values point by point (C5: 263 slices of
+            # 1000 pixels -> 17 of 16384).
+            devs = self._slice_devices(device, X_new.shape[0])
+            rows_fit = max(1, int(4.0e9 / (8.0 * max(1, self.X_train.shape[0]))))
+            chunk = min(16384, rows_fit)
+            if len(devs) > 1:
+                chunk = min(chunk, -(-X_new.shape[0] // len(devs)))
+            batch_size = max(int(batch_size), chunk) if len(devs) == 1 else max(1, chunk)
         slices = split_in_batches(X_new, batch_size, dim=0)
-        devs = self._slice_devices(device, len(slices)) if predict_fn is None else [None]
+        if len(devs) > len(slices):
+            devs = devs[:len(slices)] if len(slices) > 1 else [None]
         if len(devs) > 1:
             y_pred, y_var, info = self._predict_slices_on(devs, slices, samples, noiseless, jitter)
         else:
