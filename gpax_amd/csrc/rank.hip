@@ -382,8 +382,19 @@ int gpx_rank_predict_sweep(gpx_rank* rk, int kind, const double* X, int N, int d
       sweep_rc = rcs[(size_t)c];
       rk->err = std::string("sweep failed on rank ") + std::to_string(rk->rank) + ": " + gpx_last_error(rk->ctxs[(size_t)c]);
     }
-  // A rank whose sweep failed still takes part in the gather (its block is sent as it is) so that the other ranks do
-  // not hang in the collective; the failure is returned afterwards.
+  // Every rank learns whether ANY rank's sweep failed (one all-reduce of a flag) before the gather: a failed block must
+  // not reach rank 0 as if it were a result, and all ranks must leave the collective together.
+  {
+    double failed = sweep_rc != 0 ? 1.0 : 0.0;
+    const std::string own_err = rk->err;
+    const int arc = allreduce_max(rk, &failed, 1);
+    if (arc != 0) return arc;
+    if (failed != 0.0) {
+      if (sweep_rc == 0) rk->err = "the sweep failed on another rank";
+      else rk->err = own_err;
+      return sweep_rc != 0 ? sweep_rc : -4;
+    }
+  }
 
   // ---- 3. gather on rank 0, one download -----------------------------------------------------------------------------
   RANK_HIP(rk, hipSetDevice(rk->device));
@@ -422,7 +433,6 @@ int gpx_rank_predict_sweep(gpx_rank* rk, int kind, const double* X, int N, int d
           RANK_TRY(file_get(rk, file_name(rk, "out", seq, r), rk->pin_out.d() + boff[(size_t)r], (size_t)cnt * sizeof(double)));
       }
   }
-  if (sweep_rc != 0) return sweep_rc;
   if (root) {
     const double* ho = rk->pin_out.d();
     for (int r = 0; r < G; ++r)
