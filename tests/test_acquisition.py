@@ -111,3 +111,13 @@ def test_readme_bayesian_optimisation_loop_finds_the_minimum():
     out = bo_loop.main(num_steps=8, num_warmup=40, num_samples=40, verbose=False)
     assert out["n_measured"] == 12
     assert abs(out["x_best"] - out["x_true"]) <= 0.1 and out["y_best"] <= out["y_true"] + 0.1
+
+
+def test_penalties_reproduce_the_known_answers_of_the_reference_tests():
+    """The only literal expected values the reference's test-suite holds for this row (gpax tests/test_acq.py:232-247)."""
+    from gpax_amd.acquisition.penalties import compute_penalty
+    X = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]], dtype=float)
+    pen = compute_penalty(X, np.array([[4, 5, 6], [1, 2, 3]], dtype=float), "delta", 1.0)
+    np.testing.assert_array_equal(pen, [np.inf, np.inf, 0.0])
+    pen = compute_penalty(X, np.array([[4, 5, 6], [7, 8, 9]], dtype=float), "inverse_distance", 1.0)
+    assert pen[-1] > pen[-2] > pen[-3]
