@@ -190,8 +190,14 @@ int dev_grad(gpx_ctx* ctx, const BatchPlan& bp) {
   double* W = ctx->W.d();
   double* K = ctx->K.d();
   RoctxRange r_grad("gpx:lml_grad (L^-T trsm, K^-1 syrk, contraction)");
-  GPX_TRY(launch_set_identity(ctx, W, ctx->ldk, n128, B, w_bs));
-  GPX_TRY(trsm_right_lt(ctx, W, ctx->ldk, nt, K, ctx->ldk, ctx->Linv.d(), nt, 1, B, w_bs, bp.k_bs, bp.linv_bs));
+  if (ctx->linvt_tree) {
+    GPX_TRY(ensure(ctx, ctx->Wscr, (size_t)B * w_bs * sizeof(double)));
+    GPX_TRY(linv_t_tree(ctx, W, ctx->ldk, K, ctx->ldk, ctx->Linv.d(), nt, ctx->Wscr.d(), ctx->ldk, B, w_bs, bp.k_bs,
+                        bp.linv_bs, w_bs));
+  } else {
+    GPX_TRY(launch_set_identity(ctx, W, ctx->ldk, n128, B, w_bs));
+    GPX_TRY(trsm_right_lt(ctx, W, ctx->ldk, nt, K, ctx->ldk, ctx->Linv.d(), nt, 1, B, w_bs, bp.k_bs, bp.linv_bs));
+  }
   // alpha_i = sum_{k>=i} W[i][k] w[k], w = row N of the augmented factor (read before K is
   // overwritten by K^-1)
   GPX_TRY(launch_rowdot(ctx, W, ctx->ldk, N, N, K + (int64_t)N * ctx->ldk, 0.0, ctx->alpha.d(),
@@ -698,6 +704,7 @@ int gpx_init(int device, gpx_ctx** out) {
     if (const char* e = getenv("GPX_GEMM_SMALL")) ctx->gemm_small = (e[0] != '0');
     if (const char* e = getenv("GPX_SMALL_BK")) ctx->small_bk = (atoi(e) == 32) ? 32 : (atoi(e) == 16 ? 16 : 0);
     if (const char* e = getenv("GPX_SMALL_BK_ROWS")) ctx->small_bk_rows = atoi(e);
+    if (const char* e = getenv("GPX_LINVT")) ctx->linvt_tree = (std::strcmp(e, "sweep") == 0) ? 0 : 1;
     if (const char* e = getenv("GPX_SMALL_TILES_MAX")) ctx->small_tiles_max = atof(e);
     if (const char* e = getenv("GPX_SPLIT_FAR")) ctx->split_far = atoi(e);
     if (ctx->split_far > 0) {

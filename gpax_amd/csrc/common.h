@@ -217,6 +217,8 @@ struct gpx_ctx {
   gpx::DevBuf X;     // T x N x d
   gpx::DevBuf K;     // Np x ldk : Gram -> L (lower) -> K^-1 (lower)
   gpx::DevBuf W;     // Np x ldk : L^-T (upper), allocated on first gradient
+  gpx::DevBuf Wscr;  // Np x ldk : scratch of the L^-T tree (linalg.hip: T and the transposed C blocks of one level)
+  int linvt_tree = 1; // GPX_LINVT=tree|sweep: L^-T by the block-recursive inverse (default) or the right-looking sweep
   gpx::DevBuf Linv;  // (Np/128) x 128 x 128 inverses of the diagonal blocks of L
   gpx::DevBuf yres;  // N
   gpx::DevBuf diagv; // N: per-point variance added to K's diagonal (gpx_set_diag), when has_diag
@@ -372,6 +374,8 @@ struct GemmArgs {
   int nsplit;  // grid.z = nsplit * batch (filled in by launch_gemm_nt)
   int batch;   // independent problems per launch (0 or 1 = one); element b at base + b * *_bs
   int64_t a_bs, b_bs, c_bs;
+  int batch2;  // > 1: two-level batch — entry = outer * batch2 + inner, at base + outer * *_bs + inner * *_bs2
+  int64_t a_bs2, b_bs2, c_bs2;
 };
 int debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n, int* out, int cap);
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
@@ -394,6 +398,9 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
 int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_p, const double* dL,
                   int64_t ldl, const double* dLinv, int nblk, int upper_rows, int batch = 1,
                   int64_t b_bs = 0, int64_t l_bs = 0, int64_t linv_bs = 0);
+int linv_t_tree(gpx_ctx* ctx, double* dW, int64_t ldw, const double* dL, int64_t ldl, const double* dLinv, int nt,
+                double* dS, int64_t lds, int batch = 1, int64_t w_bs = 0, int64_t l_bs = 0, int64_t linv_bs = 0,
+                int64_t s_bs = 0);
 int launch_set_identity(gpx_ctx* ctx, double* dA, int64_t ld, int np, int batch = 1, int64_t a_bs = 0);
 int launch_lml_terms(gpx_ctx* ctx, const double* dL, int64_t ld, int N, double* dOut2, int batch = 1,
                      int64_t l_bs = 0, int64_t out_bs = 0);

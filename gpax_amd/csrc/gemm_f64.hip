@@ -215,13 +215,21 @@ int debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n
 struct TileMap {
   int tiles_m, tiles_n, per_slab, total;
   int a, f0, b, tri; // rows a .. b-1 hold f0, f0 + 1, ... tiles (the triangular part, `tri` tiles), rows >= b tiles_n each
+  int col_desc;      // full grid, column by column from the LAST column: the order that hands out the long tiles first when
+                     // the k range ends at the column tile (kupper) — row-major order would start the longest tiles last
 };
 
 // slab-local tile id -> (by, bx)
 __device__ __forceinline__ void decode_tile(const TileMap& tm, int lower, int l, int& by, int& bx) {
   if (!lower) {
-    by = l / tm.tiles_n;
-    bx = l - by * tm.tiles_n;
+    if (tm.col_desc) {
+      const int c = l / tm.tiles_m;
+      by = l - c * tm.tiles_m;
+      bx = tm.tiles_n - 1 - c;
+    } else {
+      by = l / tm.tiles_n;
+      bx = l - by * tm.tiles_n;
+    }
   } else if (l < tm.tri) { // n = rows before `by` in the triangular part: n f0 + n (n - 1) / 2 <= l
     const double q = 2.0 * tm.f0 - 1.0;
     int n = (int)((-q + sqrt(q * q + 8.0 * l)) * 0.5);
@@ -297,7 +305,9 @@ static TileMap make_tile_map2(int lower, int delta, int tiles_m, int tiles_n, in
   return tm;
 }
 static TileMap make_tile_map(const GemmArgs& g, int tiles_m, int tiles_n) {
-  return make_tile_map2(g.lower, g.ti_off - g.tj_off, tiles_m, tiles_n, g.nsplit * g.batch);
+  TileMap tm = make_tile_map2(g.lower, g.ti_off - g.tj_off, tiles_m, tiles_n, g.nsplit * g.batch);
+  tm.col_desc = (!g.lower && g.kupper && !g.ktri) ? 1 : 0;
+  return tm;
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a function: every context sets it once

@@ -15,6 +15,21 @@ constexpr size_t gemm_lds_bytes() {
   return size_t(DBUF ? 2 : 1) * (32 * MT + 32 * NT) * (BK + 1) * sizeof(double); // buffers x (A tile + B tile)
 }
 
+// Element offsets of batch entry bb.  One level: bb * *_bs.  Two levels (batch2 > 1: `batch` counts outer x inner entries, the
+// inner index runs fastest — the block pairs of one level of the L^-T tree inside every sample of a batched fit step).
+__device__ __forceinline__ void batch_offsets(const GemmArgs& g, const int bb, int64_t& oa, int64_t& ob, int64_t& oc) {
+  if (g.batch2 > 1) {
+    const int b1 = bb / g.batch2, b2 = bb - b1 * g.batch2;
+    oa = (int64_t)b1 * g.a_bs + (int64_t)b2 * g.a_bs2;
+    ob = (int64_t)b1 * g.b_bs + (int64_t)b2 * g.b_bs2;
+    oc = (int64_t)b1 * g.c_bs + (int64_t)b2 * g.c_bs2;
+  } else {
+    oa = (int64_t)bb * g.a_bs;
+    ob = (int64_t)bb * g.b_bs;
+    oc = (int64_t)bb * g.c_bs;
+  }
+}
+
 // TAG only gives the Cholesky trailing update (TAG = 1) its own symbol, so that rocprofv3 kernel
 // statistics separate the dominant kernel from the small panel GEMMs (TAG = 0).
 // MT x NT = 16x16 MFMA tiles per wave; the workgroup (2x2 waves) covers a (32 MT) x (32 NT) tile:
@@ -39,6 +54,8 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g, double* smem, co
   // grid.z = batch entry * nsplit + split-K slab
   const int bb = (g.batch > 1) ? bzz / g.nsplit : 0;
   const int bz = bzz - bb * g.nsplit;
+  int64_t off_a, off_b, off_c;
+  batch_offsets(g, bb, off_a, off_b, off_c);
   // element coordinates of this tile in the caller's global tile frame (offsets given in 128-tiles)
   const int row0 = g.ti_off * 128 + by * BM, col0 = g.tj_off * 128 + bx * BN;
   if (g.lower && col0 > row0 + BM - 1) return; // entirely above the diagonal
@@ -47,7 +64,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g, double* smem, co
   int kb = 0, ke = g.K;
   if (g.ktri) kb = row0 & ~(BK - 1);            // A rows are zero left of the diagonal (upper-triangular operand)
   if (g.kupper) ke = min(ke, col0 + BN);        // B rows are zero right of the diagonal (lower-triangular factor)
-  double* C = g.C + (int64_t)bb * g.c_bs;  // may alias A (in-place panel TRSM): no restrict here
+  double* C = g.C + off_c;  // may alias A (in-place panel TRSM): no restrict here
   if (g.kchunk > 0) {
     kb = max(kb, bz * g.kchunk);
     ke = min(ke, (bz + 1) * g.kchunk);
@@ -62,8 +79,8 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g, double* smem, co
 
   // staging map: thread -> (row lr + RPP i, cols lc, lc + 1)
   const int lr = tid / TPR, lc = (tid % TPR) * 2;
-  const double* Ap = g.A + (int64_t)bb * g.a_bs + ((int64_t)by * BM + lr) * g.lda + kb + lc;
-  const double* Bp = g.B + (int64_t)bb * g.b_bs + ((int64_t)bx * BN + lr) * g.ldb + kb + lc;
+  const double* Ap = g.A + off_a + ((int64_t)by * BM + lr) * g.lda + kb + lc;
+  const double* Bp = g.B + off_b + ((int64_t)bx * BN + lr) * g.ldb + kb + lc;
   const int64_t a_step = (int64_t)RPP * g.lda, b_step = (int64_t)RPP * g.ldb;
 
   double* sA0 = smem;
@@ -198,6 +215,8 @@ __device__ __forceinline__ void nt128_tile(const GemmArgs& g, double* smem, cons
   constexpr int BK = 16, BM = 128, BN = 128, TD = (BM + BN) * BK, GPW = 8;
   const int bb = (g.batch > 1) ? bzz / g.nsplit : 0;
   const int bz = bzz - bb * g.nsplit;
+  int64_t off_a, off_b, off_c;
+  batch_offsets(g, bb, off_a, off_b, off_c);
   const int row0 = g.ti_off * 128 + by * BM, col0 = g.tj_off * 128 + bx * BN;
   if (g.lower && col0 > row0 + BM - 1) return; // entirely above the diagonal
   if (g.skip && (row0 >> 7) == g.skip_ti && (col0 >> 7) == g.skip_tj) return; // updated by its own launch
@@ -205,7 +224,7 @@ __device__ __forceinline__ void nt128_tile(const GemmArgs& g, double* smem, cons
   int kb = 0, ke = g.K;
   if (g.ktri) kb = row0 & ~(BK - 1);
   if (g.kupper) ke = min(ke, col0 + BN);
-  double* C = g.C + (int64_t)bb * g.c_bs;
+  double* C = g.C + off_c;
   if (g.kchunk > 0) {
     kb = max(kb, bz * g.kchunk);
     ke = min(ke, (bz + 1) * g.kchunk);
@@ -222,8 +241,8 @@ __device__ __forceinline__ void nt128_tile(const GemmArgs& g, double* smem, cons
   // One wave-instruction = 64 lanes x 16 B = 1 KiB = 8 LDS rows; lane -> row (lane >> 3), LDS chunk (lane & 7),
   // which holds source chunk (lane & 7) ^ ((row >> 1) & 7) of that row.
   const bool isA = wave < 2;
-  const double* src = isA ? g.A + (int64_t)bb * g.a_bs + (int64_t)by * BM * g.lda
-                          : g.B + (int64_t)bb * g.b_bs + (int64_t)bx * BN * g.ldb;
+  const double* src = isA ? g.A + off_a + (int64_t)by * BM * g.lda
+                          : g.B + off_b + (int64_t)bx * BN * g.ldb;
   const int64_t ldx = isA ? g.lda : g.ldb;
   // 2 GiB window from the tile's first row: offsets stay below 128 rows x ld x 8 B + K x 8 B
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);

@@ -463,6 +463,105 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
   return rc;
 }
 
+// ---- W = L^-T (upper) by the block-recursive inverse, bottom-up --------------------------------
+// L = [[A, 0], [B, C]]  =>  L^-T = [[A^-T, Y], [0, C^-T]],  Y = -A^-T B^T C^-T.
+// Level s (s = 1, 2, 4, ... 128-tiles): every aligned pair of finished diagonal blocks (A: s tiles, C: up to s tiles)
+// gets its Y from two GEMMs whose k ranges are trimmed to the triangles:
+//   T = W_A B^T            (A operand upper triangular: k starts at the row tile          — ktri)
+//   Y = -T V_C^T, V_C = W_C^T   (B operand lower triangular: k ends at the column tile    — kupper)
+// The NT kernels read both operands by rows, so W_C is transposed once per level (a bandwidth-bound pass over
+// s x s per pair).  All pairs of a level — and all samples of a batched fit step — go in ONE launch each (two-level
+// batch, gemm_tile.h), a ragged last pair (C shorter than A) in its own.  There is no serial column chain: the
+// right-looking sweep (trsm_right_lt with upper_rows) needs 2 launches per 128 columns that each wait for the one
+// before; this needs 3 per level, log2(n / 128) levels, and 98 % of the flops sit in the three top levels with
+// K >= 1024.  Same N^3 / 3 flops.  The diagonal 128-blocks come from potf2's inverses (level 0: W_kk = Linv_k^T).
+// Only tiles on or above the diagonal of W are written; nothing downstream reads the others (rowdot starts at the
+// row's own tile, the K^-1 product runs with ktri).  dS: scratch of the same shape as W (T and V_C of one level).
+__global__ __launch_bounds__(256) void transpose_blocks_kernel(const double* __restrict__ in, int64_t ldi,
+                                                               double* __restrict__ out, int64_t ldo, int n,
+                                                               int inner, int64_t in_bs, int64_t in_bs2,
+                                                               int64_t out_bs, int64_t out_bs2, int upper_only) {
+  __shared__ double t[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x; // 32 x 32 block (bi, bj) of the input
+  // upper_only: the input is upper triangular in 128-tiles — tiles strictly below the diagonal hold nothing
+  if (upper_only && (bi >> 2) > (bj >> 2)) return;
+  const int e = blockIdx.z, e1 = e / inner, e2 = e - e1 * inner;
+  in += (int64_t)e1 * in_bs + (int64_t)e2 * in_bs2;
+  out += (int64_t)e1 * out_bs + (int64_t)e2 * out_bs2;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    t[r][tx] = (i < n && j < n) ? in[(int64_t)i * ldi + j] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bj * 32 + r, j = bi * 32 + tx;
+    if (i < n && j < n) out[(int64_t)i * ldo + j] = t[tx][r];
+  }
+}
+
+int linv_t_tree(gpx_ctx* ctx, double* dW, int64_t ldw, const double* dL, int64_t ldl, const double* dLinv, int nt,
+                double* dS, int64_t lds_, int batch, int64_t w_bs, int64_t l_bs, int64_t linv_bs, int64_t s_bs) {
+  if (batch < 1) batch = 1;
+  ctx->small_bk_now = ctx->small_bk != 0 ? ctx->small_bk : 16;
+  auto transpose = [&](const double* in, int64_t ldi, double* out, int64_t ldo, int n, int inner, int64_t in_bs,
+                       int64_t in_bs2, int64_t out_bs, int64_t out_bs2, int upper_only) -> int {
+    dim3 grid((n + 31) / 32, (n + 31) / 32, batch * inner);
+    transpose_blocks_kernel<<<grid, 256, 0, ctx->s>>>(in, ldi, out, ldo, n, inner, in_bs, in_bs2, out_bs, out_bs2,
+                                                      upper_only);
+    GPX_HIP(ctx, hipGetLastError());
+    return 0;
+  };
+  // level 0: the diagonal 128-blocks
+  GPX_TRY(transpose(dLinv, TILE, dW, ldw, TILE, nt, linv_bs, (int64_t)TILE * TILE, w_bs, (int64_t)TILE * (ldw + 1), 0));
+  struct Scope { // tiles of very different length (trimmed k ranges), nothing else in flight: persistent, dynamically scheduled
+    gpx_ctx* c;
+    explicit Scope(gpx_ctx* c_) : c(c_) { if (c->persist_scope_ok) c->persist_scope += 1; }
+    ~Scope() { if (c->persist_scope_ok) c->persist_scope -= 1; }
+  } scope(ctx);
+  // pairs [first, first + count) of level s, C blocks c tiles wide
+  auto level = [&](int s, int first, int count, int c) -> int {
+    if (count <= 0 || c <= 0) return 0;
+    const int64_t a0 = (int64_t)first * 2 * s * TILE;   // first row / column of the first pair's A block
+    const int64_t c0 = a0 + (int64_t)s * TILE;          //                                        C block
+    const int64_t pw = (int64_t)2 * s * TILE * (ldw + 1), pl = (int64_t)2 * s * TILE * (ldl + 1),
+                  ps = (int64_t)2 * s * TILE * (lds_ + 1);
+    const double t3 = (double)TILE * TILE * TILE;
+    double* Vc = dS + c0 * lds_ + c0;
+    double* Tm = dS + a0 * lds_ + c0;
+    GPX_TRY(transpose(dW + c0 * ldw + c0, ldw, Vc, lds_, c * TILE, count, w_bs, pw, s_bs, ps, 1));
+    {
+      GemmArgs g = gemm_args(dW + a0 * ldw + a0, ldw, dL + c0 * ldl + a0, ldl, Tm, lds_, s * TILE, 1.0, 0.0);
+      g.ktri = 1;
+      set_batch(g, batch * count, w_bs, l_bs, s_bs);
+      g.batch2 = count;
+      g.a_bs2 = pw;
+      g.b_bs2 = pl;
+      g.c_bs2 = ps;
+      GPX_TRY(launch_gemm_nt(ctx, g, s, c, 0, GPX_PROF_GEMM_OTHER, (double)s * s * c * t3));
+    }
+    {
+      GemmArgs g = gemm_args(Tm, lds_, Vc, lds_, dW + a0 * ldw + c0, ldw, c * TILE, -1.0, 0.0);
+      g.kupper = 1;
+      set_batch(g, batch * count, s_bs, s_bs, w_bs);
+      g.batch2 = count;
+      g.a_bs2 = ps;
+      g.b_bs2 = ps;
+      g.c_bs2 = pw;
+      GPX_TRY(launch_gemm_nt(ctx, g, s, c, 0, GPX_PROF_GEMM_OTHER, (double)s * c * c * t3));
+    }
+    return 0;
+  };
+  for (int s = 1; s < nt; s *= 2) {
+    const int full = nt / (2 * s), rest = nt - full * 2 * s;
+    GPX_TRY(level(s, 0, full, s));
+    if (rest > s) GPX_TRY(level(s, full, 1, rest - s));
+  }
+  return 0;
+}
+
 // ---- small kernels ---------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ A, int64_t ld,
