@@ -705,6 +705,7 @@ int gpx_init(int device, gpx_ctx** out) {
     if (const char* e = getenv("GPX_SMALL_BK")) ctx->small_bk = (atoi(e) == 32) ? 32 : (atoi(e) == 16 ? 16 : 0);
     if (const char* e = getenv("GPX_SMALL_BK_ROWS")) ctx->small_bk_rows = atoi(e);
     if (const char* e = getenv("GPX_LINVT")) ctx->linvt_tree = (std::strcmp(e, "sweep") == 0) ? 0 : 1;
+    if (const char* e = getenv("GPX_SGP_SOLVE")) ctx->sgp_inverse = (std::strcmp(e, "sweep") == 0) ? 0 : 1;
     if (const char* e = getenv("GPX_SMALL_TILES_MAX")) ctx->small_tiles_max = atof(e);
     if (const char* e = getenv("GPX_SPLIT_FAR")) ctx->split_far = atoi(e);
     if (ctx->split_far > 0) {

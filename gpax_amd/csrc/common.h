@@ -218,6 +218,7 @@ struct gpx_ctx {
   gpx::DevBuf K;     // Np x ldk : Gram -> L (lower) -> K^-1 (lower)
   gpx::DevBuf W;     // Np x ldk : L^-T (upper), allocated on first gradient
   gpx::DevBuf Wscr;  // Np x ldk : scratch of the L^-T tree (linalg.hip: T and the transposed C blocks of one level)
+  int sgp_inverse = 1; // GPX_SGP_SOLVE=inverse|sweep: sparse-GP solves with many right-hand sides as GEMMs against L^-1 (sparse.hip)
   int linvt_tree = 1; // GPX_LINVT=tree|sweep: L^-T by the block-recursive inverse (default) or the right-looking sweep
   gpx::DevBuf Linv;  // (Np/128) x 128 x 128 inverses of the diagonal blocks of L
   gpx::DevBuf yres;  // N
@@ -365,6 +366,7 @@ struct GemmArgs {
   int ti_off, tj_off;
   int ktri;    // k range starts at (ti_off + by) * 128 (upper-triangular operands)
   int kupper;  // k range ends at (tj_off + bx + 1) * 128 (B lower triangular, e.g. chol factor)
+  int kcol;    // k range starts at (tj_off + bx) * 128 (B upper triangular, e.g. L^-T as the right factor)
   int kchunk;  // split-K chunk (multiple of 16), 0 = no split
   int64_t c_split_stride;
   int skip;    // != 0: the 128-tile (skip_ti, skip_tj) of the caller's global tile frame is left out (it was updated by

@@ -215,8 +215,9 @@ int debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n
 struct TileMap {
   int tiles_m, tiles_n, per_slab, total;
   int a, f0, b, tri; // rows a .. b-1 hold f0, f0 + 1, ... tiles (the triangular part, `tri` tiles), rows >= b tiles_n each
-  int col_desc;      // full grid, column by column from the LAST column: the order that hands out the long tiles first when
-                     // the k range ends at the column tile (kupper) — row-major order would start the longest tiles last
+  int col_desc;      // full grid, column by column from the LAST column (1): the order that hands out the long tiles first when
+                     // the k range ends at the column tile (kupper) — row-major order would start the longest tiles last;
+                     // 2: from the FIRST column (kcol: the k range starts at the column tile)
 };
 
 // slab-local tile id -> (by, bx)
@@ -225,7 +226,7 @@ __device__ __forceinline__ void decode_tile(const TileMap& tm, int lower, int l,
     if (tm.col_desc) {
       const int c = l / tm.tiles_m;
       by = l - c * tm.tiles_m;
-      bx = tm.tiles_n - 1 - c;
+      bx = tm.col_desc == 2 ? c : tm.tiles_n - 1 - c;
     } else {
       by = l / tm.tiles_n;
       bx = l - by * tm.tiles_n;
@@ -306,7 +307,7 @@ static TileMap make_tile_map2(int lower, int delta, int tiles_m, int tiles_n, in
 }
 static TileMap make_tile_map(const GemmArgs& g, int tiles_m, int tiles_n) {
   TileMap tm = make_tile_map2(g.lower, g.ti_off - g.tj_off, tiles_m, tiles_n, g.nsplit * g.batch);
-  tm.col_desc = (!g.lower && g.kupper && !g.ktri) ? 1 : 0;
+  tm.col_desc = (!g.lower && g.kupper && !g.ktri) ? 1 : ((!g.lower && g.kcol && !g.ktri) ? 2 : 0);
   return tm;
 }
 
@@ -451,7 +452,7 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
         return (ctx->small_bk_now == 32 && g.K % 32 == 0) ? launch_variant<0, 1, 4, 32, false>(ctx, g, tiles_m, tiles_n, splits)
                                                       : launch_variant<0, 1, 4, 16, false>(ctx, g, tiles_m, tiles_n, splits);
     } else {
-      return (ctx->small_bk_now == 32 && g.K % 32 == 0 && !g.ktri && !g.kupper && g.kchunk % 32 == 0)
+      return (ctx->small_bk_now == 32 && g.K % 32 == 0 && !g.ktri && !g.kupper && !g.kcol && g.kchunk % 32 == 0)
                  ? launch_variant<0, 2, 2, 32, false>(ctx, g, tiles_m, tiles_n, splits)
                  : launch_variant<0, 2, 2, 16, false>(ctx, g, tiles_m, tiles_n, splits);
     }

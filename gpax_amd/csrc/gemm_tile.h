@@ -63,6 +63,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g, double* smem, co
 
   int kb = 0, ke = g.K;
   if (g.ktri) kb = row0 & ~(BK - 1);            // A rows are zero left of the diagonal (upper-triangular operand)
+  if (g.kcol) kb = max(kb, col0 & ~(BK - 1));   // B rows are zero left of the diagonal (upper-triangular right factor)
   if (g.kupper) ke = min(ke, col0 + BN);        // B rows are zero right of the diagonal (lower-triangular factor)
   double* C = g.C + off_c;  // may alias A (in-place panel TRSM): no restrict here
   if (g.kchunk > 0) {
@@ -223,6 +224,7 @@ __device__ __forceinline__ void nt128_tile(const GemmArgs& g, double* smem, cons
 
   int kb = 0, ke = g.K;
   if (g.ktri) kb = row0 & ~(BK - 1);
+  if (g.kcol) kb = max(kb, col0 & ~(BK - 1));
   if (g.kupper) ke = min(ke, col0 + BN);
   double* C = g.C + off_c;
   if (g.kchunk > 0) {

@@ -285,10 +285,24 @@ static int syrk_full(gpx_ctx* ctx, const double* V, int64_t ldv, int nt, int K, 
                      int n_valid, double* out, int64_t ldo) {
   const int np = nt * TILE;
   const int lower_tiles = nt * (nt + 1) / 2;
-  int splits = (512 + lower_tiles - 1) / lower_tiles;
-  const int max_splits = K / 256 > 0 ? K / 256 : 1;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  // Split count from a cost model instead of "just fill the 512 workgroup slots" (round 2: ceil(512 / tiles) slabs —
+  // at C5, 136 tiles x 4 slabs = 544 workgroups, i.e. two rounds with the second one nearly empty: 2.08 ms for
+  // 6.8e10 flop).  rounds x (k-tiles per slab) in units of one workgroup k-step, plus the finalisation pass that reads
+  // every slab (np^2 x 8 B per slab at ~3 TB/s against 0.218 us per k of a 128 x 128 tile on one of 512 slots).
+  // The choice depends on the shape only, so results stay run-to-run identical.
+  const int max_splits = K / 256 > 0 ? (K / 256 < 32 ? K / 256 : 32) : 1;
+  int splits = 1;
+  double best = 1e300;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const int kc = round_up((K + sp - 1) / sp, TILE);
+    const int eff = (K + kc - 1) / kc; // slabs actually launched
+    const double rounds = std::ceil((double)lower_tiles * eff / 512.0);
+    const double cost = rounds * kc * 0.218 + eff * ((double)np * np * 8.0 / 3.0e6);
+    if (cost < best - 1e-9) {
+      best = cost;
+      splits = eff;
+    }
+  }
   const int kchunk = round_up((K + splits - 1) / splits, TILE);
   splits = (K + kchunk - 1) / kchunk;
   const int64_t ldp = pick_ld(np), stride = (int64_t)np * ldp;
@@ -297,7 +311,12 @@ static int syrk_full(gpx_ctx* ctx, const double* V, int64_t ldv, int nt, int K, 
   g.lower = 1;
   g.kchunk = kchunk;
   g.c_split_stride = stride;
-  GPX_TRY(launch_gemm_nt(ctx, g, nt, nt, splits, GPX_PROF_GEMM_OTHER, (double)np * (np + 1.0) * K));
+  // persistent, dynamically scheduled: in a plain launch workgroup id -> XCD is a fixed rotation, i.e. XCD x gets the tile
+  // columns x and x + 8 — with 16 tile columns of a lower triangle that is 24 tiles per slab on one XCD and 10 on another
+  if (ctx->persist_scope_ok) ctx->persist_scope += 1;
+  const int rc_syrk = launch_gemm_nt(ctx, g, nt, nt, splits, GPX_PROF_GEMM_OTHER, (double)np * (np + 1.0) * K);
+  if (ctx->persist_scope_ok) ctx->persist_scope -= 1;
+  GPX_TRY(rc_syrk);
   dim3 grid((np + 63) / 64, (np + 15) / 16);
   sym_finalize_kernel<<<grid, 256, 0, ctx->s>>>(ctx->SplitK.d(), splits, stride, ldp, scale, diag_val, n_valid, np,
                                                 out, ldo);
@@ -305,11 +324,29 @@ static int syrk_full(gpx_ctx* ctx, const double* V, int64_t ldv, int nt, int K, 
   return 0;
 }
 
-// T = L^-T (upper, n x n) from the factor L and its diagonal-block inverses
+// T = L^-T (upper, n x n; zero below the diagonal — it enters full GEMMs) from the factor L and its diagonal-block inverses,
+// by the block-recursive tree of linalg.hip (scr: scratch of T's shape); V != nullptr: V = T^T = L^-1 (lower) as well.
+// Round 3: every triangular solve of the sparse path with many right-hand sides (W = Kfu Luu^-T, V1 = Ksu Luu^-T,
+// V2 = V1 LA^-T) is ONE GEMM against L^-1 with the k range cut at the column tile (kupper) instead of a right-looking
+// sweep of 2 dependent launches per 128 columns.
 static int build_linv_t(gpx_ctx* ctx, const double* L, int64_t ldl, const double* Linv, int nt, double* T,
-                        int64_t ldt) {
-  GPX_TRY(launch_set_identity(ctx, T, ldt, nt * TILE));
-  return trsm_right_lt(ctx, T, ldt, nt, L, ldl, Linv, nt, 1);
+                        int64_t ldt, double* scr, double* V = nullptr) {
+  GPX_HIP(ctx, hipMemsetAsync(T, 0, (size_t)nt * TILE * ldt * sizeof(double), ctx->s));
+  GPX_TRY(linv_t_tree(ctx, T, ldt, L, ldl, Linv, nt, scr, ldt));
+  if (V != nullptr) GPX_TRY(launch_transpose(ctx, T, ldt, nt * TILE, nt * TILE, V, ldt));
+  return 0;
+}
+
+// X = B V^T with V = L^-1 lower triangular (rows x nt*128):  X[i][j] = sum_{k <= j} B[i][k] V[j][k]
+static int solve_by_inverse(gpx_ctx* ctx, const double* B, int64_t ldb, int rows_t, const double* V, int64_t ldv, int nt,
+                            double* X, int64_t ldx) {
+  GemmArgs g = gargs(B, ldb, V, ldv, X, ldx, nt * TILE, 1.0, 0.0);
+  g.kupper = 1;
+  if (ctx->persist_scope_ok) ctx->persist_scope += 1; // long tiles first (TileMap.col_desc)
+  const int rc = launch_gemm_nt(ctx, g, rows_t, nt, 0, GPX_PROF_GEMM_OTHER,
+                                (double)rows_t * TILE * (double)nt * TILE * (nt + 1.0) * TILE);
+  if (ctx->persist_scope_ok) ctx->persist_scope -= 1;
+  return rc;
 }
 
 } // namespace gpx
@@ -337,6 +374,7 @@ struct SgpState {
   gpx::DevBuf Xu, Kuu, LinvU, Wn, Wt, A, Acopy, LinvA, u, c, cpad, scal, part;
   gpx::DevBuf B0, B1, B2, B3, B4, vvec, tvec, mvec, rcoef_u, rcoef_f, gxu_part, cpart, gXu, T1a, T1;
   gpx::DevBuf Xs, V1, V2, mean, var, var2, Cov;
+  gpx::DevBuf Vu, VA, Tscr, Kfu; // Luu^-1, LA^-1 (lower), scratch of the L^-T tree, Kfu before the solve
   gpx::KernelParams kp{};
   double noise = 0, jitter = 0;
 };
@@ -353,7 +391,7 @@ void sgp_release(gpx_ctx* ctx) {
   DevBuf* bufs[] = {&s->Xu, &s->Kuu, &s->LinvU, &s->Wn, &s->Wt, &s->A, &s->Acopy, &s->LinvA, &s->u, &s->c, &s->cpad,
                     &s->scal, &s->part, &s->B0, &s->B1, &s->B2, &s->B3, &s->B4, &s->vvec, &s->tvec, &s->mvec,
                     &s->rcoef_u, &s->rcoef_f, &s->gxu_part, &s->cpart, &s->gXu, &s->T1a, &s->T1, &s->Xs, &s->V1,
-                    &s->V2, &s->mean, &s->var, &s->var2, &s->Cov};
+                    &s->V2, &s->mean, &s->var, &s->var2, &s->Cov, &s->Vu, &s->VA, &s->Tscr, &s->Kfu};
   for (DevBuf* b : bufs) b->release();
   delete s;
   ctx->sgp = nullptr;
@@ -417,8 +455,18 @@ static int sgp_forward(gpx_ctx* ctx, SgpState* s) {
   GPX_TRY(launch_pad_identity(ctx, s->Kuu.d(), s->ldu, M, Mp));
   GPX_TRY(potrf_lower(ctx, s->Kuu.d(), s->ldu, Mp, 0, s->LinvU.d(), dinfo));
   // Kfu (N x M), then W = Kfu Luu^-T
-  GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->Wn.d(), s->ldw));
-  GPX_TRY(trsm_right_lt(ctx, s->Wn.d(), s->ldw, ntl, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, 0));
+  if (ctx->sgp_inverse) {
+    GPX_TRY(ens(ctx, s->B0, mm));
+    GPX_TRY(ens(ctx, s->Vu, mm));
+    GPX_TRY(ens(ctx, s->Tscr, mm));
+    GPX_TRY(ens(ctx, s->Kfu, (size_t)Ntp * s->ldw * 8));
+    GPX_TRY(build_linv_t(ctx, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, s->B0.d(), s->ldu, s->Tscr.d(), s->Vu.d())); // Tu, Luu^-1
+    GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->Kfu.d(), s->ldw));
+    GPX_TRY(solve_by_inverse(ctx, s->Kfu.d(), s->ldw, ntl, s->Vu.d(), s->ldu, mt, s->Wn.d(), s->ldw));
+  } else {
+    GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->Wn.d(), s->ldw));
+    GPX_TRY(trsm_right_lt(ctx, s->Wn.d(), s->ldw, ntl, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, 0));
+  }
   GPX_TRY(launch_transpose(ctx, s->Wn.d(), s->ldw, Ntp, Mp, s->Wt.d(), s->ldt));
   // A = I + Wt Wt^T / s2 (kept in Acopy), factor
   GPX_TRY(syrk_full(ctx, s->Wt.d(), s->ldt, mt, Ntp, 1.0 / s2, 1.0, M, s->A.d(), s->ldu));
@@ -470,8 +518,10 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
     GPX_TRY(ens(ctx, s->tvec, (size_t)Ntp * 8));
     double* Tu = s->B0.d();
     double* TA = s->B1.d();
-    GPX_TRY(build_linv_t(ctx, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, Tu, s->ldu)); // Tu = Luu^-T
-    GPX_TRY(build_linv_t(ctx, s->A.d(), s->ldu, s->LinvA.d(), mt, TA, s->ldu));   // TA = LA^-T
+    GPX_TRY(ens(ctx, s->Tscr, mm));
+    if (!ctx->sgp_inverse) // (otherwise Tu = Luu^-T is there since the forward pass)
+      GPX_TRY(build_linv_t(ctx, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, Tu, s->ldu, s->Tscr.d()));
+    GPX_TRY(build_linv_t(ctx, s->A.d(), s->ldu, s->LinvA.d(), mt, TA, s->ldu, s->Tscr.d())); // TA = LA^-T
     // v = TA c ; m = s2 Tu v ; t = s2 W v
     GPX_TRY(launch_rowdot(ctx, TA, s->ldu, M, M, s->c.d(), 0.0, s->vvec.d(), nullptr, 1));
     GPX_TRY(launch_rowdot(ctx, Tu, s->ldu, M, M, s->vvec.d(), 0.0, s->mvec.d(), nullptr, 1));
@@ -528,9 +578,11 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
   }
   { // E1 = Tu H -> B2 (Ainv dead) ; G0 = E1 Tu^T -> B3 (H dead after E1)
     GemmArgs g = gargs(Tu, s->ldu, s->B3.d(), s->ldu, s->B2.d(), s->ldu, Mp, 1.0, 0.0);
-    GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, 0, GPX_PROF_GEMM_OTHER, 2.0 * Mp * (double)Mp * Mp));
+    g.ktri = 1; // ... and row i of the left factor at column i
+    GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, 0, GPX_PROF_GEMM_OTHER, (double)Mp * Mp * (Mp + TILE)));
     GemmArgs h2 = gargs(s->B2.d(), s->ldu, Tu, s->ldu, s->B3.d(), s->ldu, Mp, 1.0, 0.0);
-    GPX_TRY(launch_gemm_nt(ctx, h2, mt, mt, 0, GPX_PROF_GEMM_OTHER, 2.0 * Mp * (double)Mp * Mp));
+    h2.kcol = 1; // Tu is upper triangular: row j of the right factor starts at column j
+    GPX_TRY(launch_gemm_nt(ctx, h2, mt, mt, 0, GPX_PROF_GEMM_OTHER, (double)Mp * Mp * (Mp + TILE)));
   }
   GPX_TRY(ens(ctx, s->T1a, (size_t)Ntp * s->ldw * 8));
   GPX_TRY(ens(ctx, s->T1, (size_t)Ntp * s->ldw * 8));
@@ -538,7 +590,11 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
     GemmArgs g = gargs(s->Wn.d(), s->ldw, s->B4.d(), s->ldu, s->T1a.d(), s->ldw, Mp, 1.0, 0.0);
     GPX_TRY(launch_gemm_nt(ctx, g, Ntp / TILE, mt, 0, GPX_PROF_GEMM_OTHER, 2.0 * Ntp * (double)Mp * Mp));
     GemmArgs h2 = gargs(s->T1a.d(), s->ldw, Tu, s->ldu, s->T1.d(), s->ldw, Mp, 1.0, 0.0);
-    GPX_TRY(launch_gemm_nt(ctx, h2, Ntp / TILE, mt, 0, GPX_PROF_GEMM_OTHER, 2.0 * Ntp * (double)Mp * Mp));
+    h2.kcol = 1;
+    if (ctx->persist_scope_ok) ctx->persist_scope += 1; // tiles of K = 128 ... Mp: dynamically scheduled, long ones first
+    const int rc_t1 = launch_gemm_nt(ctx, h2, Ntp / TILE, mt, 0, GPX_PROF_GEMM_OTHER, (double)Ntp * Mp * (Mp + TILE));
+    if (ctx->persist_scope_ok) ctx->persist_scope -= 1;
+    GPX_TRY(rc_t1);
   }
   GPX_TRY(ens(ctx, s->rcoef_u, (size_t)Mp * 8));
   GPX_TRY(ens(ctx, s->rcoef_f, (size_t)Ntp * 8));
@@ -611,10 +667,21 @@ int gpx_sgp_posterior(gpx_ctx* ctx, int kind, const double* ell, double scale, d
   GPX_TRY(ens(ctx, s->var2, (size_t)Msp * 8));
   GPX_HIP(ctx, hipMemcpyAsync(s->Xs.d(), Xnew, (size_t)Ms * d * 8, hipMemcpyHostToDevice, ctx->stream));
   // V1 = Ksu Luu^-T ; V2 = V1 LA^-T
-  GPX_TRY(launch_gram_padded(ctx, s->kp, s->Xs.d(), Ms, Msp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->V1.d(), s->ldw));
-  GPX_TRY(trsm_right_lt(ctx, s->V1.d(), s->ldw, st, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, 0));
-  GPX_HIP(ctx, hipMemcpyAsync(s->V2.d(), s->V1.d(), (size_t)Msp * s->ldw * 8, hipMemcpyDeviceToDevice, ctx->stream));
-  GPX_TRY(trsm_right_lt(ctx, s->V2.d(), s->ldw, st, s->A.d(), s->ldu, s->LinvA.d(), mt, 0));
+  if (ctx->sgp_inverse) { // one GEMM each against Luu^-1 (from the forward pass) and LA^-1
+    const size_t mm = (size_t)Mp * s->ldu * 8;
+    GPX_TRY(ens(ctx, s->B1, mm));
+    GPX_TRY(ens(ctx, s->VA, mm));
+    GPX_TRY(ens(ctx, s->Tscr, mm));
+    GPX_TRY(build_linv_t(ctx, s->A.d(), s->ldu, s->LinvA.d(), mt, s->B1.d(), s->ldu, s->Tscr.d(), s->VA.d()));
+    GPX_TRY(launch_gram_padded(ctx, s->kp, s->Xs.d(), Ms, Msp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->V2.d(), s->ldw));
+    GPX_TRY(solve_by_inverse(ctx, s->V2.d(), s->ldw, st, s->Vu.d(), s->ldu, mt, s->V1.d(), s->ldw));
+    GPX_TRY(solve_by_inverse(ctx, s->V1.d(), s->ldw, st, s->VA.d(), s->ldu, mt, s->V2.d(), s->ldw));
+  } else {
+    GPX_TRY(launch_gram_padded(ctx, s->kp, s->Xs.d(), Ms, Msp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->V1.d(), s->ldw));
+    GPX_TRY(trsm_right_lt(ctx, s->V1.d(), s->ldw, st, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, 0));
+    GPX_HIP(ctx, hipMemcpyAsync(s->V2.d(), s->V1.d(), (size_t)Msp * s->ldw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    GPX_TRY(trsm_right_lt(ctx, s->V2.d(), s->ldw, st, s->A.d(), s->ldu, s->LinvA.d(), mt, 0));
+  }
   const double kdiag = kd_value(s->kp) + noise_p + jitter; // Kss = kernel(X_new, X_new, params, noise_p, **jitter)
   GPX_TRY(launch_rowdot(ctx, s->V1.d(), s->ldw, Ms, M, s->c.d(), kdiag, nullptr, s->var.d(), 0));   // kd - |V1|^2
   GPX_TRY(launch_rowdot(ctx, s->V2.d(), s->ldw, Ms, M, s->c.d(), 0.0, s->mean.d(), s->var2.d(), 0)); // mean, -|V2|^2
