@@ -557,7 +557,7 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
 
   // ---- matrix adjoints in whitened form ------------------------------------------------------
   //   G_uu  = Tu H Tu^T - m m^T / (2 s2^2),   H = -Ainv/2 + (1/2 + [u]/2) I - [u] A/2
-  //   G_uf^T = W R Tu^T + rcoef_f m^T,        R = ([u] I - Ainv)/s2,  rcoef_f = y/s2^2 - t/s2^3
+  //   G_uf^T = W (Tu R)^T + rcoef_f m^T,        R = ([u] I - Ainv)/s2,  rcoef_f = y/s2^2 - t/s2^3
   const double uu = unclipped ? 1.0 : 0.0;
   double* Tu = s->B0.d();
   double* TA = s->B1.d();
@@ -584,17 +584,15 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
     h2.kcol = 1; // Tu is upper triangular: row j of the right factor starts at column j
     GPX_TRY(launch_gemm_nt(ctx, h2, mt, mt, 0, GPX_PROF_GEMM_OTHER, (double)Mp * Mp * (Mp + TILE)));
   }
-  GPX_TRY(ens(ctx, s->T1a, (size_t)Ntp * s->ldw * 8));
   GPX_TRY(ens(ctx, s->T1, (size_t)Ntp * s->ldw * 8));
-  { // T1a = W R ; T1 = T1a Tu^T
-    GemmArgs g = gargs(s->Wn.d(), s->ldw, s->B4.d(), s->ldu, s->T1a.d(), s->ldw, Mp, 1.0, 0.0);
-    GPX_TRY(launch_gemm_nt(ctx, g, Ntp / TILE, mt, 0, GPX_PROF_GEMM_OTHER, 2.0 * Ntp * (double)Mp * Mp));
-    GemmArgs h2 = gargs(s->T1a.d(), s->ldw, Tu, s->ldu, s->T1.d(), s->ldw, Mp, 1.0, 0.0);
-    h2.kcol = 1;
-    if (ctx->persist_scope_ok) ctx->persist_scope += 1; // tiles of K = 128 ... Mp: dynamically scheduled, long ones first
-    const int rc_t1 = launch_gemm_nt(ctx, h2, Ntp / TILE, mt, 0, GPX_PROF_GEMM_OTHER, (double)Ntp * Mp * (Mp + TILE));
-    if (ctx->persist_scope_ok) ctx->persist_scope -= 1;
-    GPX_TRY(rc_t1);
+  { // T1 = W R Tu^T as W (Tu R)^T: the M x M product first (M^3, k from the triangle of Tu; R is symmetric), then ONE
+    // N x M x M GEMM — instead of W R followed by (W R) Tu^T, i.e. 2 N M^2 + M^3 flop for 3 N M^2 (round 3)
+    double* Qt = s->B2.d(); // E1 is dead
+    GemmArgs g = gargs(Tu, s->ldu, s->B4.d(), s->ldu, Qt, s->ldu, Mp, 1.0, 0.0);
+    g.ktri = 1;
+    GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, 0, GPX_PROF_GEMM_OTHER, (double)Mp * Mp * (Mp + TILE)));
+    GemmArgs h2 = gargs(s->Wn.d(), s->ldw, Qt, s->ldu, s->T1.d(), s->ldw, Mp, 1.0, 0.0);
+    GPX_TRY(launch_gemm_nt(ctx, h2, Ntp / TILE, mt, 0, GPX_PROF_GEMM_OTHER, 2.0 * Ntp * (double)Mp * Mp));
   }
   GPX_TRY(ens(ctx, s->rcoef_u, (size_t)Mp * 8));
   GPX_TRY(ens(ctx, s->rcoef_f, (size_t)Ntp * 8));
