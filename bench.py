@@ -267,6 +267,17 @@ def base_line(a, world, K, W, dt, n_fl, parallelism):
     }
 
 
+def flush_c_stdio():
+    """RCCL prints a version banner through C stdio, which sits in the C library's buffer until the process exits when
+    stdout is a pipe — i.e. AFTER the JSON line.  Flush it out first: the JSON line is the last line a rank prints."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def single_gpu(a, device=0):
     """N = 1: K steps of the resident sweep on one GPU, `--inflight` contexts (the round-1/2 headline, unchanged)."""
     import threading
@@ -332,6 +343,7 @@ def single_gpu(a, device=0):
     out.update(device_record(eng, a, lml))
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_N or N, d, M, a.kernel, a.cpu_budget_s)
+    flush_c_stdio()
     print(json.dumps(out), flush=True)
 
 
@@ -437,6 +449,7 @@ def multi_rank(a, env):
 
     if W > 0:
         sweep(0, world * W)
+    flush_c_stdio()  # every rank's RCCL banner out now, not behind rank 0's JSON line
     rk.barrier()
     t0 = time.perf_counter()
     res = sweep(world * W, world * (W + K))
@@ -509,7 +522,9 @@ def multi_rank(a, env):
             ns = out["node_sweep"]
             if "c3_posteriors_per_s" in ns:
                 ns["c3_vs_rank_collective"] = ns["c3_posteriors_per_s"] / out["value"]
-        print(json.dumps(out), flush=True)
+        flush_c_stdio()
+        flush_c_stdio()
+    print(json.dumps(out), flush=True)
     # rank 0's solo phase (device record, node-sweep record) is over: everybody meets again
     store = launch.FileStore(os.path.join(env.rdzv_dir, f"bench{env.attempt}"))
     if root:
