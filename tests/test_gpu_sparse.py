@@ -95,3 +95,37 @@ def test_sparse_c5_shape_runs_and_is_deterministic(engine):
     full = ref.exactgp_log_likelihood(X, y, {"k_length": np.array([8.0, 8.0]), "k_scale": 1.0, "noise": 0.01},
                                       kernel="Matern")
     assert b1 <= full + 1e-6 * abs(full)  # the VFE bound never exceeds the exact log marginal likelihood
+
+
+@pytest.mark.parametrize("N,Mi", [(900, 100), (1500, 300), (2100, 700)])
+def test_solves_by_inverse_agree_with_the_sweeps(monkeypatch, N, Mi):
+    """sparse.hip round 3: W = Kfu Luu^-T, V1 = Ksu Luu^-T, V2 = V1 LA^-T as ONE GEMM each against L^-1 (from the
+    L^-T tree) and the gradient products trimmed to the triangle of Luu^-T / re-associated — against GPX_SGP_SOLVE=sweep
+    (the right-looking solves of rounds 1 - 2): bound, every gradient component and the posterior agree to rounding, and
+    both agree with the oracle (sparse_gp.py:62-114, 173-223)."""
+    from gpax_amd import _lib
+    X, y, Xn, p = bench_inputs.synthetic_problem(N, 2, 150, seed=5)
+    Xu = X[np.random.default_rng(2).choice(N, Mi, replace=False)] + 1e-3
+    outs = {}
+    for mode in ("inverse", "sweep"):
+        monkeypatch.setenv("GPX_SGP_SOLVE", mode)
+        e = _lib.Engine(0)
+        e.set_train(X)
+        b, info, g = e.sgp_bound(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, Xu, y, True)
+        mean, cov, var, info2 = e.sgp_posterior(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, Xu, y, Xn, 0.0,
+                                                want_cov=True, want_var=True)
+        assert info == 0 and info2 == 0
+        outs[mode] = (b, g, mean, cov, var)
+        e.close()
+    a, s = outs["inverse"], outs["sweep"]
+    assert abs(a[0] - s[0]) <= 1e-10 * abs(s[0])
+    for k in ("k_length", "k_scale", "noise", "Xu", "yres"):
+        u, v = np.asarray(a[1][k], dtype=float), np.asarray(s[1][k], dtype=float)
+        np.testing.assert_allclose(u, v, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(v).max()))
+    np.testing.assert_allclose(a[2], s[2], rtol=0, atol=1e-9 * np.abs(s[2]).max())
+    np.testing.assert_allclose(a[3], s[3], rtol=0, atol=1e-9 * np.abs(s[3]).max())
+    expect = ref.sparse_bound(X, y, Xu, p, kernel="Matern", jitter=1e-6)
+    assert abs(a[0] - expect) <= 1e-8 * abs(expect)
+    m_ref, c_ref = ref.sparse_posterior(X, y, Xu, Xn, p, noiseless=True, kernel="Matern", jitter=1e-6)
+    np.testing.assert_allclose(a[2], m_ref, rtol=0, atol=1e-7 * np.abs(m_ref).max())
+    np.testing.assert_allclose(a[3], c_ref, rtol=0, atol=1e-7 * np.abs(c_ref).max())
