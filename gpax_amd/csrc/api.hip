@@ -832,6 +832,7 @@ static int set_train_impl(gpx_ctx* ctx, const double* X, int T, int N, int d, bo
   if (d < 1 || d > GPX_MAX_DIM) return bad_arg(ctx, "input dimension must be 1..16");
   GPX_HIP(ctx, hipSetDevice(ctx->device));
   ctx->N = N;
+  ctx->train_gen += 1; // cached results that depend on X (sparse.hip forward pass) belong to the previous upload
   ctx->d = d;
   ctx->T = T;
   ctx->M = 0; // X_new of a previous training set does not carry over

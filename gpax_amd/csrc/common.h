@@ -265,6 +265,7 @@ struct gpx_ctx {
   int last_batch = 0;                           // samples per launch chosen by the last sweep
 
   void* sgp = nullptr; // sparse-GP state (sparse.hip)
+  uint64_t train_gen = 0; // bumped by every upload of X
 
   // ---- generic scratch for unit-test entry points ---------------------------------------
   gpx::DevBuf tA, tB, tC;

@@ -175,7 +175,11 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
                   int* info);
 
 /* viSparseGP.get_mvn_posterior (sparse_gp.py:173-223): Woodbury posterior at Xnew (Ms x d).
- * mean (Ms), cov (Ms*Ms or NULL), var (Ms or NULL).  noise_p = noise * (1 - noiseless). */
+ * mean (Ms), cov (Ms*Ms or NULL), var (Ms or NULL).  noise_p = noise * (1 - noiseless).
+ * Both sparse entry points keep the forward pass of the previous call (Kuu, Kuf, both factorisations) while the next
+ * call brings bit-identical kind / ell / scale / noise / jitter / Xu / yres on the same gpx_set_train upload — the
+ * reference's predict_in_batches (sparse_gp.py:225-262) calls the posterior once per slice of X_new with nothing else
+ * changed.  The values are those of a call that recomputes everything. */
 int gpx_sgp_posterior(gpx_ctx* ctx, int kind, const double* ell, double scale, double noise, double jitter,
                       const double* Xu, int Mi, const double* yres, const double* Xnew, int Ms, double noise_p,
                       double* mean, double* cov, double* var, int* info);

@@ -129,3 +129,45 @@ def test_solves_by_inverse_agree_with_the_sweeps(monkeypatch, N, Mi):
     m_ref, c_ref = ref.sparse_posterior(X, y, Xu, Xn, p, noiseless=True, kernel="Matern", jitter=1e-6)
     np.testing.assert_allclose(a[2], m_ref, rtol=0, atol=1e-7 * np.abs(m_ref).max())
     np.testing.assert_allclose(a[3], c_ref, rtol=0, atol=1e-7 * np.abs(c_ref).max())
+
+
+def test_forward_pass_is_reused_only_for_identical_inputs():
+    """sparse.hip sgp_setup: the forward pass (Kuu, Kfu, both factorisations, c) of the last call is kept while the next
+    call brings bit-identical kernel / theta / jitter / Xu / yres on the same X — what predict_in_batches does slice after
+    slice (sparse_gp.py:173-223 redoes it per slice).  Reused or not, the values are those of a fresh context; a new
+    yres, theta or X is noticed."""
+    from gpax_amd import _lib
+    X, y, Xn, p = bench_inputs.synthetic_problem(1100, 2, 120, seed=9)
+    Xu = X[::7] + 1e-3
+    args = lambda yy, ell: (1, ell, p["k_scale"], p["noise"], 1e-6, Xu, yy)  # noqa: E731
+
+    def fresh(Xt, yy, ell, Xs):
+        e = _lib.Engine(0)
+        e.set_train(Xt)
+        out = e.sgp_posterior(*args(yy, ell), Xs, 0.0, want_cov=False, want_var=True)
+        e.close()
+        return out
+
+    e = _lib.Engine(0)
+    e.set_train(X)
+    e.sgp_posterior(*args(y, p["k_length"]), Xn[:50], 0.0, want_cov=False, want_var=True)
+    again = e.sgp_posterior(*args(y, p["k_length"]), Xn, 0.0, want_cov=False, want_var=True)  # forward pass reused
+    base = fresh(X, y, p["k_length"], Xn)
+    np.testing.assert_array_equal(again[0], base[0])
+    np.testing.assert_array_equal(again[2], base[2])
+    b1, _, g1 = e.sgp_bound(*args(y, p["k_length"]), True)  # reused by the bound and its gradient as well
+    e2 = _lib.Engine(0)
+    e2.set_train(X)
+    b2, _, g2 = e2.sgp_bound(*args(y, p["k_length"]), True)
+    e2.close()
+    assert b1 == b2
+    for k in g1:
+        np.testing.assert_array_equal(np.asarray(g1[k]), np.asarray(g2[k]))
+    y2 = y + 0.25
+    np.testing.assert_array_equal(e.sgp_posterior(*args(y2, p["k_length"]), Xn, 0.0, want_cov=False)[0], fresh(X, y2, p["k_length"], Xn)[0])
+    ell2 = 1.3 * np.asarray(p["k_length"])
+    np.testing.assert_array_equal(e.sgp_posterior(*args(y2, ell2), Xn, 0.0, want_cov=False)[0], fresh(X, y2, ell2, Xn)[0])
+    X2 = X + 0.01
+    e.set_train(X2)
+    np.testing.assert_array_equal(e.sgp_posterior(*args(y2, ell2), Xn, 0.0, want_cov=False)[0], fresh(X2, y2, ell2, Xn)[0])
+    e.close()
