@@ -523,8 +523,7 @@ def multi_rank(a, env):
             if "c3_posteriors_per_s" in ns:
                 ns["c3_vs_rank_collective"] = ns["c3_posteriors_per_s"] / out["value"]
         flush_c_stdio()
-        flush_c_stdio()
-    print(json.dumps(out), flush=True)
+        print(json.dumps(out), flush=True)
     # rank 0's solo phase (device record, node-sweep record) is over: everybody meets again
     store = launch.FileStore(os.path.join(env.rdzv_dir, f"bench{env.attempt}"))
     if root:
