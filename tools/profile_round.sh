@@ -33,7 +33,9 @@ run sq "$B --steps 1 --warmup 0" --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYC
 python tools/c4_sweep.py > $O/c4_sweep.json 2> $O/c4_sweep.err
 run c4trace "python tools/c4_sweep.py" --kernel-trace --stats
 # fit + predict wall-clock through the model API (BASELINE metric, first half), the roctx marker trace, the ASan smoke
-python tools/fit_predict_wallclock.py > $O/fit_predict_wallclock.log 2>&1
+rm -f $O/fit_predict_wallclock.json
+python tools/fit_predict_wallclock.py C2 C3 > $O/fit_predict_wallclock.log 2>&1
+python tools/fit_predict_wallclock.py C1 >> $O/fit_predict_wallclock.log 2>&1
 rm -rf /tmp/prof_roctx
 GPX_ROCTX=1 timeout 300 rocprofv3 --marker-trace --kernel-trace --stats -d /tmp/prof_roctx -- python bench.py --no-cpu-baseline --steps 2 --warmup 1 --inflight 1 > $O/under_roctx.json 2> $O/roctx.err
 db=$(find /tmp/prof_roctx -name '*.db' | head -1)
