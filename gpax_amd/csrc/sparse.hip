@@ -510,6 +510,17 @@ static int sgp_forward_run(gpx_ctx* ctx, SgpState* s) {
   GPX_TRY(potrf_lower(ctx, s->A.d(), s->ldu, Mp, 0, s->LinvA.d(), dinfo + 1));
   // u = Wt y ;  c^T = (u^T / s2) LA^-T  (one-tile-row right TRSM)
   GPX_TRY(launch_rowdot(ctx, s->Wt.d(), s->ldt, M, N, ctx->yres.d(), 0.0, s->u.d(), nullptr, 0));
+  if (ctx->sgp_inverse) {
+    // TA = LA^-T and LA^-1 once, here: the gradient needs TA, the posterior LA^-1, and c = LA^-1 u / s2 is then one
+    // matrix-vector product instead of a one-tile-row sweep of 2 dependent launches per 128 columns (0.4 ms at 16 tiles)
+    GPX_TRY(ens(ctx, s->B1, mm));
+    GPX_TRY(ens(ctx, s->VA, mm));
+    GPX_TRY(build_linv_t(ctx, s->A.d(), s->ldu, s->LinvA.d(), mt, s->B1.d(), s->ldu, s->Tscr.d(), s->VA.d()));
+    GPX_HIP(ctx, hipMemsetAsync(s->c.d(), 0, (size_t)Mp * 8, ctx->stream));
+    GPX_TRY(launch_axpby(ctx, s->cpad.d(), 1.0 / s2, s->u.d(), 0.0, nullptr, M)); // cpad[0 .. M) = u / s2
+    GPX_TRY(launch_rowdot(ctx, s->VA.d(), s->ldu, M, M, s->cpad.d(), 0.0, s->c.d(), nullptr, 0));
+    return 0;
+  }
   GPX_HIP(ctx, hipMemsetAsync(s->cpad.d(), 0, (size_t)TILE * s->ldu * 8, ctx->stream));
   GPX_TRY(launch_axpby(ctx, s->cpad.d(), 1.0 / s2, s->u.d(), 0.0, nullptr, M));
   GPX_TRY(trsm_right_lt(ctx, s->cpad.d(), s->ldu, 1, s->A.d(), s->ldu, s->LinvA.d(), mt, 0));
@@ -557,7 +568,8 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
     GPX_TRY(ens(ctx, s->Tscr, mm));
     if (!ctx->sgp_inverse) // (otherwise Tu = Luu^-T is there since the forward pass)
       GPX_TRY(build_linv_t(ctx, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, Tu, s->ldu, s->Tscr.d()));
-    GPX_TRY(build_linv_t(ctx, s->A.d(), s->ldu, s->LinvA.d(), mt, TA, s->ldu, s->Tscr.d())); // TA = LA^-T
+    if (!ctx->sgp_inverse)
+      GPX_TRY(build_linv_t(ctx, s->A.d(), s->ldu, s->LinvA.d(), mt, TA, s->ldu, s->Tscr.d())); // TA = LA^-T
     // v = TA c ; m = s2 Tu v ; t = s2 W v
     GPX_TRY(launch_rowdot(ctx, TA, s->ldu, M, M, s->c.d(), 0.0, s->vvec.d(), nullptr, 1));
     GPX_TRY(launch_rowdot(ctx, Tu, s->ldu, M, M, s->vvec.d(), 0.0, s->mvec.d(), nullptr, 1));
@@ -701,12 +713,7 @@ int gpx_sgp_posterior(gpx_ctx* ctx, int kind, const double* ell, double scale, d
   GPX_TRY(ens(ctx, s->var2, (size_t)Msp * 8));
   GPX_HIP(ctx, hipMemcpyAsync(s->Xs.d(), Xnew, (size_t)Ms * d * 8, hipMemcpyHostToDevice, ctx->stream));
   // V1 = Ksu Luu^-T ; V2 = V1 LA^-T
-  if (ctx->sgp_inverse) { // one GEMM each against Luu^-1 (from the forward pass) and LA^-1
-    const size_t mm = (size_t)Mp * s->ldu * 8;
-    GPX_TRY(ens(ctx, s->B1, mm));
-    GPX_TRY(ens(ctx, s->VA, mm));
-    GPX_TRY(ens(ctx, s->Tscr, mm));
-    GPX_TRY(build_linv_t(ctx, s->A.d(), s->ldu, s->LinvA.d(), mt, s->B1.d(), s->ldu, s->Tscr.d(), s->VA.d()));
+  if (ctx->sgp_inverse) { // one GEMM each against Luu^-1 and LA^-1 (both from the forward pass)
     GPX_TRY(launch_gram_padded(ctx, s->kp, s->Xs.d(), Ms, Msp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->V2.d(), s->ldw));
     GPX_TRY(solve_by_inverse(ctx, s->V2.d(), s->ldw, st, s->Vu.d(), s->ldu, mt, s->V1.d(), s->ldw));
     GPX_TRY(solve_by_inverse(ctx, s->V1.d(), s->ldw, st, s->VA.d(), s->ldu, mt, s->V2.d(), s->ldw));
