@@ -11,8 +11,8 @@ Flop model (1 FMA = 2 flop; M = M_ind padded to 128, N padded to 128) — what t
 structure counted where the kernels use it (the library's own per-launch `work`, read back through gpx_profile_*):
   forward   potrf(Kuu) M^3/3 + Luu^-T (tree) M^3/3 + W = Kfu Luu^-T (one GEMM against Luu^-1, k range cut at the column
             tile)  N M^2 + A = I + W^T W / s2  N M^2 + potrf(A) M^3/3                                = 2 N M^2 + M^3
-  gradient  LA^-T M^3/3 + A^-1 = LA^-T LA^-1  M^3/3 + Tu H, (Tu H) Tu^T  2 x M^3 (k ranges start at the triangle)
-            + Tu R  M^3 + W (Tu R)^T  2 N M^2                                                        = 2 N M^2 + 11/3 M^3
+  gradient  LA^-T M^3/3 + A^-1 = LA^-T LA^-1  M^3/3 + Tu H  M^3 (k ranges start at the triangle) + the lower triangle of
+            the symmetric Tu H Tu^T  M^3/2 + Tu R  M^3 + W (Tu R)^T  2 N M^2                         = 2 N M^2 + 19/6 M^3
   posterior of Ms points: forward + V1 = Ksu Luu^-T  Ms M^2 + V2 = V1 LA^-T  Ms M^2 (+ O(Ms M) mean / variance)
 The Gram builds (Kuu, Kfu, Ksu: 8 B written per entry) and the on-the-fly dK contractions are HBM / VALU work and
 are not in the MFMA count."""
@@ -80,7 +80,7 @@ for want_grad, key in ((False, "bound"), (True, "bound_and_gradient")):
     f = lambda: eng.sgp_bound(1, ell, scale, fresh_noise(), 1e-6, Xu, y, want_grad)  # noqa: E731
     ms = median_ms(f)
     flops, kernel_ms = counted_flops(f)
-    model = 2.0 * Ntp * Mp * Mp + 1.0 * Mp ** 3 + (2.0 * Ntp * Mp * Mp + 11.0 / 3.0 * Mp ** 3 if want_grad else 0.0)
+    model = 2.0 * Ntp * Mp * Mp + 1.0 * Mp ** 3 + (2.0 * Ntp * Mp * Mp + 19.0 / 6.0 * Mp ** 3 if want_grad else 0.0)
     rec[key] = {"ms": ms, "mfma_flops_counted": flops, "mfma_flops_model": model, "tflops": flops / (ms * 1e-3) / 1e12,
                 "frac_of_fp64_peak": flops / (ms * 1e-3) / PEAK, "mfma_kernel_ms_sum": kernel_ms}
 b, info, g = eng.sgp_bound(1, ell, scale, noise, 1e-6, Xu, y, True)
