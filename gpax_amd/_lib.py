@@ -17,7 +17,7 @@ KERNEL_KINDS = {"RBF": 0, "Matern": 1, "Periodic": 2}
 KIND_PERIODIC = 2
 MAX_DIM = 16
 
-PROF_GEMM_TRAILING, PROF_GEMM_OTHER, PROF_POTF2, PROF_GRAM, PROF_PANEL = 0, 1, 2, 3, 4
+PROF_GEMM_TRAILING, PROF_GEMM_OTHER, PROF_POTF2, PROF_GRAM = 0, 1, 2, 3
 STAGE_GRAM, STAGE_POTRF, STAGE_FITSTEP, STAGE_POSTERIOR, STAGE_PREDICT = 0, 1, 2, 3, 4
 
 # GPX_LIB: another build of the same ABI (e.g. the AddressSanitizer build, `make -C gpax_amd/csrc asan`)
@@ -77,9 +77,8 @@ def load_library() -> C.CDLL:
         "gpx_profile_reset": (C.c_int, [vp]),
         "gpx_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64), _dp, _dp]),
         "gpx_profile_read_bytes": (C.c_int, [vp, C.c_int, _dp]),
-        "gpx_debug_tile_order": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_int), C.c_int]),
+        "gpx_debug_set_potf2": (C.c_int, [vp, C.c_char_p]),
         "gpx_time_stage": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
-        "gpx_panel_stats": (C.c_int, [vp, C.POINTER(C.c_int64), _ip, _ip]),
         "gpx_sweep_resident": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp]),
         "gpx_sweep_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
         "gpx_mfma_f64_peak": (C.c_int, [vp, _dp]),
@@ -117,7 +116,7 @@ EXPORTED_SYMBOLS = (
     "gpx_init gpx_device_count gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
     "gpx_factor gpx_lml_grad gpx_lml_grad_diag gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
-    "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_tile_order gpx_time_stage gpx_panel_stats gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
+    "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_set_potf2 gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_predict_sweep_multi "
     "gpx_rank_unique_id gpx_rank_init gpx_rank_destroy gpx_rank_last_error gpx_rank_info gpx_rank_barrier "
     "gpx_rank_allreduce_max gpx_rank_bcast gpx_rank_predict_sweep gpx_shard_range"
@@ -427,12 +426,10 @@ class Engine:
         self._check(self._lib.gpx_profile_read_bytes(self._ctx, cls, C.byref(b)), "gpx_profile_read_bytes")
         return b.value
 
-    def panel_stats(self) -> dict:
-        """Cooperative panel-chain kernel (csrc/panel.hip): launches issued by this context, launches that ran on the
-        device, and the device-side fail flag."""
-        n, ran, failed = C.c_int64(), C.c_int(), C.c_int()
-        self._check(self._lib.gpx_panel_stats(self._ctx, C.byref(n), C.byref(ran), C.byref(failed)), "gpx_panel_stats")
-        return {"launches": int(n.value), "ran": int(ran.value), "failed": int(failed.value)}
+    def set_potf2(self, mode: str) -> None:
+        """Diagonal-block kernel of the blocked Cholesky for the following calls: 'slim' (default), 'chain', 'tile' —
+        the same bits from all three (gpx_debug_set_potf2; bench.py's in-process A/B)."""
+        self._check(self._lib.gpx_debug_set_potf2(self._ctx, mode.encode()), "gpx_debug_set_potf2")
 
     def time_stage(self, stage: int, reps: int) -> float:
         ms = C.c_double()

@@ -634,50 +634,11 @@ int gpx_init(int device, gpx_ctx** out) {
   {
     int lo = 0, hi = 0; // numerically lower = higher priority
     GPX_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    // CU reservation: mask bit i is CU (i / 8) of XCD (i % 8) on gfx950 (tools/exp/cumask_probe.hip: bits 0..7 =
-    // CU 0 of each of the 8 XCDs), so reserving a multiple of 8 bits keeps the XCDs balanced.
-    // MEASURED AND REJECTED as a default (profiles/r02/cu_reserve.md): with 8 CUs reserved the potf2 launches drop
-    // from 171 to 50 us each inside the pipeline, but a masked queue still gets its workgroups balanced over the 32
-    // shader engines, so the engines that lost a CU (7 of 8 left) set the pace of the trailing update: 28.7 -> 32.4 ms
-    // per factorisation (roofline 0.69 -> 0.61), potrf 31.4 -> 32.5 ms.  Kept behind GPX_CU_RESERVE for experiments.
-    int reserve = 0;
-    if (const char* e = getenv("GPX_CU_RESERVE")) reserve = atoi(e);
-    const int ncu = ctx->prop.multiProcessorCount;
-    reserve = (reserve / 8) * 8;
-    if (reserve < 0 || reserve > ncu / 4 || ncu % 32 != 0) reserve = 0;
-    bool soft = false;
-    if (const char* e = getenv("GPX_CU_RESERVE_SOFT")) {
-      if (atoi(e) == 8 && ncu % 32 == 0) {
-        reserve = 8;
-        soft = true;
-      }
-    }
-    if (reserve > 0) {
-      const int words = ncu / 32;
-      std::vector<uint32_t> m_main((size_t)words, 0xffffffffu), m_res((size_t)words, 0u);
-      for (int b = 0; b < reserve; ++b) {
-        m_main[(size_t)(b / 32)] &= ~(1u << (b % 32));
-        m_res[(size_t)(b / 32)] |= (1u << (b % 32));
-      }
-      // soft reservation: only the q stream of the diagonal blocks is masked; the main stream stays an ordinary
-      // low-priority stream and the persistent GEMM keeps off the reserved CUs by itself
-      if ((!soft && hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)words, m_main.data()) != hipSuccess) ||
-          hipExtStreamCreateWithCUMask(&ctx->rstream, (uint32_t)words, m_res.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-        if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
-        ctx->stream = ctx->rstream = nullptr;
-        reserve = 0;
-      } else {
-        GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evR0, hipEventDisableTiming));
-        GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evR1, hipEventDisableTiming));
-      }
-    }
-    ctx->cu_reserved = reserve;
-    ctx->soft_reserve = soft && reserve > 0;
-    ctx->persist_gemm = reserve > 0;
-    if (const char* e = getenv("GPX_PERSIST_GEMM")) ctx->persist_gemm = (e[0] == '1');
-    if (const char* e = getenv("GPX_PERSIST_SLACK")) ctx->persist_slack = atoi(e);
+    // The library's switches (12 in all, this list + GPX_ROCTX, GPX_SWEEP_BATCH, GPX_NODE_TRANSPORT, GPX_RANK_FILE_TIMEOUT):
+    // each selects the ONE alternate of a kernel / schedule that the bit-identity tests compare the default against.
+    // Everything else rounds 1 - 3 measured and rejected (CU reservations, early diagonal, split U1 / far updates,
+    // XCD-aware tile order, cooperative panel kernel, column / blocked potf2) left the library in round 4:
+    // profiles/r04/pruned.md names the commit each one last lived in.
     if (const char* e = getenv("GPX_PERSIST_SCOPE")) ctx->persist_scope_ok = (e[0] != '0');
     if (const char* e = getenv("GPX_LAZY_GROUP")) {
       const int lg = atoi(e);
@@ -687,40 +648,16 @@ int gpx_init(int device, gpx_ctx** out) {
       const int ot = atoi(e);
       if (ot >= 1 && ot <= 32) ctx->outer_tiles = ot;
     }
-    if (!ctx->stream) GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, lo));
+    if (const char* e = getenv("GPX_TAIL_TILES")) ctx->tail_tiles = atoi(e);
+    GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, lo));
     GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->pstream, hipStreamNonBlocking, hi));
-    GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->qstream, hipStreamNonBlocking, hi));
     GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evD, hipEventDisableTiming));
-    GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evQ, hipEventDisableTiming));
-    GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evB, hipEventDisableTiming));
-    if (const char* e = getenv("GPX_U1_SPLIT")) ctx->u1_split = atoi(e);
-    if (const char* e = getenv("GPX_FAR_AFTER_U1")) ctx->far_after_u1 = atoi(e);
-    if (const char* e = getenv("GPX_POTF2")) { // "chain" (default) | "tile": the four-phase kernel of round 2 | "column": round 1
-      const std::string v(e);
-      ctx->potf2_column = (v == "column");
-      ctx->potf2_chain = !(v == "tile" || v == "column");
+    if (const char* e = getenv("GPX_POTF2")) {
+      if (gpx_debug_set_potf2(ctx, e) != 0) return -1;
     }
-    if (const char* e = getenv("GPX_POTF2_DIAG")) ctx->potf2_diag_blocked = (e[0] == 'b');
-    if (const char* e = getenv("GPX_GEMM_SMALL")) ctx->gemm_small = (e[0] != '0');
     if (const char* e = getenv("GPX_SMALL_BK")) ctx->small_bk = (atoi(e) == 32) ? 32 : (atoi(e) == 16 ? 16 : 0);
-    if (const char* e = getenv("GPX_SMALL_BK_ROWS")) ctx->small_bk_rows = atoi(e);
     if (const char* e = getenv("GPX_LINVT")) ctx->linvt_tree = (std::strcmp(e, "sweep") == 0) ? 0 : 1;
     if (const char* e = getenv("GPX_SGP_SOLVE")) ctx->sgp_inverse = (std::strcmp(e, "sweep") == 0) ? 0 : 1;
-    if (const char* e = getenv("GPX_SMALL_TILES_MAX")) ctx->small_tiles_max = atof(e);
-    if (const char* e = getenv("GPX_SPLIT_FAR")) ctx->split_far = atoi(e);
-    if (ctx->split_far > 0) {
-      GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo));
-      GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evS2, hipEventDisableTiming));
-      GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evU2, hipEventDisableTiming));
-    }
-    if (const char* e = getenv("GPX_PANEL_KERNEL")) ctx->panel_mode = atoi(e);
-    if (const char* e = getenv("GPX_PANEL_MAX_FAR")) ctx->panel_max_far = atoi(e);
-    if (const char* e = getenv("GPX_EARLY_DIAG")) ctx->early_diag = atoi(e); // 0 off, 1 everywhere, 2 in the tail
-    if (const char* e = getenv("GPX_TAIL_TILES")) ctx->tail_tiles = atoi(e);
-    if (const char* e = getenv("GPX_TAIL_OUTER_TILES")) ctx->tail_outer_tiles = atoi(e);
-    if (const char* e = getenv("GPX_TILE_SWIZZLE")) ctx->tile_swizzle = atoi(e);
-    if (const char* e = getenv("GPX_TILE_SWIZZLE_MIN")) ctx->tile_swizzle_min = atoi(e);
-    if (const char* e = getenv("GPX_GRID_PAD8")) ctx->grid_pad8 = atoi(e);
     ctx->s = ctx->stream;
   }
   GPX_HIP(ctx, hipEventCreate(&ctx->ev0));
@@ -755,19 +692,9 @@ void gpx_destroy(gpx_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->evP) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->evU) (void)hipEventDestroy(e);
-    ctx->panel_sync.release();
     for (hipEvent_t e : ctx->tile_counter_ev)
       if (e) (void)hipEventDestroy(e);
-    if (ctx->evR0) (void)hipEventDestroy(ctx->evR0);
-    if (ctx->evR1) (void)hipEventDestroy(ctx->evR1);
-    if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
     if (ctx->evD) (void)hipEventDestroy(ctx->evD);
-    if (ctx->evQ) (void)hipEventDestroy(ctx->evQ);
-    if (ctx->qstream) (void)hipStreamDestroy(ctx->qstream);
-    if (ctx->evB) (void)hipEventDestroy(ctx->evB);
-    if (ctx->evS2) (void)hipEventDestroy(ctx->evS2);
-    if (ctx->evU2) (void)hipEventDestroy(ctx->evU2);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->pstream) (void)hipStreamDestroy(ctx->pstream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   }
@@ -1228,15 +1155,14 @@ int gpx_profile_read_bytes(gpx_ctx* ctx, int cls, double* total_bytes) {
   return 0;
 }
 
-int gpx_debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n, int* xcd_by_bx, int cap) {
-  if (tiles_m < 1 || tiles_n < 1 || cap < 0 || (cap > 0 && !xcd_by_bx)) return -1;
-  return gpx::debug_tile_order(lower, ti_off, tj_off, tiles_m, tiles_n, xcd_by_bx, cap);
-}
-
-int gpx_panel_stats(gpx_ctx* ctx, int64_t* launches, int* ran, int* failed) {
-  if (!ctx || ctx->device < 0) return -1;
-  GPX_HIP(ctx, hipSetDevice(ctx->device));
-  return panel_stats(ctx, launches, ran, failed);
+int gpx_debug_set_potf2(gpx_ctx* ctx, const char* mode) {
+  if (!ctx || !mode) return -1;
+  const std::string v(mode);
+  if (v == "slim") ctx->potf2_mode = gpx::GPX_POTF2_SLIM;
+  else if (v == "chain") ctx->potf2_mode = gpx::GPX_POTF2_CHAIN;
+  else if (v == "tile") ctx->potf2_mode = gpx::GPX_POTF2_TILE;
+  else return bad_arg(ctx, "potf2 kernel: slim | chain | tile");
+  return 0;
 }
 
 int gpx_time_stage(gpx_ctx* ctx, int stage, int reps, double* elapsed_ms) {

@@ -14,12 +14,16 @@
 namespace gpx {
 
 constexpr int GPX_TILE_COUNTERS = 1024;
-constexpr int GPX_SWZ_MAX_STRIPS = 32; // XCD-aware tile order: strips of 8 tile rows, i.e. up to 256 tile rows (32768 matrix rows) per launch
 constexpr int TILE = 128;      // MFMA GEMM block tile and diagonal-block size
 constexpr int OUTER_TILES = 4; // default outer blocking of the right-looking sweeps (4*128 = 512); ctx->outer_tiles
 constexpr double AUG_BIG = 1e300;
 constexpr double SQRT5 = 2.23606797749978969641;
 constexpr double MATERN_EPS = 1e-12; // gpax/kernels/kernels.py:20-21
+// k-step 32 of the latency shapes for SINGLE-SAMPLE sweeps over matrices of up to this many tile rows (gpx_ctx::small_bk)
+constexpr int SMALL_BK_ROWS = 40;
+// tile rows below which the single-sample far update of the Cholesky waits for U1 of the same block (linalg.hip)
+constexpr int FAR_AFTER_U1 = 40;
+enum { GPX_POTF2_SLIM = 0, GPX_POTF2_CHAIN = 1, GPX_POTF2_TILE = 2 }; // gpx_ctx::potf2_mode
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -143,63 +147,26 @@ struct gpx_ctx {
   hipStream_t stream = nullptr;  // main stream (API copies, trailing updates)
   hipStream_t pstream = nullptr; // high-priority panel stream (lookahead)
   hipStream_t s = nullptr;       // stream the launch helpers currently target
-  // CU reservation (GPX_CU_RESERVE = multiple of 8, default 0 = off; see gpx_init): the main stream's CU mask leaves
-  // these CUs out and `rstream` may ONLY use them, so the single-workgroup diagonal-block factorisations of the panel
-  // chain do not share a CU (MFMA pipe, LDS) with two resident trailing-update workgroups
-  hipStream_t rstream = nullptr;
-  int cu_reserved = 0;
-  hipEvent_t evR0 = nullptr, evR1 = nullptr;
-  // early diagonal (linalg.hip): the next diagonal block is factored on `qstream` while the rest of the update that
-  // produced it is still running on the panel stream
-  hipStream_t qstream = nullptr;
-  // GPX_SPLIT_FAR: the trailing updates of the Cholesky are issued as two launches — even and odd tile rows — on two
-  // streams, so that the partly filled last round of one fills with the other's workgroups (linalg.hip)
-  bool potf2_diag_blocked = false; // GPX_POTF2_DIAG=blocked: the 16 x 16 diagonal tiles factored four columns per LDS round trip (bit-identical, slower)
-  bool potf2_chain = true;        // GPX_POTF2=tile: the four-phase kernel of round 2 instead of the wave-specialised one (potf2_chain.h)
-  bool potf2_column = false;      // GPX_POTF2=column: the column-by-column diagonal-block kernel of round 1
+  // diagonal-block kernel (potf2.hip): GPX_POTF2 = slim (default: placed at once beside two resident trailing-update
+  // workgroups) | chain (round 3: all tiles in registers, needs a drained CU) | tile (round 2: the tests' reference)
+  int potf2_mode = gpx::GPX_POTF2_SLIM;
   // k-step of the latency shapes: GPX_SMALL_BK = 16 | 32 forces it; default 0 = per driver call (small_bk_now): 32 for
-  // SINGLE-SAMPLE sweeps over matrices of up to GPX_SMALL_BK_ROWS tile rows — nothing saturates the chip there and the
+  // SINGLE-SAMPLE sweeps over matrices of up to SMALL_BK_ROWS tile rows — nothing saturates the chip there and the
   // fatter k-step halves the barriers of every chain launch (potrf -2 ... -5 % at N = 512 ... 4096) — 16 otherwise (34 /
   // 42 KB of LDS no longer fit beside two resident trailing-update workgroups: +2 % at N = 16384; batched small-N
   // sweeps lose 3 - 6 % of their occupancy-bound throughput).  Never changes a bit.
   int small_bk = 0;
-  int small_bk_rows = 40;
   int small_bk_now = 16;
-  bool gemm_small = true;         // GPX_GEMM_SMALL=0: no latency shapes
-  double small_tiles_max = 400.0; // GPX_SMALL_TILES_MAX: launches with fewer 128x128 tiles take the latency shapes
-  int far_after_u1 = 40; // GPX_FAR_AFTER_U1: tile rows below which the (single-sample) far update waits for U1 of the same block (0: never)
-  int split_far = 0;
-  int u1_split = 0; // GPX_U1_SPLIT: the columns of U1 the next potf2 + TRSM do not need run on the q stream (1: tail, 2: always)
-  hipEvent_t evB = nullptr;
-  hipStream_t stream2 = nullptr;
-  hipEvent_t evS2 = nullptr, evU2 = nullptr;
-  hipEvent_t evD = nullptr, evQ = nullptr;
-  // persistent, dynamically scheduled big-tile GEMM (gemm_f64.hip) — switched on together with the CU reservation
-  bool persist_gemm = false;
+  hipEvent_t evD = nullptr;
   // > 0 while a driver whose own panel chain holds no potf2 (the right-looking TRSM sweeps, the K^-1 = W W^T product)
   // is queueing launches: its big-tile GEMMs run persistently (GPX_PERSIST_SCOPE=0 disables)
-  int persist_slack = 0;
-  bool soft_reserve = false; // GPX_CU_RESERVE_SOFT=8: rstream masked to 8 CUs, persistent GEMM workgroups avoid them themselves
   int persist_scope = 0;
   bool persist_scope_ok = true;
   gpx::DevBuf tile_counters;
   unsigned tile_counter_seq = 0;
   std::vector<hipEvent_t> tile_counter_ev;      // per ring slot: recorded behind the last kernel that used it ...
   std::vector<hipStream_t> tile_counter_stream; // ... and the stream it ran on
-  int grid_pad8 = 0; // GPX_GRID_PAD8: grid.x of the big-tile GEMM padded to a multiple of 8, so that XCD x (workgroup id % 8) sees tile columns x, x + 8, ... in every tile row
-  int tile_swizzle_min = 1024; // GPX_TILE_SWIZZLE_MIN: tiles a launch must have for the XCD-aware order
-  int tile_swizzle = 0; // GPX_TILE_SWIZZLE: XCD-aware tile order of the big-tile GEMM (8x8-tile chunks per XCD), 0 = grid order
-  int tail_outer_tiles = 0; // GPX_TAIL_OUTER_TILES: outer block width in the tail (0 / >= outer_tiles: same as the head)
   int tail_tiles = 72; // GPX_TAIL_TILES: an outer block is in the chain-bound tail when fewer tile rows than this remain (0: no tail)
-  // cooperative panel-chain kernel (panel.hip): GPX_PANEL_KERNEL = 0 off (default: measured slower than the launches at
-  // every size, profiles/r03/panel_kernel.md), 1 in the chain-bound tail (single-sample factorisations), 2 everywhere
-  int panel_mode = 0;
-  int panel_max_far = 16; // GPX_PANEL_MAX_FAR: tile rows below an outer block up to which its chain runs cooperatively
-  int panel_ok = -1; // -1: dispatch rule not probed yet; 0 / 1: result of panel_probe on this device
-  gpx::DevBuf panel_sync;
-  int panel_epoch = 0;
-  int64_t panel_launches = 0;
-  int early_diag = 0; // GPX_EARLY_DIAG=1 switches it on: measured slower (profiles/r02/chain_experiments.md), default off
   std::vector<hipEvent_t> evP, evU; // per-outer-block panel / next-panel-update events
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
@@ -370,30 +337,19 @@ struct GemmArgs {
   int kcol;    // k range starts at (tj_off + bx) * 128 (B upper triangular, e.g. L^-T as the right factor)
   int kchunk;  // split-K chunk (multiple of 16), 0 = no split
   int64_t c_split_stride;
-  int skip;    // != 0: the 128-tile (skip_ti, skip_tj) of the caller's global tile frame is left out (it was updated by
-  int skip_ti, skip_tj; // an earlier launch of its own: the "early diagonal" of the Cholesky panel chain, linalg.hip)
-  int nx;      // > 0: workgroups with blockIdx.x >= nx have no tile (grid.x padded to a multiple of 8, GPX_GRID_PAD8)
-  int row_step, row_phase; // row_step > 1 (big-tile kernel only): the launch covers tile rows row_phase, row_phase + row_step, ...
   int nsplit;  // grid.z = nsplit * batch (filled in by launch_gemm_nt)
   int batch;   // independent problems per launch (0 or 1 = one); element b at base + b * *_bs
   int64_t a_bs, b_bs, c_bs;
   int batch2;  // > 1: two-level batch — entry = outer * batch2 + inner, at base + outer * *_bs + inner * *_bs2
   int64_t a_bs2, b_bs2, c_bs2;
 };
-int debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n, int* out, int cap);
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
                    int prof_cls, double work);
 int mfma_peak(gpx_ctx* ctx, double* tflops);
 
 // potf2.hip
 int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo,
-                     int info_base, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0,
-                     const double* dPre = nullptr, int Kpre = 0);
-
-// panel.hip
-int panel_probe(gpx_ctx* ctx);
-int launch_panel_chain(gpx_ctx* ctx, double* dA, int64_t lda, int nrows, int ob, int oe, double* dLinv, int* dInfo);
-int panel_stats(gpx_ctx* ctx, int64_t* launches, int* ran, int* failed);
+                     int info_base, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0);
 
 // linalg.hip
 int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,

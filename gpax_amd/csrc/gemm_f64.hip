@@ -48,166 +48,7 @@ template <int TAG, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // non-trailing launches sit on the critical path of the look-ahead
-  if (g.nx > 0 && (int)blockIdx.x >= g.nx) return;
-  const int by = g.row_step > 1 ? (int)blockIdx.y * g.row_step + g.row_phase : (int)blockIdx.y;
-  nt128_tile<EPI>(g, smem, blockIdx.x, by, blockIdx.z);
-}
-
-// XCD-AWARE TILE ORDER.  Workgroup b of a launch runs on XCD b % 8 (observed dispatch rule, used for speed only), and
-// each XCD has its own 4 MB L2.  In grid order the 64 workgroups an XCD holds at a time (2 per CU) are every 8th tile
-// of ~7 consecutive tile rows: they share 7 A row panels but almost no B panels, and the A / B panels are fetched
-// 2.1 x as often as an ideal 8 x 8 block of tiles would need (profiles/r02/fetch.md: 1.9 GB fetched per launch for
-// 0.2 GB of C tiles).  Here the tiles are cut into strips of 8 tile rows; an ITEM is one tile column of a strip (up to 8
-// tiles that share their B panel), items are numbered strip by strip, left to right, and XCD x takes the CONTIGUOUS
-// item range xstart[x] .. xstart[x + 1]: its 64 resident workgroups are 8 neighbouring items = an 8 x 8 block of tiles
-// that needs 8 A + 8 B panels, each fetched once per XCD and k step while the block proceeds in step.  The ranges are
-// cut where the cumulative tile count passes k / 8 of the total, so every XCD gets the same number of tiles to within
-// one item (a round-robin of whole 8 x 8 chunks left up to 12 % imbalance: diagonal chunks hold 36 tiles, not 64).
-// A tile's arithmetic does not depend on who computes it or when: results are those of grid order bit for bit.
-struct SwzMap {
-  int tiles_m, tiles_n, nstrips, max_items;
-  int mode; // 1: contiguous item range per XCD; 2: items dealt round-robin (item i -> XCD i % 8)
-  int pre[GPX_SWZ_MAX_STRIPS + 1]; // items before strip t
-  int xstart[9];
-};
-
-static bool make_swz_map(const GemmArgs& g, int tiles_m, int tiles_n, SwzMap& sm) {
-  sm.tiles_m = tiles_m;
-  sm.tiles_n = tiles_n;
-  const int delta = g.ti_off - g.tj_off;
-  if (sm.mode == 3) {
-    // ANTI-LOCALITY order (diagnostic): super blocks of 64 x 64 tiles; in round rho of a super block XCD x takes the
-    // wrapped diagonal { (i, (i + 8 rho + x) mod 64) }: its 64 resident workgroups share no A and no B panel.
-    sm.nstrips = (tiles_m + 63) / 64; // super-block rows
-    if (sm.nstrips > GPX_SWZ_MAX_STRIPS) return false;
-    const int ncb = (tiles_n + 63) / 64;
-    int acc = 0;
-    for (int R = 0; R < sm.nstrips; ++R) {
-      sm.pre[R] = acc;
-      int nc = ncb;
-      if (g.lower) {
-        const int last = (64 * R + 63 < tiles_m ? 64 * R + 63 : tiles_m - 1) + delta; // largest admissible column
-        nc = last < 0 ? 0 : last / 64 + 1;
-        if (nc > ncb) nc = ncb;
-      }
-      acc += nc;
-    }
-    sm.pre[sm.nstrips] = acc;
-    sm.max_items = acc * 64; // x 64 workgroups each in the launch arithmetic below = 4096 per super block
-    for (int k = 0; k <= 8; ++k) sm.xstart[k] = 0;
-    return acc > 0;
-  }
-  sm.nstrips = (tiles_m + 7) / 8;
-  if (sm.nstrips > GPX_SWZ_MAX_STRIPS) return false;
-  // tiles of item (t, bx): rows max(8 t, bx - delta) .. last(t) when lower, all rows of the strip otherwise
-  auto strip_last = [&](int t) { return 8 * t + 7 < tiles_m ? 8 * t + 7 : tiles_m - 1; };
-  auto strip_cols = [&](int t) {
-    if (!g.lower) return tiles_n;
-    int nc = strip_last(t) + delta + 1;
-    return nc < 0 ? 0 : (nc > tiles_n ? tiles_n : nc);
-  };
-  auto item_tiles = [&](int t, int bx) {
-    int lo = 8 * t;
-    if (g.lower && bx - delta > lo) lo = bx - delta;
-    return strip_last(t) - lo + 1;
-  };
-  int64_t total = 0;
-  int items = 0;
-  for (int t = 0; t < sm.nstrips; ++t) {
-    sm.pre[t] = items;
-    const int nc = strip_cols(t);
-    for (int bx = 0; bx < nc; ++bx) total += item_tiles(t, bx);
-    items += nc;
-  }
-  sm.pre[sm.nstrips] = items;
-  if (items <= 0 || total <= 0) return false;
-  if (sm.mode == 2) {
-    sm.max_items = (items + 7) / 8;
-    for (int k = 0; k <= 8; ++k) sm.xstart[k] = 0;
-    return true;
-  }
-  int x = 1, i = 0;
-  int64_t cum = 0;
-  sm.xstart[0] = 0;
-  for (int t = 0; t < sm.nstrips && x < 8; ++t) {
-    const int nc = strip_cols(t);
-    for (int bx = 0; bx < nc && x < 8; ++bx, ++i) {
-      const int64_t w = item_tiles(t, bx);
-      // item i goes to the range whose share its midpoint falls in
-      while (x < 8 && (cum + w / 2) * 8 >= total * x) sm.xstart[x++] = i;
-      cum += w;
-    }
-  }
-  while (x <= 8) sm.xstart[x++] = items;
-  sm.xstart[8] = items;
-  sm.max_items = 0;
-  for (int k = 0; k < 8; ++k)
-    if (sm.xstart[k + 1] - sm.xstart[k] > sm.max_items) sm.max_items = sm.xstart[k + 1] - sm.xstart[k];
-  return true;
-}
-
-// workgroup L of a launch -> its tile; false: nothing to do (range exhausted, or a row past the last strip's end)
-__host__ __device__ __forceinline__ bool swz_decode(const SwzMap& sm, int L, int& by, int& bx) {
-  const int x = L & 7, s = L >> 3; // slot s of XCD x: item xstart[x] + s / 8, row s % 8 of its strip
-  if (sm.mode == 3) {
-    const int rho = s >> 6, i = s & 63;
-    const int sb = rho >> 3, off = ((rho & 7) << 3) + ((x + i) & 7); // rotated with the row: every XCD gets every offset equally often
-    if (sb >= sm.pre[sm.nstrips]) return false;
-    int R = 0;
-    while (R + 1 < sm.nstrips && sm.pre[R + 1] <= sb) ++R;
-    by = 64 * R + i;
-    bx = 64 * (sb - sm.pre[R]) + ((i + off) & 63);
-    return by < sm.tiles_m && bx < sm.tiles_n;
-  }
-  int item;
-  if (sm.mode == 2) {
-    item = ((s >> 3) << 3) + ((x + (s >> 3)) & 7); // rotated per group of 8: the short diagonal items go round the XCDs
-    if (item >= sm.pre[sm.nstrips]) return false;
-  } else {
-    item = sm.xstart[x] + (s >> 3);
-    if (item >= sm.xstart[x + 1]) return false;
-  }
-  int t = 0;
-  while (t + 1 < sm.nstrips && sm.pre[t + 1] <= item) ++t;
-  by = 8 * t + (s & 7);
-  bx = item - sm.pre[t];
-  return by < sm.tiles_m;
-}
-
-template <int TAG, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt128_swz_kernel(GemmArgs g, SwzMap sm) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (TAG == 0) __builtin_amdgcn_s_setprio(2);
-  int by, bx;
-  if (!swz_decode(sm, blockIdx.x, by, bx)) return;
-  nt128_tile<EPI>(g, smem, bx, by, blockIdx.y);
-}
-
-// host-side view of the order for tests: out[3 i .. 3 i + 2] = (xcd, by, bx) of the i-th tile a launch would compute
-// (lower: tiles above the diagonal are dropped as the kernel drops them); returns the count, -1 if the shape is not
-// handled (more than GPX_SWZ_MAX_STRIPS strips)
-int debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n, int* out, int cap) {
-  GemmArgs g{};
-  g.lower = lower;
-  g.ti_off = ti_off;
-  g.tj_off = tj_off;
-  SwzMap sm;
-  sm.mode = lower >= 4 ? 3 : (lower >= 2 ? 2 : 1); // diagnostic: lower = 2 / 3: round-robin deal, 4 / 5: anti-locality
-  g.lower = lower = (lower & 1);
-  if (!make_swz_map(g, tiles_m, tiles_n, sm)) return -1;
-  int n = 0;
-  for (int L = 0; L < sm.max_items * 64; ++L) {
-    int by, bx;
-    if (!swz_decode(sm, L, by, bx)) continue;
-    if (lower && (tj_off + bx) * 128 > (ti_off + by) * 128 + 127) continue;
-    if (n < cap) {
-      out[3 * n] = L & 7;
-      out[3 * n + 1] = by;
-      out[3 * n + 2] = bx;
-    }
-    ++n;
-  }
-  return n;
+  nt128_tile<EPI>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Tile enumeration of a persistent launch: only the tiles a launch really has (lower: tj_off + bx <= ti_off + by),
@@ -245,24 +86,14 @@ __device__ __forceinline__ void decode_tile(const TileMap& tm, int lower, int l,
   }
 }
 
-// PERSISTENT, dynamically scheduled variant (used when CUs are reserved for the panel chain, gpx_init): the grid is
-// two workgroups per CU the stream may use; each takes the next tile from an atomic counter until none is left.  A
-// tile's arithmetic does not depend on who computes it, so results are those of gemm_nt128_kernel bit for bit; what
-// changes is that a CU-masked queue no longer suffers from the dispatcher spreading workgroups evenly over shader
-// engines of unequal size (profiles/r02/cu_reserve.md): every resident workgroup simply works until the queue is dry.
+// PERSISTENT, dynamically scheduled variant: the grid is two workgroups per CU; each takes the next tile from an atomic
+// counter until none is left.  A tile's arithmetic does not depend on who computes it, so results are those of
+// gemm_nt128_kernel bit for bit.  Used where a launch's tiles differ widely in length (k ranges trimmed to a triangle)
+// and where the panel chain of the driver holds no kernel that needs a drained CU (ctx->persist_scope).
 template <int TAG, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt128_persist_kernel(GemmArgs g, TileMap tm, int* __restrict__ counter,
-                                                                    int avoid_cu0) {
+__global__ __launch_bounds__(256, 2) void gemm_nt128_persist_kernel(GemmArgs g, TileMap tm, int* __restrict__ counter) {
   constexpr int TD = 256 * 16;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (avoid_cu0) {
-    // "soft" CU reservation: workgroups that land on CU 0 of shader engine 0 of an XCD (the 8 CUs the q stream's CU
-    // mask names, tools/exp/cumask_probe.hip) retire at once; the others drain the tile queue.  Unlike a CU mask on
-    // this kernel's own queue this cannot unbalance the dispatcher (profiles/r02/cu_reserve.md).
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    if (((hw >> 8) & 0xf) == 0 && ((hw >> 12) & 1) == 0 && ((hw >> 13) & 7) == 0) return;
-  }
   if (TAG == 0) __builtin_amdgcn_s_setprio(2);
   int* s_tile = reinterpret_cast<int*>(smem + 2 * TD); // 16 B behind the two k-tile buffers (one LDS object only)
   for (;;) {
@@ -314,7 +145,7 @@ static TileMap make_tile_map(const GemmArgs& g, int tiles_m, int tiles_n) {
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a function: every context sets it once
 // for each variant it launches (a process may hold contexts on several GPUs; contexts are also driven from
 // different host threads, so the "done" bits live in the context, not in a function-local static).
-enum : unsigned { ATTR_SMALL_22 = 0, ATTR_SMALL_24 = 1, ATTR_BIG_BASE = 2 /* + 3 * TAG + EPI */, ATTR_PERSIST_BASE = 8, ATTR_SWZ_BASE = 14,
+enum : unsigned { ATTR_SMALL_22 = 0, ATTR_SMALL_24 = 1, ATTR_BIG_BASE = 2 /* + 3 * TAG + EPI */, ATTR_PERSIST_BASE = 8,
                   ATTR_SMALL_22_BK32 = 20, ATTR_SMALL_24_BK32 = 21 };
 
 template <int TAG, int MT, int NT, int BK, bool DBUF>
@@ -340,7 +171,7 @@ template <int TAG, int EPI>
 static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n) {
   constexpr size_t lds = (size_t)2 * 256 * 16 * sizeof(double); // 2 buffers x (128 A rows + 128 B rows) x 128 B
   constexpr unsigned bit = 1u << (ATTR_BIG_BASE + 3 * TAG + EPI);
-  if ((ctx->persist_gemm || ctx->persist_scope > 0) && g.row_step <= 1) {
+  if (ctx->persist_scope > 0) {
     constexpr unsigned pbit = 1u << (ATTR_PERSIST_BASE + 3 * TAG + EPI);
     if (!(ctx->func_attr_mask & pbit)) {
       GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_persist_kernel<TAG, EPI>),
@@ -362,12 +193,9 @@ static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
       GPX_HIP(ctx, hipStreamWaitEvent(ctx->s, ctx->tile_counter_ev[slot], 0));
     int* counter = ctx->tile_counters.i() + slot;
     GPX_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->s));
-    // persist_slack: workgroup slots deliberately left empty (GPX_PERSIST_SLACK) so that a chain kernel that cannot share
-    // a SIMD with two big-tile waves (potf2: 238 VGPRs) finds a CU with a single resident workgroup at once
-    int slots = 2 * (ctx->prop.multiProcessorCount - ((ctx->rstream && !ctx->soft_reserve) ? ctx->cu_reserved : 0));
-    if (ctx->persist_gemm && ctx->persist_slack > 0 && slots > 4 * ctx->persist_slack) slots -= ctx->persist_slack;
-    const int grid = (tm.total < slots && !ctx->soft_reserve) ? tm.total : slots;
-    gemm_nt128_persist_kernel<TAG, EPI><<<grid, 256, lds + 16, ctx->s>>>(g, tm, counter, ctx->soft_reserve ? 1 : 0);
+    const int slots = 2 * ctx->prop.multiProcessorCount;
+    const int grid = tm.total < slots ? tm.total : slots;
+    gemm_nt128_persist_kernel<TAG, EPI><<<grid, 256, lds + 16, ctx->s>>>(g, tm, counter);
     GPX_HIP(ctx, hipGetLastError());
     if (ctx->tile_counter_ev[slot] == nullptr)
       GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->tile_counter_ev[slot], hipEventDisableTiming));
@@ -375,33 +203,10 @@ static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
     ctx->tile_counter_stream[slot] = ctx->s;
     return 0;
   }
-  SwzMap sm;
-  // worth it from about two full rounds of workgroups (below that the ranges are too short to balance)
-  if (ctx->tile_swizzle && g.row_step <= 1 && (double)tiles_m * tiles_n * (g.lower ? 0.5 : 1.0) >= ctx->tile_swizzle_min &&
-      make_swz_map(g, tiles_m, tiles_n, sm)) {
-    constexpr unsigned sbit = 1u << (ATTR_SWZ_BASE + 3 * TAG + EPI);
-    if (!(ctx->func_attr_mask & sbit)) {
-      GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_swz_kernel<TAG, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      ctx->func_attr_mask |= sbit;
-    }
-    dim3 grid(sm.max_items * 64, g.nsplit * g.batch, 1);
-    gemm_nt128_swz_kernel<TAG, EPI><<<grid, 256, lds, ctx->s>>>(g, sm);
-    GPX_HIP(ctx, hipGetLastError());
-    return 0;
-  }
   if (!(ctx->func_attr_mask & bit)) {
     GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_kernel<TAG, EPI>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ctx->func_attr_mask |= bit;
-  }
-  if (ctx->grid_pad8 && tiles_n > 8 && (tiles_n & 7) != 0) {
-    GemmArgs gp = g;
-    gp.nx = tiles_n;
-    dim3 grid((tiles_n + 7) & ~7, tiles_m, g.nsplit * g.batch);
-    gemm_nt128_kernel<TAG, EPI><<<grid, 256, lds, ctx->s>>>(gp);
-    GPX_HIP(ctx, hipGetLastError());
-    return 0;
   }
   dim3 grid(tiles_n, tiles_m, g.nsplit * g.batch);
   gemm_nt128_kernel<TAG, EPI><<<grid, 256, lds, ctx->s>>>(g);
@@ -437,13 +242,11 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   const int nsplit = splits > 0 ? splits : 1;
   const int bmul = (g.batch > 1 && g.K >= 512) ? g.batch : 1;
   const double tiles = (double)tiles_m * tiles_n * nsplit * (g.lower ? 0.55 : 1.0) * bmul;
-  // persistent mode: the trailing update's workgroups hold their slots until its queue is dry, so a big-shape launch
-  // on the panel stream would only find room on the reserved CUs: everything there takes the shapes that fit next to
-  // two resident trailing workgroups
-  const bool on_panel = (ctx->persist_gemm || ctx->persist_scope > 0) && ctx->s != ctx->stream;
-  const bool small_ok = ctx->gemm_small;           // GPX_GEMM_SMALL (gpx_init)
-  const double small_max = ctx->small_tiles_max;   // GPX_SMALL_TILES_MAX
-  if (small_ok && (tiles < small_max || on_panel)) {
+  // persistent scope: the bulk update's workgroups hold their slots until its queue is dry, so a big-shape launch on
+  // the panel stream would find no room: everything there takes the shapes that fit next to two resident workgroups
+  const bool on_panel = ctx->persist_scope > 0 && ctx->s != ctx->stream;
+  constexpr double small_max = 400.0; // launches with fewer 128x128 tiles take the latency shapes (profiles/r02/chain_experiments.md)
+  if (tiles < small_max || on_panel) {
     if (g.C == g.A) { // in-place (panel TRSM): one workgroup must own the whole row width
       // 32x128 strip, single LDS buffer: 22 KB and < 80 VGPRs, i.e. it fits in what two resident trailing-update
       // workgroups leave free on a CU (32 KB, 80 registers per SIMD) and is placed at once; the round-1 64x128 shape

@@ -59,7 +59,6 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g, double* smem, co
   // element coordinates of this tile in the caller's global tile frame (offsets given in 128-tiles)
   const int row0 = g.ti_off * 128 + by * BM, col0 = g.tj_off * 128 + bx * BN;
   if (g.lower && col0 > row0 + BM - 1) return; // entirely above the diagonal
-  if (g.skip && (row0 >> 7) == g.skip_ti && (col0 >> 7) == g.skip_tj) return; // updated by its own launch
 
   int kb = 0, ke = g.K;
   if (g.ktri) kb = row0 & ~(BK - 1);            // A rows are zero left of the diagonal (upper-triangular operand)
@@ -220,7 +219,6 @@ __device__ __forceinline__ void nt128_tile(const GemmArgs& g, double* smem, cons
   batch_offsets(g, bb, off_a, off_b, off_c);
   const int row0 = g.ti_off * 128 + by * BM, col0 = g.tj_off * 128 + bx * BN;
   if (g.lower && col0 > row0 + BM - 1) return; // entirely above the diagonal
-  if (g.skip && (row0 >> 7) == g.skip_ti && (col0 >> 7) == g.skip_tj) return; // updated by its own launch
 
   int kb = 0, ke = g.K;
   if (g.ktri) kb = row0 & ~(BK - 1);

@@ -53,50 +53,17 @@ static inline void set_batch(GemmArgs& g, int batch, int64_t a_bs, int64_t b_bs,
   g.c_bs = c_bs;
 }
 
-// Factor the diagonal block kb on the q stream, after everything queued so far on the panel stream (which has just
-// brought that block up to date), and remember that the panel stream must wait for it (evQ) before it uses the result.
-static int queue_potf2(gpx_ctx* ctx, double* dA, int64_t lda, int kb, double* dLinv, int* dInfo,
-                       const BatchStrides& bs, const double* dPre = nullptr, int Kpre = 0) {
-  hipStream_t span = ctx->s;
-  GPX_HIP(ctx, hipEventRecord(ctx->evD, span));
-  GPX_HIP(ctx, hipStreamWaitEvent(ctx->qstream, ctx->evD, 0));
-  ctx->s = ctx->qstream;
-  const int rc = launch_potf2_inv(ctx, dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE, lda,
-                                  dLinv + (int64_t)kb * TILE * TILE, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs,
-                                  dPre, Kpre);
-  ctx->s = span;
-  GPX_TRY(rc);
-  GPX_HIP(ctx, hipEventRecord(ctx->evQ, ctx->qstream));
-  return 0;
-}
-
 // One outer block (diagonal blocks ob .. oe-1).  Per diagonal block kb: potf2 (+ inverse) -> panel TRSM (GEMM with
 // the inverse) -> update of the outer block's remaining columns.
-// EARLY DIAGONAL: potf2(kb + 1) only needs the diagonal tile (kb+1, kb+1) of that update.  The factorisation kernel
-// applies the update to its own block (pre-update, potf2.hip) and is queued on the q stream right after the TRSM,
-// while the rest of the update (that tile skipped) runs on the panel stream: per step the chain is
-// TRSM + max(potf2, update) instead of their sum, with no additional launch
-// (inside the pipeline a potf2 launch costs ~160 us next to resident trailing-update workgroups, the update ~50 us).
-// Every tile still receives the same updates in the same order: results do not change (tests/test_gpu_edges.py).
-// MEASURED AND LEFT OFF BY DEFAULT (GPX_EARLY_DIAG=1 enables it; profiles/r02/chain_experiments.md): with or without
-// an extra launch for the diagonal tile, running two chain kernels side by side next to the saturating trailing
-// update slows each by what the other takes — potrf 30.7 -> 32.7 ms at C3.
-// first_queued: potf2(ob) was queued on the q stream by the caller (the early diagonal of U1).
-// wait_u1b: the rest of the previous block's U1 (columns ob+1 ..) runs on the q stream (split U1, potrf_lower): the first
-// inner update, which writes those columns next, waits for it (evB).
+// (Round 2 overlapped the next potf2 with that update — "early diagonal", with and without fusing the update into the
+// potf2 kernel — and round 3 ran a whole block's chain as one cooperative kernel; both bit-identical, both slower:
+// profiles/r02/chain_experiments.md, profiles/r03/panel_kernel.md, tools/exp/panel.hip.)
 static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob, int oe,
-                       double* dLinv, int* dInfo, const BatchStrides& bs, bool first_queued, bool early,
-                       bool wait_u1b = false) {
-  bool queued = first_queued;
+                       double* dLinv, int* dInfo, const BatchStrides& bs) {
   for (int kb = ob; kb < oe; ++kb) {
     double* Akk = dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE;
     double* Li = dLinv + (int64_t)kb * TILE * TILE;
-    if (queued) {
-      GPX_HIP(ctx, hipStreamWaitEvent(ctx->s, ctx->evQ, 0)); // L_kk and its inverse come from the q stream
-      queued = false;
-    } else {
-      GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs));
-    }
+    GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs));
     const int below = nblk - kb - 1 + extra;
     if (below <= 0) continue;
     double* Apan = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)kb * TILE;
@@ -107,10 +74,6 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
                              2.0 * below * TILE * (double)TILE * TILE));
     }
     const int inner_cols = oe - kb - 1;
-    if (wait_u1b && (inner_cols > 0 || kb + 1 == oe)) { // also before the panel is declared done (single-tile blocks)
-      GPX_HIP(ctx, hipStreamWaitEvent(ctx->s, ctx->evB, 0));
-      wait_u1b = false;
-    }
     if (inner_cols > 0) { // update the rest of the outer block's columns (lower tiles)
       double* Cin = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)(kb + 1) * TILE;
       GemmArgs g = gemm_args(Apan, lda, Apan, lda, Cin, lda, TILE, -1.0, 1.0);
@@ -118,33 +81,18 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
       g.lower = 1;
       g.ti_off = kb + 1;
       g.tj_off = kb + 1;
-      if (early) { // the next diagonal block is updated by its own factorisation kernel, on the q stream, meanwhile
-        GPX_TRY(queue_potf2(ctx, dA, lda, kb + 1, dLinv, dInfo, bs, Apan, TILE));
-        queued = true;
-        g.skip = 1;
-        g.skip_ti = kb + 1;
-        g.skip_tj = kb + 1;
-      }
       GPX_TRY(launch_gemm_nt(ctx, g, below, inner_cols, 0, GPX_PROF_GEMM_OTHER,
                              2.0 * below * inner_cols * (double)TILE * TILE * TILE));
     }
   }
-  if (wait_u1b) GPX_HIP(ctx, hipStreamWaitEvent(ctx->s, ctx->evB, 0)); // nothing below the block: still join
   return 0;
 }
 
 // C[rows r0.., cols c0..c1) -= Pan[rows, ob..oe) * Pan[cols, ob..oe)^T, lower tiles only.
-// skip_tile >= 0: everything but the diagonal tile (skip_tile, skip_tile) (its own factorisation kernel updates it).
-// parity >= 0: only the tile rows whose ABSOLUTE index has that parity (split far updates, potrf_lower).
 static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob,
-                           int oe, int r0, int c0, int c1, int prof_cls, const BatchStrides& bs,
-                           int skip_tile = -1, int parity = -1) {
-  const int rows_all = nblk + extra - r0, cols = c1 - c0;
-  if (rows_all <= 0 || cols <= 0) return 0;
-  const int step = parity >= 0 ? 2 : 1;
-  const int phase = parity >= 0 ? ((parity - r0) & 1) : 0;
-  const int rows = (rows_all - phase + step - 1) / step; // tile rows this launch covers
-  if (rows <= 0) return 0;
+                           int oe, int r0, int c0, int c1, int prof_cls, const BatchStrides& bs) {
+  const int rows = nblk + extra - r0, cols = c1 - c0;
+  if (rows <= 0 || cols <= 0) return 0;
   const int K = (oe - ob) * TILE;
   const double* PanR = dA + (int64_t)r0 * TILE * lda + (int64_t)ob * TILE;
   const double* PanC = dA + (int64_t)c0 * TILE * lda + (int64_t)ob * TILE;
@@ -154,23 +102,14 @@ static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int 
   g.lower = 1;
   g.ti_off = r0;
   g.tj_off = c0;
-  if (step > 1) {
-    g.row_step = step;
-    g.row_phase = phase;
-  }
-  if (skip_tile >= 0) {
-    g.skip = 1;
-    g.skip_ti = g.skip_tj = skip_tile;
-  }
   // algorithmic flops: 2K per updated entry with column <= row
   double entries = 0.0;
-  for (int i = phase; i < rows_all; i += step) {
+  for (int i = 0; i < rows; ++i) {
     const int R = r0 + i; // absolute tile row: full tiles in columns c0 .. min(c1, R) - 1, half a tile on the diagonal
     const int full = (R < c1 ? R : c1) - c0;
     if (full > 0) entries += (double)full * TILE * TILE;
     if (R >= c0 && R < c1) entries += 0.5 * TILE * (TILE + 1.0);
   }
-  if (skip_tile >= 0) entries -= 0.5 * TILE * (TILE + 1.0);
   return launch_gemm_nt(ctx, g, rows, cols, 0, prof_cls, 2.0 * K * entries);
 }
 
@@ -205,40 +144,24 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
                 int* dInfo, int batch, int64_t a_bs, int64_t linv_bs) {
   const BatchStrides bs{batch > 1 ? batch : 1, a_bs, linv_bs};
   const int nblk = np / TILE;
-  ctx->small_bk_now = ctx->small_bk != 0 ? ctx->small_bk : ((bs.batch == 1 && nblk + extra_tiles <= ctx->small_bk_rows) ? 32 : 16);
+  ctx->small_bk_now = ctx->small_bk != 0 ? ctx->small_bk : ((bs.batch == 1 && nblk + extra_tiles <= SMALL_BK_ROWS) ? 32 : 16);
   const int OT = ctx->outer_tiles;
   const int G = ctx->lazy_group > 0 ? ctx->lazy_group : 1;
-  // Outer block boundaries.  Head blocks are OT tiles wide; a block that would leave fewer than `tail_tiles` tile rows
-  // behind it belongs to the chain-bound tail and is `tail_outer_tiles` wide (narrower blocks: a shorter U1 + panel
-  // chain per trailing update there, where the chain and not the GEMM sets the pace).
+  // ADAPTIVE schedule (the timeline of one C3 factorisation, profiles/r02/timeline_c3.md): while the remaining matrix is
+  // large the trailing updates follow each other without gaps and the panel chain hides behind them (GEMM-bound
+  // "head"): bulk updates take `lazy_group` outer blocks at a time (larger K).  Once an outer block's chain takes
+  // longer than the trailing update it overlaps with, the chain sets the pace (chain-bound "tail": a block that leaves
+  // fewer than `tail_tiles` tile rows behind it): one outer block per update.  Every combination gives the same bits.
   const int tail_tiles = ctx->tail_tiles;
-  const int OTt = (ctx->tail_outer_tiles > 0 && ctx->tail_outer_tiles < OT) ? ctx->tail_outer_tiles : OT;
-  std::vector<int> bounds;
-  std::vector<char> is_tail;
-  for (int c = 0; c < nblk;) {
-    const bool t = tail_tiles > 0 && (nblk - (c + OT) + extra_tiles) < tail_tiles;
-    bounds.push_back(c);
-    is_tail.push_back(t ? 1 : 0);
-    c += t ? OTt : OT;
-  }
-  const int nouter = (int)bounds.size();
+  const int nouter = (nblk + OT - 1) / OT;
   GPX_TRY(ensure_events(ctx, nouter));
   hipStream_t smain = ctx->stream, span = ctx->pstream;
-  auto ob_of = [&](int k) { return k < nouter ? bounds[(size_t)k] : nblk; }; // first tile column of outer block k (clamped)
+  auto ob_of = [&](int k) { return k < nouter ? k * OT : nblk; }; // first tile column of outer block k (clamped)
+  auto in_tail = [&](int k) { return k < nouter && tail_tiles > 0 && (nblk - (k * OT + OT) + extra_tiles) < tail_tiles; };
   // the panel stream starts after everything already queued on the main stream (Gram etc.)
   GPX_HIP(ctx, hipEventRecord(ctx->evU[nouter], smain));
   GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[nouter], 0));
   int rc = 0;
-  // ADAPTIVE schedule (the timeline of one C3 factorisation, profiles/r02/timeline_c3.md): while the remaining matrix is
-  // large the trailing updates follow each other without gaps and the panel chain hides behind them (GEMM-bound
-  // "head"); once an outer block's chain takes longer than the trailing update it overlaps with, the chain sets the
-  // pace (chain-bound "tail": 15 of 32 outer blocks, 23 % of the time for 10 % of the flops at C3).  What helps one
-  // phase hurts the other, so the knobs are set per outer block — every combination gives the same bits:
-  //   head: bulk updates take `lazy_group` outer blocks at a time (larger K), no early diagonal;
-  //   tail: one outer block per update, early diagonal if early_diag = 2 (potf2 of the next diagonal block overlapped
-  //         with the update that feeds it: the chip is not saturated any more, so the overlap is real).
-  // early_diag = 1 / lazy_group with tail_tiles = 0: everywhere (the experiments of chain_experiments.md).
-  auto in_tail = [&](int k) { return k < nouter && is_tail[(size_t)k] != 0; };
   // groups: consecutive head blocks are grouped G at a time, tail blocks stay single
   std::vector<int> gfirst((size_t)nouter), glast((size_t)nouter);
   for (int k = 0; k < nouter;) {
@@ -251,34 +174,12 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     }
     k += len;
   }
-  auto early_at = [&](int k) {
-    if (ctx->qstream == nullptr || k >= nouter) return false;
-    return ctx->early_diag == 1 || (ctx->early_diag == 2 && in_tail(k));
-  };
-  hipStream_t s2 = (ctx->split_far > 0 && !ctx->persist_gemm && ctx->tile_swizzle == 0) ? ctx->stream2 : nullptr;
-  bool s2_pending = false, u2_pending = false, split_done = false, u1b_pending = false;
-  bool first_queued = false; // potf2 of the next outer block's first diagonal block already queued on the q stream
   for (int k = 0; k < nouter && rc >= 0; ++k) {
     const int ob = ob_of(k), oe = ob_of(k + 1);
     const int gs = gfirst[(size_t)k], ge = glast[(size_t)k];
     // P(k) on the panel stream (it follows U1(k-1) there, in stream order)
     ctx->s = span;
-    // The chain of a tail block as ONE cooperative kernel (panel.hip): the dependencies between the diagonal-block
-    // factorisations, TRSMs and inner updates are flags in device memory instead of 12 dependent launches.  Same tile
-    // bodies, same fma chains: bit-identical to the launches.  Single-sample factorisations only (a batch is B times
-    // more work per launch and never chain-bound), and not combined with the early-diagonal / split-U1 experiments.
-    // Only where few tile rows lie below the block (panel_max_far): the cooperative kernel lives on ONE XCD (32 CUs), so
-    // the rows below the block — whose TRSMs and updates the launches spread over the whole chip — must be few.
-    bool coop = ctx->panel_mode > 0 && bs.batch == 1 && (ctx->panel_mode >= 2 || in_tail(k)) && !first_queued &&
-                !early_at(k) && !u1b_pending && oe - ob <= 8 && dInfo != nullptr &&
-                (nblk + extra_tiles - oe) <= ctx->panel_max_far;
-    if (coop && ctx->panel_ok < 0) ctx->panel_ok = panel_probe(ctx);
-    if (coop && ctx->panel_ok == 1)
-      rc = launch_panel_chain(ctx, dA, lda, nblk + extra_tiles, ob, oe, dLinv, dInfo);
-    else
-      rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs, first_queued, early_at(k), u1b_pending);
-    first_queued = false;
-    u1b_pending = false;
+    rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs);
     if (rc < 0) break;
     GPX_HIP(ctx, hipEventRecord(ctx->evP[k], span));
     if (oe >= nblk) {
@@ -287,47 +188,17 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
     }
     // U1(k): block k alone (K = its columns) onto outer columns k+1 .. ge+1, on the PANEL stream.  The first block of
     // a group writes columns the previous group's far update also wrote: wait for the launch that did (fixed order).
-    if (k == gs && k > 0) {
-      GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
-      if (u2_pending) { // the odd-row half of that launch ran on stream2
-        GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU2, 0));
-        u2_pending = false;
-      }
-    }
-    int skip_tile = -1;
-    if (early_at(k + 1)) { // early diagonal: potf2(oe) applies block k's update to its tile itself, while U1(k) runs
-      rc = queue_potf2(ctx, dA, lda, oe, dLinv, dInfo, bs, dA + (int64_t)oe * TILE * lda + (int64_t)ob * TILE,
-                       (oe - ob) * TILE);
-      if (rc < 0) break;
-      first_queued = true;
-      skip_tile = oe;
-    }
-    // SPLIT U1 (GPX_U1_SPLIT: 1 in the tail, 2 everywhere): the next panel starts with potf2 + TRSM on tile column oe
-    // alone, so only that column's update stays on the chain; the other columns of U1 run on the q stream meanwhile
-    // and are joined before the next panel's first inner update (panel_block, evB).
+    if (k == gs && k > 0) GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[k - 1], 0));
     const int u1_end = ob_of(ge + 2);
-    const bool u1_split = ctx->qstream != nullptr && skip_tile < 0 && oe + 1 < u1_end &&
-                          (ctx->u1_split == 2 || (ctx->u1_split == 1 && in_tail(k)));
-    if (u1_split) {
-      GPX_HIP(ctx, hipEventRecord(ctx->evD, span)); // the panel of block k and everything U1(k) waited for
-      GPX_HIP(ctx, hipStreamWaitEvent(ctx->qstream, ctx->evD, 0));
-      ctx->s = ctx->qstream;
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe + 1, u1_end, GPX_PROF_GEMM_OTHER, bs);
-      ctx->s = span;
-      if (rc < 0) break;
-      GPX_HIP(ctx, hipEventRecord(ctx->evB, ctx->qstream));
-      u1b_pending = true;
-    }
-    rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, u1_split ? oe + 1 : u1_end,
-                         GPX_PROF_GEMM_OTHER, bs, skip_tile);
+    rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, ob, oe, oe, oe, u1_end, GPX_PROF_GEMM_OTHER, bs);
     if (rc < 0) break;
     if (k == ge) { // far update of the whole group on the main stream
       GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[k], 0));
-      // GPX_FAR_AFTER_U1 = t: once fewer than t tile rows remain (deep in the chain-bound tail, where the far update is
-      // shorter than the chain it hides behind) it starts only when U1(k) is done, so that U1 — on the chain — has the
-      // chip to itself instead of sharing it with the update that has time to spare.  Single-sample launches only: a
-      // batched update is B times longer and sets the pace itself.
-      if (ctx->far_after_u1 > 0 && bs.batch == 1 && (nblk - oe + extra_tiles) < ctx->far_after_u1) {
+      // Deep in the chain-bound tail (fewer than FAR_AFTER_U1 tile rows left: the far update is shorter than the chain it
+      // hides behind) it starts only when U1(k) is done, so that U1 — on the chain — has the chip to itself instead of
+      // sharing it with the update that has time to spare (potrf -0.5 ... -2.1 % at N = 4096 ... 16384).  Single-sample
+      // launches only: a batched update is B times longer and sets the pace itself.
+      if (bs.batch == 1 && (nblk - oe + extra_tiles) < FAR_AFTER_U1) {
         GPX_HIP(ctx, hipEventRecord(ctx->evD, span));
         GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evD, 0));
       }
@@ -338,44 +209,14 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
       // factorisation): one launch then, the round-1 schedule.
       const int gn = (k + 1 < nouter) ? glast[(size_t)(k + 1)] : k + 1;
       const int n0 = ob_of(ge + 2), n1 = (gn - ge >= 2) ? ob_of(gn + 2) : nblk;
-      // SPLIT (GPX_SPLIT_FAR): even tile rows on the main stream, odd tile rows on stream2 — two independent chains of
-      // launches (a tile keeps its stream for the whole factorisation, so every tile still receives its updates in
-      // order), whose partly filled last rounds fill with each other's workgroups.  Only while a half still has
-      // `split_far` tiles; from then on single launches again, which first wait for stream2's last one.
-      const double rows_left = (double)(nblk + extra_tiles - n0);
-      const bool split = s2 != nullptr && !split_done && 0.25 * rows_left * rows_left >= (double)ctx->split_far;
-      if (s2_pending && !split) { // back to single launches: they write both parities
-        GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evS2, 0));
-        s2_pending = false;
-        split_done = true;
-      }
-      if (split) {
-        GPX_HIP(ctx, hipStreamWaitEvent(s2, ctx->evP[k], 0));
-        ctx->s = s2;
-        rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n0, n0, n1, GPX_PROF_GEMM_TRAILING, bs, -1, 1);
-        if (rc < 0) break;
-        GPX_HIP(ctx, hipEventRecord(ctx->evU2, s2));
-        rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n1, n1, nblk, GPX_PROF_GEMM_TRAILING, bs, -1, 1);
-        if (rc < 0) break;
-        GPX_HIP(ctx, hipEventRecord(ctx->evS2, s2));
-        s2_pending = true;
-        u2_pending = true;
-      }
       ctx->s = smain;
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n0, n0, n1, GPX_PROF_GEMM_TRAILING, bs, -1,
-                           split ? 0 : -1);
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n0, n0, n1, GPX_PROF_GEMM_TRAILING, bs);
       if (rc < 0) break;
       GPX_HIP(ctx, hipEventRecord(ctx->evU[k], smain)); // what the next group's first U1 waits for
-      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n1, n1, nblk, GPX_PROF_GEMM_TRAILING, bs, -1,
-                           split ? 0 : -1);
+      rc = trailing_update(ctx, dA, lda, nblk, extra_tiles, gob, oe, n1, n1, nblk, GPX_PROF_GEMM_TRAILING, bs);
     }
   }
-  if (s2_pending) GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evS2, 0));
-  // everything queued on the q / panel streams happens-before whatever follows on the main stream
-  if (ctx->qstream) {
-    GPX_HIP(ctx, hipEventRecord(ctx->evQ, ctx->qstream));
-    GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evQ, 0));
-  }
+  // everything queued on the panel stream happens-before whatever follows on the main stream
   GPX_HIP(ctx, hipEventRecord(ctx->evP[nouter], span));
   GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[nouter], 0));
   ctx->s = smain;
@@ -393,7 +234,7 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
                   int64_t ldl, const double* dLinv, int nblk, int upper_rows, int batch,
                   int64_t b_bs, int64_t l_bs, int64_t linv_bs) {
   if (batch < 1) batch = 1;
-  ctx->small_bk_now = ctx->small_bk != 0 ? ctx->small_bk : ((batch == 1 && (rows_t > nblk ? rows_t : nblk) <= ctx->small_bk_rows) ? 32 : 16);
+  ctx->small_bk_now = ctx->small_bk != 0 ? ctx->small_bk : ((batch == 1 && (rows_t > nblk ? rows_t : nblk) <= SMALL_BK_ROWS) ? 32 : 16);
   const int OT = ctx->outer_tiles;
   const int nouter = (nblk + OT - 1) / OT;
   GPX_TRY(ensure_events(ctx, nouter));

@@ -44,8 +44,7 @@ typedef struct gpx_ctx gpx_ctx;
 #define GPX_PROF_GEMM_OTHER 1    /* every other MFMA GEMM launch */
 #define GPX_PROF_POTF2 2         /* diagonal-block factor+inverse */
 #define GPX_PROF_GRAM 3          /* Gram builds */
-#define GPX_PROF_PANEL 4         /* cooperative panel-chain kernel (potf2 + TRSM + inner updates of one outer block) */
-#define GPX_PROF_NCLASS 5
+#define GPX_PROF_NCLASS 4
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
 
@@ -256,15 +255,11 @@ int gpx_profile_read(gpx_ctx* ctx, int cls, int64_t* launches, double* total_ms,
 /* Algorithmic BYTES of the MFMA classes since the last reset: 16 B (one read, one write) per C entry a launch
  * updates (8 B when beta == 0) — the per-launch figure bench.py's roofline block quotes beside the PMC traffic. */
 int gpx_profile_read_bytes(gpx_ctx* ctx, int cls, double* total_bytes);
-/* Diagnostic, host only (no device call): the XCD-aware tile order of the big-tile GEMM (GPX_TILE_SWIZZLE,
- * DESIGN.md 3) for a launch of tiles_m x tiles_n 128-tiles whose first tile sits at (ti_off, tj_off); lower != 0:
- * only tiles on or below the diagonal.  Writes (xcd, by, bx) triples in workgroup order, up to `cap` of them, and
- * returns the number of tiles the launch computes (-1: shape not handled, the launch falls back to grid order). */
-int gpx_debug_tile_order(int lower, int ti_off, int tj_off, int tiles_m, int tiles_n, int* xcd_by_bx, int cap);
-
-/* Diagnostic: launches of the cooperative panel-chain kernel (csrc/panel.hip) issued by this context, launches that ran
- * on the device, and the device-side fail flag (a spin time-out; such a factorisation reports a failed pivot). */
-int gpx_panel_stats(gpx_ctx* ctx, int64_t* launches, int* ran, int* failed);
+/* Diagnostic: select the diagonal-block kernel of the blocked Cholesky for the following calls on this context —
+ * "slim" (default, csrc/potf2_slim.h), "chain" (round 3, csrc/potf2_chain.h) or "tile" (round 2, the reference of the
+ * bit-identity tests).  All three produce the same bits; bench.py uses it for the in-process A/B of the potf2 class.
+ * The environment variable GPX_POTF2 sets the same thing at gpx_init. */
+int gpx_debug_set_potf2(gpx_ctx* ctx, const char* mode);
 
 /* Device-only timed repetitions (inputs resident in HBM; used by bench.py so that `value`
  * excludes PCIe).  Each call runs `reps` passes of the named stage at the theta/Xnew last set

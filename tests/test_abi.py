@@ -51,27 +51,37 @@ def test_product_never_imports_oracle():
                     assert not re.match(r"\s*(from|import)\s+oracle", line), (f, line)
 
 
-def test_xcd_aware_tile_order_covers_every_tile_once_and_balances_the_xcds():
-    """The XCD-aware order of the big-tile GEMM (gemm_f64.hip make_swz_map / swz_decode, run on the host through the
-    diagnostic entry point): every tile of the launch exactly once — lower launches only those on or below the
-    diagonal, for square, near (ti_off > tj_off) and rectangular shapes — and the same tile count per XCD to within a
-    couple of items of 8 tiles."""
-    import ctypes as C
-    import numpy as np
-    from gpax_amd import _lib
+def test_chain_kernels_fit_beside_two_resident_trailing_update_workgroups():
+    """What makes the diagonal-block kernel of the blocked Cholesky (gpax/models/gp.py:160-164) cheap inside the pipeline
+    is that it is PLACED AT ONCE: the trailing SYRK keeps two workgroups resident per CU, and what they leave free is
+    512 - 2 x alloc(trailing) VGPRs per SIMD lane and 160 KB - 2 x 64 KB of LDS.  Read from the code objects hipcc emits
+    for the sources as committed (no GPU needed): the default potf2 kernel and the latency GEMM shapes of the panel
+    chain fit in that, the round-3 kernel (kept as the reference) does not."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import kernel_resources as kr
 
-    lib = _lib.load_library()
-    for lower, ti, tj, tm, tn in [(1, 0, 0, 77, 77), (1, 5, 5, 40, 40), (1, 12, 4, 30, 38), (1, 4, 4, 124, 124),
-                                  (0, 0, 0, 33, 8), (0, 3, 0, 16, 64), (1, 0, 0, 9, 9), (1, 20, 0, 50, 20)]:
-        cap = tm * tn
-        out = np.zeros(3 * cap, dtype=np.int32)
-        n = lib.gpx_debug_tile_order(lower, ti, tj, tm, tn, out.ctypes.data_as(C.POINTER(C.c_int)), cap)
-        want = {(by, bx) for by in range(tm) for bx in range(tn) if not lower or tj + bx <= ti + by}
-        assert n == len(want), (lower, ti, tj, tm, tn, n, len(want))
-        trip = out[:3 * n].reshape(n, 3)
-        got = [(int(b), int(c)) for _, b, c in trip]
-        assert len(set(got)) == n and set(got) == want
-        per_xcd = np.bincount(trip[:, 0], minlength=8)
-        if n >= 1024:
-            assert per_xcd.max() - per_xcd.min() <= 24, per_xcd
-    assert lib.gpx_debug_tile_order(1, 0, 0, 8 * 40, 8, None, 0) == -1  # more strips than the map holds: grid order
+    csrc = os.path.join(os.path.dirname(__file__), "..", "gpax_amd", "csrc")
+    rows = {r["name"]: r for f in ("potf2.hip", "gemm_f64.hip") for r in kr.resources(os.path.join(csrc, f))}
+
+    def find(sub):
+        hit = [r for n, r in rows.items() if sub in n]
+        assert len(hit) == 1, (sub, [n for n in rows if sub in n])
+        return hit[0]
+
+    def alloc(r):  # VGPRs are allocated in blocks of 8 on gfx90a+
+        return (int(r["vgpr_count"]) + 7) // 8 * 8
+
+    trailing = find("gemm_nt128_kernelILi1ELi1E")  # TAG = 1 (Cholesky trailing update), accumulators from -C
+    free_vgpr = 512 - 2 * alloc(trailing)
+    free_lds = 160 * 1024 - 2 * (2 * 256 * 16 * 8)
+    assert free_vgpr >= 104 and free_lds == 32 * 1024
+    slim = find("potf2_slim_kernel")
+    assert alloc(slim) <= free_vgpr, (slim["vgpr_count"], free_vgpr)
+    assert int(slim["vgpr_spill_count"]) == 0 and int(slim["private_segment_fixed_size"]) == 0
+    assert (13 * 16 * 17 + 64) * 8 <= free_lds  # POTF2_SLIM_LDS (dynamic LDS: csrc/potf2_slim.h)
+    chain = find("potf2_chain_kernel")
+    assert alloc(chain) > free_vgpr  # why it waited 80 - 155 us per launch for a drained CU (VERDICT r3)
+    for shape in ("gemm_nt_kernelILi0ELi2ELi2ELi16E", "gemm_nt_kernelILi0ELi1ELi4ELi16E"):  # 64x64, 32x128 strips
+        assert alloc(find(shape)) <= free_vgpr

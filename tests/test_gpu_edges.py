@@ -155,36 +155,19 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
     eps = np.random.default_rng(1).standard_normal((2, 1, M))
     ells = np.stack([p["k_length"], 1.1 * p["k_length"]])
     outs = []
-    variants = [dict(), dict(GPX_EARLY_DIAG="2", GPX_TAIL_TILES="12", GPX_LAZY_GROUP="2"),
-                dict(GPX_EARLY_DIAG="2", GPX_TAIL_TILES="9"), dict(GPX_LAZY_GROUP="3", GPX_TAIL_TILES="14"),
-                dict(GPX_EARLY_DIAG="1"), dict(GPX_LAZY_GROUP="2", GPX_EARLY_DIAG="1"), dict(GPX_LAZY_GROUP="3"),
-                dict(GPX_LAZY_GROUP="4", GPX_EARLY_DIAG="1"), dict(GPX_OUTER_TILES="2"),
-                dict(GPX_LAZY_GROUP="2", GPX_OUTER_TILES="3"),
-                # persistent, dynamically scheduled big-tile GEMM; with CUs reserved for the diagonal blocks
-                dict(GPX_PERSIST_GEMM="1"), dict(GPX_CU_RESERVE="8"), dict(GPX_CU_RESERVE="8", GPX_LAZY_GROUP="2"),
-                dict(GPX_PERSIST_SCOPE="0"), dict(GPX_CU_RESERVE_SOFT="8"), dict(GPX_PERSIST_GEMM="1", GPX_PERSIST_SLACK="8"),
-                # XCD-aware tile order of the big-tile GEMM on / off
-                dict(GPX_TILE_SWIZZLE="1"), dict(GPX_TILE_SWIZZLE="2", GPX_TILE_SWIZZLE_MIN="64"), dict(GPX_TILE_SWIZZLE="1", GPX_LAZY_GROUP="1", GPX_TILE_SWIZZLE_MIN="64"),
-                # narrower outer blocks in the tail
-                dict(GPX_TAIL_OUTER_TILES="2", GPX_TAIL_TILES="12"), dict(GPX_TAIL_OUTER_TILES="1", GPX_TAIL_TILES="15"),
-                dict(GPX_TAIL_OUTER_TILES="2", GPX_TAIL_TILES="40", GPX_OUTER_TILES="3"),
-                # far updates split in even / odd tile rows on two streams
-                dict(GPX_SPLIT_FAR="1"), dict(GPX_SPLIT_FAR="40"), dict(GPX_SPLIT_FAR="30", GPX_LAZY_GROUP="1"),
-                dict(GPX_SPLIT_FAR="1", GPX_LAZY_GROUP="3", GPX_TAIL_TILES="0"),
-                # U1 split: only the next diagonal column stays on the chain, the rest runs on the q stream
-                dict(GPX_U1_SPLIT="2"), dict(GPX_U1_SPLIT="1", GPX_TAIL_TILES="12"), dict(GPX_U1_SPLIT="2", GPX_LAZY_GROUP="3"),
-                dict(GPX_U1_SPLIT="2", GPX_OUTER_TILES="2", GPX_LAZY_GROUP="1"), dict(GPX_U1_SPLIT="2", GPX_SPLIT_FAR="1"), dict(GPX_GRID_PAD8="1"),
-                dict(GPX_TILE_SWIZZLE="3", GPX_TILE_SWIZZLE_MIN="64"), dict(GPX_FAR_AFTER_U1="0"), dict(GPX_FAR_AFTER_U1="100", GPX_LAZY_GROUP="1"),
-                # the panel chain of an outer block as launches (0) / as one cooperative kernel in the tail (1, default:
-                # the whole matrix is "tail" at this size) / everywhere (2), with other outer blockings
-                dict(GPX_PANEL_KERNEL="0"), dict(GPX_PANEL_KERNEL="2"), dict(GPX_PANEL_KERNEL="2", GPX_PANEL_MAX_FAR="1000"),
-                dict(GPX_SMALL_BK="32"), dict(GPX_SMALL_BK="32", GPX_LAZY_GROUP="3"), dict(GPX_PANEL_KERNEL="0", GPX_OUTER_TILES="2"),
-                dict(GPX_PANEL_KERNEL="2", GPX_OUTER_TILES="2"), dict(GPX_PANEL_KERNEL="2", GPX_OUTER_TILES="8", GPX_LAZY_GROUP="1"),
-                dict(GPX_PANEL_KERNEL="1", GPX_TAIL_TILES="12", GPX_LAZY_GROUP="2"), dict(GPX_PANEL_KERNEL="2", GPX_OUTER_TILES="1")]
+    variants = [dict(), dict(GPX_TAIL_TILES="12", GPX_LAZY_GROUP="2"), dict(GPX_TAIL_TILES="9"),
+                dict(GPX_LAZY_GROUP="3", GPX_TAIL_TILES="14"), dict(GPX_LAZY_GROUP="1"), dict(GPX_LAZY_GROUP="3"),
+                dict(GPX_LAZY_GROUP="4", GPX_TAIL_TILES="0"), dict(GPX_OUTER_TILES="2"),
+                dict(GPX_LAZY_GROUP="2", GPX_OUTER_TILES="3"), dict(GPX_OUTER_TILES="8", GPX_LAZY_GROUP="1"),
+                dict(GPX_OUTER_TILES="1"),
+                # big-tile GEMMs of the sweeps as plain launches instead of persistent ones
+                dict(GPX_PERSIST_SCOPE="0"),
+                # k-step of the latency shapes, the diagonal-block kernels
+                dict(GPX_SMALL_BK="32"), dict(GPX_SMALL_BK="16", GPX_LAZY_GROUP="3"), dict(GPX_POTF2="chain"),
+                dict(GPX_POTF2="tile", GPX_OUTER_TILES="2")]
+    switches = ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_PERSIST_SCOPE", "GPX_TAIL_TILES", "GPX_SMALL_BK", "GPX_POTF2")
     for env in variants:
-        for k in ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_EARLY_DIAG", "GPX_PERSIST_GEMM", "GPX_CU_RESERVE",
-                  "GPX_PERSIST_SCOPE", "GPX_CU_RESERVE_SOFT", "GPX_PERSIST_SLACK", "GPX_TAIL_TILES", "GPX_TILE_SWIZZLE", "GPX_TILE_SWIZZLE_MIN",
-                  "GPX_TAIL_OUTER_TILES", "GPX_SPLIT_FAR", "GPX_U1_SPLIT", "GPX_GRID_PAD8", "GPX_FAR_AFTER_U1", "GPX_PANEL_KERNEL", "GPX_PANEL_MAX_FAR", "GPX_SMALL_BK"):
+        for k in switches:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -204,41 +187,13 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_blocked_diagonal_tile_factor_is_bit_identical_to_the_column_version(monkeypatch):
-    """potf2.hip diag16_blk (16 x 16 diagonal tiles of the 128 x 128 block kernel factored four columns per LDS round
-    trip) restates diag16 (one column per round trip) operation by operation: factor, block inverses (through the solve
-    they feed) and the pivot report must agree bit for bit — also on a matrix that is not positive definite."""
-    import numpy as np
-    from gpax_amd import _lib
-
-    rng = np.random.default_rng(5)
-    mats = []
-    for n in (128, 200, 640):
-        B = rng.standard_normal((n, n + 8))
-        mats.append(B @ B.T / n + 0.3 * np.eye(n))
-    bad = mats[1].copy()
-    bad[150, 150] = -1.0  # pivot 151 fails
-    mats.append(bad)
-    res = {}
-    for mode in ("column", "blocked"):
-        monkeypatch.setenv("GPX_POTF2_DIAG", mode)
-        e = _lib.Engine(0)
-        res[mode] = [e.potrf(A) for A in mats]
-        e.close()
-    for (L0, i0), (L1, i1) in zip(res["column"], res["blocked"]):
-        assert i0 == i1
-        assert np.array_equal(L0, L1, equal_nan=True)
-    assert [i for _, i in res["blocked"]] == [0, 0, 0, 151]
-    L = res["blocked"][2][0]
-    assert np.abs(np.tril(L) @ np.tril(L).T - mats[2]).max() < 1e-12
-
-
-@pytest.mark.gpu
-def test_wave_specialised_diagonal_block_kernel_is_bit_identical_to_the_four_phase_kernel(monkeypatch):
-    """potf2_chain.h (default): wave 0 runs only the dependent chain diag16 -> L(p+1,p) -> D(p+1), waves 1-3 own all tiles
-    and do every other TRSM / update beside it.  Tile for tile the MFMA sequences of potf2_tile_body (GPX_POTF2=tile):
-    factors, block inverses (through the solves they feed), log-likelihood, gradient, posterior and the pivot report agree
-    bit for bit — batched launches and a matrix that is not positive definite included."""
+def test_the_three_diagonal_block_kernels_are_bit_identical(monkeypatch):
+    """potf2_slim.h (default: memory-resident tiles, 88 VGPRs / 28 KB LDS, placed at once beside two resident
+    trailing-update workgroups), potf2_chain.h (round 3: every tile in registers) and potf2_tile.h (round 2, four phases)
+    run tile for tile the same MFMA sequences: factors, block inverses (through the solves they feed), log-likelihood,
+    gradient, posterior and the pivot report agree bit for bit — batched launches, a leading dimension that is not the
+    block's own, and a matrix that is not positive definite included.  The kernel is switched in ONE context
+    (gpx_debug_set_potf2), as bench.py's in-process A/B does."""
     import numpy as np
     from bench_inputs import synthetic_problem, synthetic_theta_samples
     from gpax_amd import _lib
@@ -251,69 +206,37 @@ def test_wave_specialised_diagonal_block_kernel_is_bit_identical_to_the_four_pha
     bad = mats[3].copy()
     bad[150, 150] = -1.0  # pivot 151 fails
     mats.append(bad)
+    worse = mats[2].copy()
+    worse[0, 0] = 0.0  # the very first pivot fails: everything after it is NaN in all three
+    mats.append(worse)
     X, y, Xn, p = synthetic_problem(900, 2, 70, seed=3)
     th = synthetic_theta_samples(5, 2, seed=4)
     eps = np.random.default_rng(1).standard_normal((5, 1, 70))
     res = {}
-    for mode in ("tile", "chain"):
-        monkeypatch.setenv("GPX_POTF2", mode)
-        e = _lib.Engine(0)
+    e = _lib.Engine(0)
+    for mode in ("tile", "chain", "slim"):
+        e.set_potf2(mode)
         out = [e.potrf(A) for A in mats]
         e.set_train(X)
         lml, info = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
         grad = e.lml_grad()
         sweep = e.predict_sweep(1, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps)  # batched potf2
         res[mode] = (out, lml, info, grad, sweep)
-        e.close()
-    for (L0, i0), (L1, i1) in zip(res["tile"][0], res["chain"][0]):
-        assert i0 == i1
-        assert np.array_equal(L0, L1, equal_nan=True)
-    assert [i for _, i in res["chain"][0]] == [0, 0, 0, 0, 0, 0, 151]
-    assert res["tile"][1] == res["chain"][1] and res["tile"][2] == res["chain"][2] == 0
-    for a, b in zip(res["tile"][3], res["chain"][3]):
-        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
-    for a, b in zip(res["tile"][4], res["chain"][4]):
-        np.testing.assert_array_equal(a, b)
-    L = res["chain"][0][4][0]
-    assert np.abs(np.tril(L) @ np.tril(L).T - mats[4]).max() < 1e-12
-
-
-@pytest.mark.gpu
-def test_cooperative_panel_chain_kernel_runs_and_changes_no_bit(monkeypatch):
-    """panel.hip: in the chain-bound tail of a single-sample factorisation the panel chain of an outer block (potf2 ->
-    TRSM -> inner update, 12 dependent launches) is ONE kernel whose workgroups hand tiles over through flags in
-    device memory.  Same tile bodies => the factor, the ride-along solve, the gradient and the draws equal the
-    launched chain's bit for bit; the kernel really runs (stats) and no spin ever times out."""
-    import numpy as np
-    from bench_inputs import synthetic_problem
-    from gpax_amd import _lib
-
-    N, d, M = 9300, 2, 700  # 73 tile rows + 6 ride-along: head blocks (launches) and tail blocks (cooperative) in one factor
-    X, y, Xn, p = synthetic_problem(N, d, M, seed=17)
-    eps = np.random.default_rng(1).standard_normal((1, M))
-    outs, stats = [], []
-    monkeypatch.setenv("GPX_PANEL_MAX_FAR", "1000")  # every block below the threshold: the far-row roles get exercised
-    for mode in ("0", "1", "2"):
-        monkeypatch.setenv("GPX_PANEL_KERNEL", mode)
-        e = _lib.Engine(0)
-        e.set_train(X)
-        lml, info = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
-        assert info == 0
-        mean, cov, var = e.posterior(Xn, p["noise"], 1e-6, want_cov=True, want_var=True)
-        draws, dinfo = e.mvn_draw(eps)
-        sweep = e.predict_sweep(1, p["k_length"][None], [p["k_scale"]], [p["noise"]], y, Xn, False, 1e-6, eps[None])
-        lml2, _ = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
-        grad = e.lml_grad()
-        outs.append((lml, mean, cov, var, draws, sweep[0], sweep[1], grad[0], grad[1], grad[2], grad[3]))
-        stats.append(e.panel_stats())
-        e.close()
-    assert stats[0] == {"launches": 0, "ran": 0, "failed": 0}
-    for st in stats[1:]:
-        assert st["launches"] > 0 and st["ran"] == st["launches"] and st["failed"] == 0, st
-    assert stats[2]["launches"] > stats[1]["launches"]  # mode 2 also covers the head blocks
-    for o in outs[1:]:
-        for a, b in zip(outs[0], o):
+    with pytest.raises(RuntimeError):
+        e.set_potf2("column")
+    e.close()
+    for mode in ("chain", "slim"):
+        for (L0, i0), (L1, i1) in zip(res["tile"][0], res[mode][0]):
+            assert i0 == i1
+            assert np.array_equal(L0, L1, equal_nan=True)
+        assert res["tile"][1] == res[mode][1] and res["tile"][2] == res[mode][2] == 0
+        for a, b in zip(res["tile"][3], res[mode][3]):
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+        for a, b in zip(res["tile"][4], res[mode][4]):
+            np.testing.assert_array_equal(a, b)
+    assert [i for _, i in res["slim"][0]] == [0, 0, 0, 0, 0, 0, 151, 1]
+    L = res["slim"][0][4][0]
+    assert np.abs(np.tril(L) @ np.tril(L).T - mats[4]).max() < 1e-12
 
 
 @pytest.mark.gpu
