@@ -109,6 +109,21 @@ def cpu_baseline(N, d, M, kernel, budget_s=150.0):
     dti = time.perf_counter() - t0
     inv = {"value": 1.0 / dti, "unit": f"posteriors/s at N={Ni}", "seconds": dti, "N": Ni,
            "route": "explicit inverse, as gpax/models/gp.py:271-273"}
+    # SURVEY 8d's protocol (median of 3 after one warm-up) at a size where it fits the bench's time budget: N = 4096
+    med = None
+    try:
+        Nm = min(4096, N)
+        Xm, ym, Xnm, pm = synthetic_problem(Nm, d, M, seed=0)
+        ref.predict_one(Xm, ym, Xnm, pm, eps, False, kernel=kernel, jitter=1e-6, route="chol")  # warm-up
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ref.predict_one(Xm, ym, Xnm, pm, eps, False, kernel=kernel, jitter=1e-6, route="chol")
+            ts.append(time.perf_counter() - t0)
+        med = {"value": 1.0 / float(np.median(ts)), "unit": f"posteriors/s at N={Nm}", "N": Nm, "seconds_runs": ts,
+               "seconds_median": float(np.median(ts)), "protocol": "median of 3 after 1 warm-up, all cores, Cholesky route"}
+    except Exception as ex:  # the headline sample above stands on its own
+        med = {"error": str(ex)}
     one = None
     try:
         from threadpoolctl import threadpool_limits
@@ -136,6 +151,9 @@ def cpu_baseline(N, d, M, kernel, budget_s=150.0):
         "blas": blas,
         "inv_route": inv,
         "one_core": one,
+        "median_of_3": med,
+        "protocol_note": "value = ONE sample at the bench's own N (a second one would double the ~15 s it costs); "
+                         "median_of_3 = SURVEY 8d's protocol at N = 4096",
     }
 
 
@@ -158,7 +176,7 @@ def committed_pmc_record(N, d, M):
     out = {"traffic": None, "traffic_note": None, "serialised_avg_launch_ms": None}
     if (N, d, M) != (16384, 2, 1024):
         return out
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         tj = os.path.join(ROOT, "profiles", rnd, "traffic.json")
         if not os.path.exists(tj):
             continue
@@ -166,13 +184,48 @@ def committed_pmc_record(N, d, M):
         if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
             out["traffic"] = (2.0 * t["FETCH_SIZE"]["avg_per_launch"] + t["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
             out["traffic_note"] = (f"bytes per launch, profiles/{rnd}/{{fetch,write}}.md: (2*FETCH_SIZE + WRITE_SIZE) KB"
-                                   + ("" if rnd == "r03" else " (an earlier round's kernel)"))
+                                   + ("" if rnd in ("r03", "r04") else " (an earlier round's kernel)"))
             us = [v["avg_duration_us"] for v in t.values() if isinstance(v, dict) and "avg_duration_us" in v]
             if us:
                 out["serialised_avg_launch_ms"] = float(np.mean(us)) * 1e-3
                 out["serialised_note"] = f"average duration of the same kernel under the --pmc passes of profiles/{rnd} (every dispatch alone on the chip)"
             break
     return out
+
+
+def potf2_record(eng, a):
+    """The diagonal-block kernel of the blocked Cholesky, so that a slow box explains itself: HIP-event
+    time per launch stand-alone (potrf of one 128 x 128 block: nothing else on the chip) and inside this workload's
+    pipeline (average over the launches of one predict pass: placement + execution beside the trailing update), for
+    the default kernel and — switched in THIS process and context (gpx_debug_set_potf2; all three give the same bits)
+    — the two it replaced, with the potrf stage time each gives."""
+    from gpax_amd import _lib
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((128, 128))
+    A = A @ A.T + 128 * np.eye(128)
+    rec = {"default": "slim", "standalone_us": {}, "in_pipeline_us": {}, "potf2_ms_per_predict": {}, "potrf_ms": {}}
+    for mode in ("chain", "tile", "slim"):  # the default last: the context is left on it
+        eng.set_potf2(mode)
+        for _ in range(3):
+            eng.potrf(A)
+        eng.profile_enable(True)
+        eng.profile_reset()
+        for _ in range(20):
+            eng.potrf(A)
+        n, ms, _ = eng.profile_read(_lib.PROF_POTF2)
+        rec["standalone_us"][mode] = ms / n * 1e3 if n else None
+        eng.profile_reset()
+        eng.time_stage(_lib.STAGE_PREDICT, 1)
+        n, ms, _ = eng.profile_read(_lib.PROF_POTF2)
+        eng.profile_enable(False)
+        rec["in_pipeline_us"][mode] = ms / n * 1e3 if n else None
+        rec["potf2_ms_per_predict"][mode] = ms
+        eng.time_stage(_lib.STAGE_POTRF, 1)
+        rec["potrf_ms"][mode] = float(np.median([eng.time_stage(_lib.STAGE_POTRF, 1) for _ in range(3)]))
+    rec["note"] = ("slim (csrc/potf2_slim.h): 88 VGPRs / 28 KB LDS, placed at once beside two resident trailing-update "
+                   "workgroups; chain (round 3): 344 VGPRs / 46 KB, waits for a drained CU; tile (round 2): the tests' "
+                   "reference.  in_pipeline = HIP events around each launch on its stream, one theta in flight")
+    return rec
 
 
 def device_record(eng, a, lml):
@@ -199,6 +252,7 @@ def device_record(eng, a, lml):
     pmc = committed_pmc_record(N, d, M)
     post_flops = N ** 3 / 3 + N * N * M + N * M * M + 2 * N * N + 2 * N * M
     pk = FP64_MFMA_PEAK_TFLOPS * 1e12
+    p2 = potf2_record(eng, a)
     roof = {
         "bound": "mfma",
         "kernel": "gpx::gemm_nt128_kernel<1,1> (Cholesky trailing SYRK, lower tiles, LDS-direct staging; K = 1024 while the "
@@ -218,9 +272,15 @@ def device_record(eng, a, lml):
         "serialised_frac": ((flops / n_l) / (pmc["serialised_avg_launch_ms"] * 1e-3) / pk)
         if (pmc["serialised_avg_launch_ms"] and n_l) else None,
         "serialised_note": pmc.get("serialised_note"),
+        "committed_constants": ["traffic", "traffic_over_alg_bytes (its numerator)", "serialised_avg_launch_ms", "serialised_frac "
+                                "(its denominator)"],
+        "committed_constants_note": "read from the committed rocprofv3 --pmc summaries under profiles/ (separate passes of this "
+                                    "same command, MI355X_MICROARCH.md HBM section); every other field of this block is "
+                                    "measured live in this run with HIP events on the launching stream",
     }
     return {
         "roofline": roof,
+        "potf2": p2,
         "stages": stages,
         "stages_frac_of_fp64_peak": {
             "potrf": (N ** 3 / 3) / (stages["potrf_ms"] * 1e-3) / pk,
@@ -453,8 +513,20 @@ def multi_rank(a, env):
     rk.barrier()
     t0 = time.perf_counter()
     res = sweep(world * W, world * (W + K))
+    dt_own = time.perf_counter() - t0  # this rank's view: its block + its part in broadcast / gather
     rk.barrier()
     dt = float(rk.allreduce_max([time.perf_counter() - t0])[0])
+    # per-rank seconds and the GPU every rank drives, so that ONE JSON line explains a partial failure or ranks that
+    # share a device (one slot per rank, the other slots at -inf, max over ranks: an all-gather of small vectors)
+    slots = min(world, 32)
+    vec = np.full(2 * slots, -np.inf)
+    if rank < slots:
+        vec[rank] = dt_own
+        vec[slots + rank] = float(rk.device_pci())
+    vec = rk.allreduce_max(vec)
+    per_rank_s = [float(v) for v in vec[:slots]]
+    pci = [int(v) for v in vec[slots:2 * slots] if np.isfinite(v)]
+    n_distinct = len(set(pci))
 
     # ---- second record: C4 (BASELINE.json configs[3]) through the same collective, and on rank 0 alone -------------------
     c4 = None
@@ -501,6 +573,12 @@ def multi_rank(a, env):
         out = base_line(a, world, K, W, dt, n_fl,
                         f"sample-sharded x{world} (one process per GPU), {n_fl} samples in flight per GPU")
         out["multi_gpu_path"] = "rank-" + info["transport"]
+        # n_gpus = distinct physical devices (ranks may share one: LOCAL_RANK beyond the visible devices, --share-gpu)
+        out["ranks"] = world
+        out["n_gpus"] = n_distinct
+        out["shared_devices"] = n_distinct < world
+        out["per_rank_seconds"] = per_rank_s
+        out["devices_pci"] = ["%04x:%02x:%02x" % (v >> 16, (v >> 8) & 0xff, v & 0xff) for v in pci]
         out["rccl_version"] = info["rccl_version"]
         out["rccl_ranks"] = world if info["transport"] == "rccl" else 0
         out["collective"] = ("gpx_rank_predict_sweep: H2D on rank 0, ncclBroadcast, per-rank block, ncclSend/ncclRecv "

@@ -96,6 +96,7 @@ def load_library() -> C.CDLL:
         "gpx_rank_destroy": (None, [vp]),
         "gpx_rank_last_error": (C.c_char_p, [vp]),
         "gpx_rank_info": (C.c_int, [vp, _ip, _ip, _ip, _ip, _ip]),
+        "gpx_rank_device_pci": (C.c_int, [vp, _ip, _ip, _ip]),
         "gpx_rank_barrier": (C.c_int, [vp]),
         "gpx_rank_allreduce_max": (C.c_int, [vp, _dp, C.c_int]),
         "gpx_rank_bcast": (C.c_int, [vp, _dp, C.c_int64]),
@@ -118,7 +119,7 @@ EXPORTED_SYMBOLS = (
     "gpx_profile_enable "
     "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_set_potf2 gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_predict_sweep_multi "
-    "gpx_rank_unique_id gpx_rank_init gpx_rank_destroy gpx_rank_last_error gpx_rank_info gpx_rank_barrier "
+    "gpx_rank_unique_id gpx_rank_init gpx_rank_destroy gpx_rank_last_error gpx_rank_info gpx_rank_device_pci gpx_rank_barrier "
     "gpx_rank_allreduce_max gpx_rank_bcast gpx_rank_predict_sweep gpx_shard_range"
 ).split()
 
@@ -628,6 +629,12 @@ class Rank:
         return {"rank": r.value, "nranks": n.value, "inflight": f.value, "transport": "rccl" if t.value else "file",
                 "rccl_version": v.value}
 
+    def device_pci(self) -> int:
+        """(domain << 16) | (bus << 8) | device of the GPU this rank drives (gpx_rank_device_pci)."""
+        d, b, v = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.gpx_rank_device_pci(self._rk, C.byref(d), C.byref(b), C.byref(v)), "gpx_rank_device_pci")
+        return (int(d.value) << 16) | (int(b.value) << 8) | int(v.value)
+
     def barrier(self):
         self._check(self._lib.gpx_rank_barrier(self._rk), "gpx_rank_barrier")
 
@@ -651,17 +658,23 @@ class Rank:
         (means, samples, infos[, vars]) on rank 0, None on the other ranks."""
         root = self.rank == 0
         means = samples = infos = vars_ = None
+        prep_error = None
         if root:
-            X = _f64(X, (N, d))
-            ells = _f64(ells, (S, n_ell(kind, d)))
-            scales, noises = _f64(scales, (S,)), _f64(noises, (S,))
-            yres = _f64(yres, (yres_rows, N))
-            Xnew = _f64(Xnew, (M, d))
-            eps = None if n == 0 else _f64(eps, (S, n, M))
-            means = np.empty((S, M))
-            samples = np.empty((S, n, M))
-            infos = np.zeros(S, dtype=np.int32)
-            vars_ = np.empty((S, M)) if want_var else None
+            try:
+                X = _f64(X, (N, d))
+                ells = _f64(ells, (S, n_ell(kind, d)))
+                scales, noises = _f64(scales, (S,)), _f64(noises, (S,))
+                yres = _f64(yres, (yres_rows, N))
+                Xnew = _f64(Xnew, (M, d))
+                eps = None if n == 0 else _f64(eps, (S, n, M))
+                means = np.empty((S, M))
+                samples = np.empty((S, n, M))
+                infos = np.zeros(S, dtype=np.int32)
+                vars_ = np.empty((S, M)) if want_var else None
+            except Exception as ex:  # a bad array on the root must not strand the other ranks inside the collective:
+                prep_error = ex       # enter it with null pointers — the library makes every rank leave with an error
+                X = ells = scales = noises = yres = Xnew = eps = means = samples = infos = vars_ = None
+                S = max(int(S), 1)
         else:
             X = ells = scales = noises = yres = Xnew = eps = None
         rc = self._lib.gpx_rank_predict_sweep(
@@ -669,6 +682,8 @@ class Rank:
             int(yres_rows), _ptr(Xnew), int(M), int(bool(noiseless)), float(jitter), _ptr(eps), int(n), _ptr(means),
             _ptr(samples) if (root and n) else None, None if infos is None else infos.ctypes.data_as(_ip), _ptr(vars_),
             int(bool(want_var)), int(m_slice))
+        if prep_error is not None:
+            raise prep_error
         self._check(rc, "gpx_rank_predict_sweep")
         if not root:
             return None

@@ -279,6 +279,19 @@ int gpx_rank_info(const gpx_rank* rk, int* rank, int* nranks, int* inflight, int
   return 0;
 }
 
+int gpx_rank_device_pci(const gpx_rank* rk, int* domain, int* bus, int* dev) {
+  if (!rk || rk->device < 0) return -1;
+  int d = 0, b = 0, v = 0;
+  if (hipDeviceGetAttribute(&d, hipDeviceAttributePciDomainID, rk->device) != hipSuccess ||
+      hipDeviceGetAttribute(&b, hipDeviceAttributePciBusId, rk->device) != hipSuccess ||
+      hipDeviceGetAttribute(&v, hipDeviceAttributePciDeviceId, rk->device) != hipSuccess)
+    return -2;
+  if (domain) *domain = d;
+  if (bus) *bus = b;
+  if (dev) *dev = v;
+  return 0;
+}
+
 int gpx_rank_allreduce_max(gpx_rank* rk, double* v, int n) {
   if (!rk || !v) return -1;
   return allreduce_max(rk, v, n);
@@ -305,14 +318,23 @@ int gpx_rank_predict_sweep(gpx_rank* rk, int kind, const double* X, int N, int d
                            const double* Xnew, int M, int noiseless, double jitter, const double* eps, int n,
                            double* means, double* samples, int* infos, double* vars, int want_vars, int m_slice) {
   if (!rk || rk->device < 0) return -1;
-  if (S < 0 || n < 0) return rank_bad_arg(rk, "negative count");
-  if (N < 1 || M < 1 || d < 1 || d > GPX_MAX_DIM) return rank_bad_arg(rk, "sizes");
-  if (yres_rows != 1 && yres_rows != S) return rank_bad_arg(rk, "yres_rows must be 1 or S");
   const bool root = rk->rank == 0;
-  if (root) {
-    if (S > 0 && (!X || !ells || !scales || !noises || !yres || !Xnew || !means)) return rank_bad_arg(rk, "null pointer on rank 0");
-    if (S > 0 && n > 0 && (!eps || !samples)) return rank_bad_arg(rk, "eps/samples required when n > 0");
-    if (want_vars && !vars) return rank_bad_arg(rk, "vars required when want_vars");
+  // Argument checks must not let one rank leave while the others enter the broadcast (they would wait for it for
+  // ever — 600 s under the file transport): every rank first learns whether ANY rank found a bad argument (one
+  // all-reduce of a flag; the arrays exist on rank 0 only, so only it can judge them) and all leave together.
+  const char* bad = nullptr;
+  if (S < 0 || n < 0) bad = "negative count";
+  else if (N < 1 || M < 1 || d < 1 || d > GPX_MAX_DIM) bad = "sizes";
+  else if (yres_rows != 1 && yres_rows != S) bad = "yres_rows must be 1 or S";
+  else if (root && S > 0 && (!X || !ells || !scales || !noises || !yres || !Xnew || !means)) bad = "null pointer on rank 0";
+  else if (root && S > 0 && n > 0 && (!eps || !samples)) bad = "eps/samples required when n > 0";
+  else if (root && want_vars && !vars) bad = "vars required when want_vars";
+  {
+    double flag = bad ? 1.0 : 0.0;
+    const int arc = allreduce_max(rk, &flag, 1);
+    if (arc != 0) return arc;
+    if (bad) return rank_bad_arg(rk, bad);
+    if (flag != 0.0) return rank_bad_arg(rk, "another rank rejected its arguments (the arrays live on rank 0)");
   }
   if (S == 0) return 0;
   const int G = rk->nranks;

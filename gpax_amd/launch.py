@@ -34,6 +34,41 @@ class RankEnv:
     rdzv_dir: str
     attempt: int = 0
     owns_dir: bool = False  # the directory was derived here (not handed over by a launcher that cleans it up)
+    token: str = ""         # names THIS launch inside the directory (see launch_token)
+
+
+def launch_token(environ=None) -> str:
+    """A name every rank of ONE launch derives alike and that no other launch shares, so that a rendezvous directory
+    that is used again (a GPX_RDZV_DIR set by hand, a crashed run, a launcher restarting its workers under the same
+    port) never shows this launch the keys or transfer files of an earlier one: $GPX_RDZV_TOKEN when the launcher hands
+    one out (spawn_ranks does), else the launcher's agent process — the common parent of the ranks — by PID AND start
+    time, plus what the launcher exports about the run."""
+    e = os.environ if environ is None else environ
+    t = e.get("GPX_RDZV_TOKEN")
+    if t:
+        return "".join(c if (c.isalnum() or c in "-_.") else "_" for c in t)[:96]
+    ppid, start = os.getppid(), "0"
+    try:
+        with open(f"/proc/{ppid}/stat") as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]  # field 22: start time of the process, in clock ticks since boot
+    except (OSError, IndexError):
+        pass
+    run = "".join(c if c.isalnum() else "_" for c in e.get("TORCHELASTIC_RUN_ID", ""))[:32]
+    return f"p{ppid}_{start}_{e.get('MASTER_PORT', '0')}_{run}"
+
+
+def _private_dir(path: str) -> None:
+    """Create `path` for this user only and refuse one that somebody else could have planted (another owner, group /
+    world access, a symbolic link): the directory carries the 128-byte RCCL bootstrap id."""
+    os.makedirs(path, mode=0o700, exist_ok=True)
+    st = os.lstat(path)
+    import stat as _stat
+    if _stat.S_ISLNK(st.st_mode) or not _stat.S_ISDIR(st.st_mode):
+        raise PermissionError(f"rendezvous directory {path} is not a plain directory")
+    if hasattr(os, "geteuid") and st.st_uid != os.geteuid():
+        raise PermissionError(f"rendezvous directory {path} belongs to uid {st.st_uid}, not to this user")
+    if st.st_mode & 0o022:
+        raise PermissionError(f"rendezvous directory {path} is writable by others (mode {oct(st.st_mode & 0o777)})")
 
 
 def rank_env(environ=None) -> Optional[RankEnv]:
@@ -49,7 +84,7 @@ def rank_env(environ=None) -> Optional[RankEnv]:
         # all ranks of one launch share their parent (the launcher's agent process) and its rendezvous port
         d = os.path.join(tempfile.gettempdir(), f"gpx_rdzv_{os.getppid()}_{e.get('MASTER_PORT', '0')}")
         owns = True
-    return RankEnv(rank, world, local, d, int(e.get("GPX_RDZV_ATTEMPT", "0")), owns)
+    return RankEnv(rank, world, local, d, int(e.get("GPX_RDZV_ATTEMPT", "0")), owns, launch_token(e))
 
 
 class FileStore:
@@ -57,7 +92,7 @@ class FileStore:
 
     def __init__(self, directory: str, fresh_after: Optional[float] = None):
         self.dir = directory
-        os.makedirs(directory, exist_ok=True)
+        _private_dir(directory)
         # keys older than this are leftovers of an earlier launch that happened to reuse the directory name
         self.fresh_after = fresh_after
 
@@ -95,6 +130,8 @@ def _reexec_with_file_transport(env: RankEnv, why: str):
     os.environ["GPX_RANK_TRANSPORT"] = "file"
     os.environ["GPX_RDZV_ATTEMPT"] = str(env.attempt + 1)
     os.environ["GPX_RDZV_DIR"] = env.rdzv_dir
+    if env.token:
+        os.environ["GPX_RDZV_TOKEN"] = env.token
     if env.owns_dir:
         os.environ["GPX_RDZV_OWNS"] = "1"
     os.execv(sys.executable, [sys.executable] + sys.argv)
@@ -127,9 +164,14 @@ def init_rank(env: RankEnv, device: Optional[int] = None, inflight: Optional[int
         raise ValueError(f"transport {transport!r}")
 
     t_start = time.time()
-    store = FileStore(os.path.join(env.rdzv_dir, f"attempt{env.attempt}"), fresh_after=t_start - 300.0)
+    # <directory>/<launch token>/attempt<k>: nothing an earlier launch left in the directory is visible from here, neither
+    # store keys nor the file transport's transfer files (their names restart at sequence 0 in every process)
+    _private_dir(env.rdzv_dir)
+    base = os.path.join(env.rdzv_dir, env.token) if env.token else env.rdzv_dir
+    _private_dir(base)
+    store = FileStore(os.path.join(base, f"attempt{env.attempt}"), fresh_after=t_start - 300.0)
     xfer_dir = os.path.join(store.dir, "xfer")
-    os.makedirs(xfer_dir, exist_ok=True)
+    _private_dir(xfer_dir)
 
     done = threading.Event()
 
@@ -229,12 +271,13 @@ def spawn_ranks(script: str, argv: List[str], nranks: int, timeout: Optional[flo
     """Minimal single-node launcher: N copies of `python script argv...`, one per rank, sharing a fresh rendezvous
     directory.  Returns the first non-zero exit code (the remaining ranks are terminated), else 0."""
     rdzv = tempfile.mkdtemp(prefix="gpx_rdzv_")
+    token = "l" + os.urandom(8).hex()
     procs = []
     try:
         for r in range(nranks):
             env = dict(os.environ)
             env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nranks), "MASTER_ADDR": "127.0.0.1",
-                        "GPX_RDZV_DIR": rdzv})
+                        "GPX_RDZV_DIR": rdzv, "GPX_RDZV_TOKEN": token})
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env))
         t0 = time.monotonic()

@@ -435,8 +435,14 @@ class ExactGP:
                     gl = glik.get(s.name)
                     if gl is not None:
                         gx = np.asarray(gl, dtype=np.float64).reshape(-1)
-                        if gx.size != s.size:  # one lengthscale shared by all input dimensions (custom kernel_prior)
-                            gx = np.array([gx.sum()])
+                        if gx.size != s.size:
+                            # a site with fewer values than the device gradient has entries: one lengthscale shared by all
+                            # input dimensions (custom kernel_prior) — per TASK when the site carries the task axis
+                            # (vExactGP: gradient (T, d), site (T,) or (T, 1)): each site element collects its own row
+                            if s.size > 1 and gx.size % s.size == 0:
+                                gx = gx.reshape(s.size, -1).sum(axis=1)
+                            else:
+                                gx = np.array([gx.sum()])
                     else:  # mean-function parameter: d lml / d phi = sum_i alpha_i d m_i / d phi
                         gx = self._dmean(self.X_train, theta, s.name) @ np.asarray(alpha, dtype=np.float64).reshape(-1)
                     gu = (gx + d_.grad_log_prob(x)) * d_.dx_du(ui)

@@ -56,13 +56,9 @@ class viSparseGP(viGP):
             val += float(np.sum(s.dist.log_prob(xi)))
             if s.name in glik:
                 gx = glik[s.name].reshape(-1)
-            else:  # mean-function parameter through d bound / d yres
-                h = 1e-6 * max(1.0, abs(float(xi[0])))
-                tp, tm = dict(theta), dict(theta)
-                tp[s.name] = float(xi[0]) + h
-                tm[s.name] = float(xi[0]) - h
-                dm = (self._mean(self.X_train, tp) - self._mean(self.X_train, tm)) / (2 * h)
-                gx = np.array([-float(g["yres"] @ dm)])
+            else:  # mean-function parameter through d bound / d yres: the full Jacobian of the site (a vector-valued
+                # site — a plate inside mean_fn_prior — gets one row per element, as ExactGP's chain rule does)
+                gx = -(self._dmean(self.X_train, theta, s.name) @ np.asarray(g["yres"], dtype=np.float64).reshape(-1))
             gx = gx + s.dist.grad_log_prob(xi)
             gu = gx * s.dist.dx_du(ui)
             if jacobian:

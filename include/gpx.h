@@ -229,6 +229,9 @@ int gpx_rank_init(int device, int rank, int nranks, const char* unique_id, const
 void gpx_rank_destroy(gpx_rank* rk);
 const char* gpx_rank_last_error(const gpx_rank* rk);
 int gpx_rank_info(const gpx_rank* rk, int* rank, int* nranks, int* inflight, int* transport_rccl, int* rccl_version);
+/* PCI address of the GPU this rank drives: what tells ranks that SHARE a device (a launcher whose LOCAL_RANK exceeds the
+ * visible devices, a test box) from ranks on distinct GPUs — bench.py reports the number of distinct devices as n_gpus. */
+int gpx_rank_device_pci(const gpx_rank* rk, int* domain, int* bus, int* dev);
 int gpx_rank_barrier(gpx_rank* rk);
 int gpx_rank_allreduce_max(gpx_rank* rk, double* v, int n);
 int gpx_rank_bcast(gpx_rank* rk, double* buf, int64_t count);

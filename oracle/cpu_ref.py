@@ -266,6 +266,49 @@ def exactgp_log_likelihood_grad(X, y, params, kernel="RBF", jitter=1e-6, yres=No
     return g_ell, g_scale, g_noise, alpha
 
 
+def exactgp_log_likelihood_grad_blocked(X, y, params, kernel="RBF", jitter=1e-6, block=1024):
+    """exactgp_log_likelihood_grad for sizes where its (N, N, d) temporaries do not fit (C3: N = 16384 would need
+    ~15 GB): the same formula, 1/2 sum_ij (alpha alpha^T - K^-1)_ij dK_ij/dtheta, with K^-1 from the Cholesky factor
+    (LAPACK potri) and the contraction accumulated over row blocks.  Peak memory 2 N^2 doubles.  tests/test_oracle.py
+    holds it against the unblocked function; the GPU test of the headline size uses it."""
+    from scipy.linalg import lapack
+    X, y = _set_data(X, y)
+    N, d = X.shape
+    ell = np.broadcast_to(np.asarray(params["k_length"], dtype=np.float64).reshape(-1), (d,)).astype(np.float64)
+    s = float(params["k_scale"])
+    K = get_kernel(kernel)(X, X, params, params["noise"], jitter=jitter)
+    c, info = lapack.dpotrf(K, lower=1, overwrite_a=1)
+    assert info == 0
+    alpha = sla.cho_solve((c, True), y)
+    Kinv, info = lapack.dpotri(c, lower=1, overwrite_c=1)  # lower triangle of K^-1
+    assert info == 0
+    g_ell = np.zeros(d)
+    g_scale = 0.0
+    g_trace = 0.0
+    for r0 in range(0, N, block):
+        r1 = min(N, r0 + block)
+        # row block of G = alpha alpha^T - K^-1 (symmetric: the block's upper part comes from the transposed column block)
+        Kb = np.tril(Kinv[r0:r1, :], k=r0)  # entries (i, j) with j <= i
+        Kb[:, r0:] += np.triu(Kinv[r0:, r0:r1].T, k=1)[:, : N - r0]
+        G = np.outer(alpha[r0:r1], alpha) - Kb
+        g_trace += float(np.trace(G[:, r0:r1]))
+        diff = (X[r0:r1, None, :] - X[None, :, :]) / ell
+        r2 = (diff ** 2).sum(-1)
+        if kernel == "RBF":
+            kb = s * np.exp(-0.5 * r2)
+            dk = -0.5 * kb
+        else:
+            r = np.sqrt(r2 + 1e-12)
+            e = np.exp(-math.sqrt(5.0) * r)
+            kb = s * (1 + math.sqrt(5.0) * r + (5 / 3) * r2) * e
+            dk = -(5.0 / 6.0) * s * e * (1 + math.sqrt(5.0) * r2 / r)
+        Gd = G * dk
+        for m in range(d):
+            g_ell[m] += 0.5 * float(np.sum(Gd * (-2.0 * diff[:, :, m] ** 2 / ell[m])))
+        g_scale += 0.5 * float(np.sum(G * kb)) / s
+    return g_ell, g_scale, 0.5 * g_trace, alpha
+
+
 def get_mvn_posterior(X_train, y_train, X_new, params, noiseless=False, kernel="RBF", jitter=1e-6,
                       mean_fn=None, mean_fn_has_params=False, route="inv") -> Tuple[np.ndarray, np.ndarray]:
     """ExactGP.get_mvn_posterior, gpax/models/gp.py:253-277.
@@ -394,8 +437,10 @@ def sparse_bound(X, y, Xu, params, kernel="Matern", jitter=1e-6, f_loc=None) -> 
     return lowrank_mvn_log_prob(y, loc, W, D) - trace_term / 2.0
 
 
-def sparse_posterior(X_train, y_train, Xu, X_new, params, noiseless=False, kernel="Matern", jitter=1e-6):
-    """viSparseGP.get_mvn_posterior, gpax/models/sparse_gp.py:173-223 (no mean function)."""
+def sparse_posterior(X_train, y_train, Xu, X_new, params, noiseless=False, kernel="Matern", jitter=1e-6, mean_fn=None,
+                     mean_fn_has_params=False):
+    """viSparseGP.get_mvn_posterior, gpax/models/sparse_gp.py:173-223; mean_fn / mean_fn_has_params as
+    sparse_gp.py:189-192 (residual) and :219-221 (mean added back at X_new)."""
     X_train, y_train = _set_data(X_train, y_train)
     X_new = _set_data(X_new)
     kfn = get_kernel(kernel)
@@ -404,6 +449,9 @@ def sparse_posterior(X_train, y_train, Xu, X_new, params, noiseless=False, kerne
     D = np.broadcast_to(noise, (N,)).astype(np.float64)
     noise_p = noise * (1 - int(bool(noiseless)))
     y_residual = y_train.copy()
+    if mean_fn is not None:
+        args = [X_train, params] if mean_fn_has_params else [X_train]
+        y_residual = y_residual - np.asarray(mean_fn(*args)).squeeze()
     Kuu = kfn(Xu, Xu, params, jitter=jitter)
     Luu = np.linalg.cholesky(Kuu)
     Kuf = kfn(Xu, X_train, params, jitter=0)
@@ -424,6 +472,9 @@ def sparse_posterior(X_train, y_train, Xu, X_new, params, noiseless=False, kerne
     Kss = kfn(X_new, X_new, params, noise_p, jitter=jitter)
     Qss = Ws.T @ Ws
     cov = Kss - Qss + Linv_Ws.T @ Linv_Ws
+    if mean_fn is not None:
+        args = [X_new, params] if mean_fn_has_params else [X_new]
+        mean = mean + np.asarray(mean_fn(*args)).squeeze()
     return mean, cov
 
 

@@ -49,7 +49,8 @@ def check_one_theta(engine, kind, name, X, y, Xn, p, eps, route, want_grad):
         engine.factor(kind, p["k_length"], p["k_scale"], p["noise"], JIT, y)
         g_ell, g_scale, g_noise, alpha = engine.lml_grad()
         if want_grad:
-            e_ell, e_scale, e_noise, e_alpha = ref.exactgp_log_likelihood_grad(X, y, p, kernel=name, jitter=JIT)
+            # (the blocked restatement: same formula, N^2 memory — tests/test_oracle.py holds it against the plain one)
+            e_ell, e_scale, e_noise, e_alpha = ref.exactgp_log_likelihood_grad_blocked(X, y, p, kernel=name, jitter=JIT)
             sc = max(np.abs(e_ell).max(), abs(e_scale), abs(e_noise))
             np.testing.assert_allclose(g_ell, e_ell, rtol=1e-8, atol=1e-8 * sc)
             assert abs(g_scale - e_scale) <= 1e-8 * sc and abs(g_noise - e_noise) <= 1e-8 * sc
@@ -103,6 +104,39 @@ def test_c3_matern_n16384_vs_oracle(engine):
     X, y, Xn, p = synthetic_problem(N, d, M, seed=0)
     eps = np.random.default_rng(2).standard_normal((1, M))
     check_one_theta(engine, 1, "Matern", X, y, Xn, p, eps, route="chol", want_grad=False)
+
+
+def test_c3_gradient_n16384_vs_oracle_and_tree_vs_sweep(monkeypatch):
+    """the fit step's gradient at the HEADLINE size.  `linv_t_tree` runs 7 levels deep at N = 16384
+    and K^-1 = W W^T has 129 tile rows there; until round 4 both were oracle-checked to N = 8192 only.  gpx_lml_grad (tree
+    path) against the oracle's analytic gradient (gpax/models/gp.py:137-164 gets it from JAX autodiff) at 1e-8, and
+    against the right-looking sweep (GPX_LINVT=sweep, another summation order) at 1e-10."""
+    from gpax_amd import _lib
+
+    N, d = 16384, 2
+    X, y, _, p = synthetic_problem(N, d, 8, seed=0)
+    got = {}
+    for mode in ("tree", "sweep"):
+        monkeypatch.setenv("GPX_LINVT", mode)
+        e = _lib.Engine(0)
+        e.set_train(X)
+        lml, info = e.factor(1, p["k_length"], p["k_scale"], p["noise"], JIT, y)
+        assert info == 0
+        got[mode] = (lml,) + tuple(e.lml_grad())
+        e.close()
+    monkeypatch.delenv("GPX_LINVT")
+    e_ell, e_scale, e_noise, e_alpha = ref.exactgp_log_likelihood_grad_blocked(X, y, p, kernel="Matern", jitter=JIT)
+    sc = max(np.abs(e_ell).max(), abs(e_scale), abs(e_noise))
+    for mode, tol in (("tree", 1e-8), ("sweep", 1e-8)):
+        lml, g_ell, g_scale, g_noise, alpha = got[mode]
+        np.testing.assert_allclose(g_ell, e_ell, rtol=0, atol=tol * sc)
+        assert abs(g_scale - e_scale) <= tol * sc and abs(g_noise - e_noise) <= tol * sc
+        assert relerr(alpha, e_alpha) < 1e-8
+    t, s_ = got["tree"], got["sweep"]
+    assert t[0] == s_[0]  # the factorisation is the same launch sequence
+    np.testing.assert_allclose(t[1], s_[1], rtol=0, atol=1e-10 * sc)
+    assert abs(t[2] - s_[2]) <= 1e-10 * sc and abs(t[3] - s_[3]) <= 1e-10 * sc
+    assert relerr(t[4], s_[4]) < 1e-10
 
 
 def test_c5_exact_vigp_on_the_512x512_image():

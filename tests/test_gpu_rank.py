@@ -54,6 +54,23 @@ def test_ranks_sharing_the_gpu_over_the_file_transport(ranks):
     assert "rank_check ok: %d ranks, transport file" % ranks in rc.stdout
 
 
+def test_a_rank_that_dies_before_the_sweep_fails_the_others_instead_of_hanging_them():
+    """rank 1 of 2 (file transport, shared GPU) leaves without a word before the collective; rank 0 must
+    come back from gpx_rank_predict_sweep with an error within the transport's time-out (GPX_RANK_FILE_TIMEOUT)."""
+    import time
+    env = _env()
+    env["GPX_RANK_FILE_TIMEOUT"] = "4"
+    t0 = time.monotonic()
+    rc = subprocess.run([sys.executable, "-c",
+                         "import sys; sys.path.insert(0, %r); from gpax_amd import launch; "
+                         "sys.exit(launch.spawn_ranks(%r, ['--share-gpu', '--die-rank', '1'], 2, timeout=300))"
+                         % (ROOT, os.path.join(ROOT, "tools", "rank_check.py"))],
+                        capture_output=True, text=True, env=env, timeout=400)
+    assert rc.returncode == 0, rc.stdout[-1500:] + rc.stderr[-3000:]
+    assert "rank 0: peer lost detected" in rc.stdout and "timed out waiting for" in rc.stdout
+    assert time.monotonic() - t0 < 120
+
+
 def test_one_rank_per_visible_gpu_over_rccl():
     from gpax_amd import _lib
     n_dev = _lib.visible_device_count()

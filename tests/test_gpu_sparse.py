@@ -171,3 +171,52 @@ def test_forward_pass_is_reused_only_for_identical_inputs():
     e.set_train(X2)
     np.testing.assert_array_equal(e.sgp_posterior(*args(y2, ell2), Xn, 0.0, want_cov=False)[0], fresh(X2, y2, ell2, Xn)[0])
     e.close()
+
+
+def test_vector_valued_mean_site_on_the_gpu():
+    """viSparseGP with a 2-element mean-function site (sparse_gp.py:85-89): the gradient of the objective w.r.t. each
+    element against central differences of the device objective, the posterior against the oracle (mean function
+    subtracted from the residual and added back at X_new, sparse_gp.py:189-192,219-221)."""
+    from bench_inputs import synthetic_problem
+    from gpax_amd import _lib, dist, plate, sample, viSparseGP
+    from oracle import cpu_ref as ref
+
+    _lib.set_engine(None)
+    X, y, Xn, _ = synthetic_problem(400, 2, 50, seed=11)
+    y = y + 0.5 * X[:, 0] - 0.3 * X[:, 1]
+
+    def mean_fn(x, p):
+        return p["w"][0] * x[:, 0] + p["w"][1] * x[:, 1]
+
+    def mean_prior():
+        with plate("w_plate", 2):
+            w = sample("w", dist.Normal(0.0, 2.0))
+        return {"w": w}
+
+    m = viSparseGP(2, "Matern", mean_fn=mean_fn, mean_fn_prior=mean_prior)
+    m.X_train, m.y_train = m._set_data(X, y)
+    sites = m._sites()
+    nu = sum(s.size for s in sites)
+    rng = np.random.default_rng(1)
+    Xu = X[rng.choice(400, 40, replace=False)].copy()
+    x0 = np.concatenate([0.2 * rng.standard_normal(nu), Xu.reshape(-1)])
+    val, grad = m._sparse_log_joint(sites, x0, 40, 1e-4, jacobian=False)
+    off = 0
+    for s_ in sites:
+        if s_.name == "w":
+            break
+        off += s_.size
+    for i in (off, off + 1):
+        h = 1e-5
+        xp, xm = x0.copy(), x0.copy()
+        xp[i] += h
+        xm[i] -= h
+        fd = (m._sparse_log_joint(sites, xp, 40, 1e-4, False)[0] - m._sparse_log_joint(sites, xm, 40, 1e-4, False)[0]) / (2 * h)
+        assert abs(grad[i] - fd) <= 2e-6 * max(1.0, abs(fd)), (i, grad[i], fd)
+    m.Xu = Xu
+    params = {"k_length": np.array([1.3, 1.6]), "k_scale": 1.1, "noise": 0.05, "w": np.array([0.45, -0.25])}
+    mean, cov = m.get_mvn_posterior(Xn, params, jitter=1e-4)
+    e_mean, e_cov = ref.sparse_posterior(X, y, Xu, Xn, params, False, kernel="Matern", jitter=1e-4, mean_fn=mean_fn,
+                                         mean_fn_has_params=True)
+    assert np.linalg.norm(mean - e_mean) <= 1e-8 * np.linalg.norm(e_mean)
+    assert np.linalg.norm(cov - e_cov) <= 1e-8 * np.linalg.norm(e_cov)

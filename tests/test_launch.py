@@ -125,6 +125,50 @@ def test_file_store_ignores_leftovers_of_an_earlier_launch(tmp_path):
     assert st.get("uid", timeout=1.0) == b"fresh"
 
 
+def test_a_reused_directory_never_shows_an_earlier_launch(tmp_path):
+    """the file transport's transfer files are named <tag>.<seq>.<rank> with seq restarting at 0 in every
+    process, and FileStore's freshness window lets a 5-minute-old key through.  Two launches that share a rendezvous
+    directory (GPX_RDZV_DIR set by hand and run twice, a crashed run, a launcher restarting its workers) must still not
+    see each other: each works under <directory>/<launch token>/, and the token differs between launches."""
+    from gpax_amd import launch
+    rdzv = str(tmp_path / "rdzv")
+    first = launch.rank_env({"RANK": "0", "WORLD_SIZE": "1", "GPX_RDZV_DIR": rdzv, "GPX_RDZV_TOKEN": "launchA"})
+    second = launch.rank_env({"RANK": "0", "WORLD_SIZE": "1", "GPX_RDZV_DIR": rdzv, "GPX_RDZV_TOKEN": "launchB"})
+    assert first.token == "launchA" and second.token == "launchB"
+    rk1 = launch.init_rank(first, transport="file", timeout=10.0, make_rank=FakeRank, make_uid=lambda: b"x" * 128)
+    d1 = rk1.args["file_dir"]
+    with open(os.path.join(d1, "in.0.0"), "wb") as f:  # what a first launch's sweep leaves behind
+        f.write(b"stale payload")
+    rk2 = launch.init_rank(second, transport="file", timeout=10.0, make_rank=FakeRank, make_uid=lambda: b"x" * 128)
+    d2 = rk2.args["file_dir"]
+    assert d1 != d2 and os.listdir(d2) == [] and os.path.exists(os.path.join(d1, "in.0.0"))
+    # without a token from the launcher: the common parent of the ranks by PID and start time — the same for every
+    # rank of one launch, and a sanitised path component
+    t = launch.launch_token({"MASTER_PORT": "29511", "TORCHELASTIC_RUN_ID": "run/../7"})
+    assert t == launch.launch_token({"MASTER_PORT": "29511", "TORCHELASTIC_RUN_ID": "run/../7"})
+    assert t.startswith(f"p{os.getppid()}_") and "/" not in t and ".." not in t
+    assert launch.launch_token({"MASTER_PORT": "29512"}) != t
+
+
+def test_the_rendezvous_directory_must_be_private(tmp_path):
+    """a directory another user could have planted (a symbolic link, group / world writable) is refused —
+    it carries the RCCL bootstrap id — and what the store creates is mode 0700."""
+    from gpax_amd.launch import FileStore
+    st = FileStore(str(tmp_path / "fresh"))
+    assert (os.stat(st.dir).st_mode & 0o777) == 0o700
+    loose = tmp_path / "loose"
+    loose.mkdir()
+    os.chmod(loose, 0o777)
+    with pytest.raises(PermissionError, match="writable by others"):
+        FileStore(str(loose))
+    target = tmp_path / "elsewhere"
+    target.mkdir(mode=0o700)
+    link = tmp_path / "link"
+    os.symlink(target, link)
+    with pytest.raises(PermissionError, match="not a plain directory"):
+        FileStore(str(link))
+
+
 def test_rank_env_reads_the_launcher_variables():
     from gpax_amd.launch import rank_env
     assert rank_env({}) is None

@@ -176,3 +176,17 @@ def test_full_pass_equals_the_separate_restatements():
         np.testing.assert_array_equal(draws, ref.mvn_sample(m2, c2, eps))
         K = ref.get_kernel(name)(X, X, p, p["noise"])
         np.testing.assert_allclose(K @ alpha, y, rtol=1e-9, atol=1e-9)
+
+
+def test_blocked_gradient_restatement_equals_the_unblocked_one():
+    """oracle.exactgp_log_likelihood_grad_blocked (row blocks, K^-1 from the Cholesky factor: what the GPU test of the
+    headline size N = 16384 runs on the host) against exactgp_log_likelihood_grad (the faithful, memory-hungry form)."""
+    from bench_inputs import synthetic_problem
+    for name, N, block in (("RBF", 300, 128), ("Matern", 515, 100), ("Matern", 64, 1024)):
+        X, y, _, p = synthetic_problem(N, 2, 4, seed=N)
+        a = ref.exactgp_log_likelihood_grad(X, y, p, kernel=name)
+        b = ref.exactgp_log_likelihood_grad_blocked(X, y, p, kernel=name, block=block)
+        sc = max(np.abs(a[0]).max(), abs(a[1]), abs(a[2]))
+        np.testing.assert_allclose(b[0], a[0], rtol=0, atol=1e-11 * sc)
+        assert abs(b[1] - a[1]) <= 1e-11 * sc and abs(b[2] - a[2]) <= 1e-11 * sc
+        np.testing.assert_allclose(b[3], a[3], rtol=1e-10, atol=1e-12 * np.abs(a[3]).max())

@@ -225,3 +225,43 @@ def test_custom_kernel_and_noise_priors_are_used_not_ignored():
     bad.X_train = np.zeros((T, 5, d))
     with pytest.raises(ValueError, match="tasks"):
         bad._sites()
+
+
+@pytest.mark.parametrize("shape", ["T", "T1"])
+def test_per_task_shared_lengthscale_gradient_matches_finite_differences(shape):
+    """a `kernel_prior` whose k_length has shape (T,) or (T, 1) — one lengthscale per task, shared by the d
+    input dimensions — must get, per task, the sum over ITS OWN d device-gradient entries (not the grand total broadcast
+    to every task)."""
+    from gpax_amd import dist, plate, sample
+    from gpax_amd.models.vgp import vExactGP
+
+    T, d, N = 3, 2, 12
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 3, (T, N, d))
+    y = np.sin(X[..., 0]) * np.cos(X[..., 1]) + 0.1 * rng.standard_normal((T, N))
+
+    def kprior():
+        if shape == "T":
+            with plate("tasks", T):
+                length = sample("k_length", dist.LogNormal(0.0, 1.0))
+        else:
+            with plate("tasks", T, dim=-2):
+                with plate("one", 1, dim=-1):
+                    length = sample("k_length", dist.LogNormal(0.0, 1.0))
+        with plate("tasks2", T):
+            scale = sample("k_scale", dist.LogNormal(0.0, 1.0))
+        return {"k_length": length, "k_scale": scale}
+
+    m = vExactGP(d, "RBF", kernel_prior=kprior)
+    m.X_train, m.y_train = m._set_data(X, y)
+    sites = m._sites()
+    u = 0.3 * rng.standard_normal(sum(s.size for s in sites))
+    val, grad = m._log_joint(sites, u, 1e-6, jacobian=True)
+    fd = np.zeros_like(u)
+    h = 1e-6
+    for i in range(u.size):
+        up, um = u.copy(), u.copy()
+        up[i] += h
+        um[i] -= h
+        fd[i] = (m._log_joint(sites, up, 1e-6, True)[0] - m._log_joint(sites, um, 1e-6, True)[0]) / (2 * h)
+    np.testing.assert_allclose(grad, fd, rtol=2e-5, atol=2e-6)

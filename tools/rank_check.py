@@ -21,6 +21,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--share-gpu", action="store_true")
     ap.add_argument("--inflight", type=int, default=2)
+    ap.add_argument("--die-rank", type=int, default=-1, help="this rank leaves (exit code 0, no goodbye) before the first "
+                    "sweep: the others must come back from the collective with an error, not hang")
     a = ap.parse_args()
     env = launch.rank_env()
     assert env is not None, "start me under a launcher (RANK / WORLD_SIZE)"
@@ -33,6 +35,23 @@ def main():
     b = rk.bcast(np.arange(5.0) if root else np.zeros(5))
     assert np.array_equal(b, np.arange(5.0))
     eng = _lib.Engine(0 if a.share_gpu else env.local_rank) if root else None
+    if a.die_rank >= 0:
+        import time
+        if env.rank == a.die_rank:
+            os._exit(0)
+        t0 = time.monotonic()
+        kw = {}
+        if root:
+            X, y, Xn, _ = synthetic_problem(300, 2, 40, seed=1)
+            th = synthetic_theta_samples(2 * env.world, 2, seed=2)
+            kw = dict(X=X, ells=th["k_length"], scales=th["k_scale"], noises=th["noise"], yres=y, Xnew=Xn)
+        try:
+            rk.predict_sweep(1, 300, 2, 2 * env.world, 40, 0, False, 1e-6, want_var=True, **kw)
+            print(f"rank {env.rank}: the sweep RETURNED although rank {a.die_rank} is gone", flush=True)
+            sys.exit(5)
+        except RuntimeError as ex:
+            print(f"rank {env.rank}: peer lost detected after {time.monotonic() - t0:.1f} s: {ex}", flush=True)
+        os._exit(0)  # no finalize: the communicator is broken
     cases = [  # N, d, M, S, n, kind, per-sample yres, m_slice, want_var, bad theta
         (300, 3, 70, 4 * env.world + 1, 1, 0, True, 32, False, True),
         (3100, 2, 130, 2 * env.world + 1, 2, 1, False, 0, True, False),
@@ -64,6 +83,14 @@ def main():
                 assert want[2][S // 2] != 0 and np.isnan(got[0][S // 2]).all()
         else:
             assert got is None
+    # a bad array on the ROOT (the only rank that holds arrays): every rank leaves the collective with an error — the
+    # others must not wait for a broadcast that never comes
+    try:
+        rk.predict_sweep(1, 300, 2, 3, 40, 1, False, 1e-6, X=np.zeros((7, 2)) if root else None)
+        raise SystemExit(f"rank {env.rank}: a mis-shaped X on rank 0 went through")
+    except (ValueError, RuntimeError, TypeError):
+        pass
+    rk.barrier()  # ... and the communicator is still usable
     # the model API: ExactGP.predict_distributed over this communicator against ExactGP.predict on rank 0 alone
     from gpax_amd import ExactGP
     from gpax_amd.utils import get_keys
