@@ -57,7 +57,10 @@ static inline void set_batch(GemmArgs& g, int batch, int64_t a_bs, int64_t b_bs,
 // the inverse) -> update of the outer block's remaining columns.
 // (Round 2 overlapped the next potf2 with that update — "early diagonal", with and without fusing the update into the
 // potf2 kernel — and round 3 ran a whole block's chain as one cooperative kernel; both bit-identical, both slower:
-// profiles/r02/chain_experiments.md, profiles/r03/panel_kernel.md, tools/exp/panel.hip.)
+// profiles/r02/chain_experiments.md, profiles/r03/panel_kernel.md, tools/exp/panel.hip.  Round 4 ran the inner updates
+// left-looking — column kb brought up to date in ONE update of K = 128 (kb - ob) right before its potf2, a column of
+// the block read and written once instead of (kb - ob) times; bit-identical — potrf 29.1 -> 29.3 ms at C3, the fit
+// step at N = 512 0.565 -> 0.609 ms: the longer update sits on the chain right before the potf2.  Not kept.)
 static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob, int oe,
                        double* dLinv, int* dInfo, const BatchStrides& bs) {
   for (int kb = ob; kb < oe; ++kb) {

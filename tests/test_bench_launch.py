@@ -37,14 +37,17 @@ def test_gpus_1_does_not_relaunch():
 
 
 @pytest.mark.gpu
-def test_two_ranks_sharing_the_gpu_report_n_gpus_2():
+def test_two_ranks_sharing_the_gpu_report_two_ranks_on_one_device():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--N", "2048",
                           "--M", "256", "--steps", "4", "--warmup", "1", "--inflight", "1", "--c4-S", "12", "--c4-N",
                           "1024"], capture_output=True, text=True, env=_env(), timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
-    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["value"] > 0 and rec["nan_rows"] == 0
+    # n_gpus counts distinct physical devices (by PCI address), `ranks` the processes
+    assert rec["ranks"] == 2 and rec["n_gpus"] == 1 and rec["shared_devices"] is True and len(rec["devices_pci"]) == 2
+    assert len(rec["per_rank_seconds"]) == 2 and all(0 < t <= rec["ms_per_step"] * rec["steps"] / 1e3 * 1.5 for t in rec["per_rank_seconds"])
+    assert rec["steps"] == 4 and rec["value"] > 0 and rec["nan_rows"] == 0
     assert rec["multi_gpu_path"] == "rank-file" and rec["rccl_ranks"] == 0
     assert rec["roofline"]["frac"] > 0
     c4 = rec["c4_sweep"]
