@@ -368,15 +368,24 @@ def single_gpu(a, device=0):
             e.synchronize()
 
     def sweep(sl):
-        """The steps of slice `sl`, split in contiguous blocks over the in-flight contexts."""
-        idx = np.arange(sl.start, sl.stop)
-        parts = [idx[(len(idx) * i) // n_fl:(len(idx) * (i + 1)) // n_fl] for i in range(n_fl)]
+        """The steps of slice `sl` over the in-flight contexts: every context takes the next step when it has finished its
+        own (a shared cursor), so all of them stop within one step of each other.  (Rounds 1 - 3 dealt contiguous blocks
+        of K / n_fl steps: the context the hardware happened to favour finished early and the others ran the last steps
+        with fewer samples in flight — the reason `value` moved by +-4 % between runs of the same binary.)"""
+        idx = list(range(sl.start, sl.stop))
+        cursor = [0]
+        lock = threading.Lock()
         ev = [0.0] * n_fl
 
         def work(i):
-            if len(parts[i]):
-                ev[i] = engines[i].sweep_resident(kind, thetas["k_length"][parts[i]], thetas["k_scale"][parts[i]],
-                                                  thetas["noise"][parts[i]], False, 1e-6, 1)
+            while True:
+                with lock:
+                    if cursor[0] >= len(idx):
+                        return
+                    k = idx[cursor[0]]
+                    cursor[0] += 1
+                ev[i] += engines[i].sweep_resident(kind, thetas["k_length"][k:k + 1], thetas["k_scale"][k:k + 1],
+                                                   thetas["noise"][k:k + 1], False, 1e-6, 1)
 
         ts = [threading.Thread(target=work, args=(i,)) for i in range(n_fl)]
         for t_ in ts:

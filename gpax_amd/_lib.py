@@ -97,6 +97,7 @@ def load_library() -> C.CDLL:
         "gpx_rank_last_error": (C.c_char_p, [vp]),
         "gpx_rank_info": (C.c_int, [vp, _ip, _ip, _ip, _ip, _ip]),
         "gpx_rank_device_pci": (C.c_int, [vp, _ip, _ip, _ip]),
+        "gpx_rank_collective_calls": (C.c_int64, [vp]),
         "gpx_rank_barrier": (C.c_int, [vp]),
         "gpx_rank_allreduce_max": (C.c_int, [vp, _dp, C.c_int]),
         "gpx_rank_bcast": (C.c_int, [vp, _dp, C.c_int64]),
@@ -119,7 +120,7 @@ EXPORTED_SYMBOLS = (
     "gpx_profile_enable "
     "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_set_potf2 gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_predict_sweep_multi "
-    "gpx_rank_unique_id gpx_rank_init gpx_rank_destroy gpx_rank_last_error gpx_rank_info gpx_rank_device_pci gpx_rank_barrier "
+    "gpx_rank_unique_id gpx_rank_init gpx_rank_destroy gpx_rank_last_error gpx_rank_info gpx_rank_device_pci gpx_rank_collective_calls gpx_rank_barrier "
     "gpx_rank_allreduce_max gpx_rank_bcast gpx_rank_predict_sweep gpx_shard_range"
 ).split()
 
@@ -628,6 +629,10 @@ class Rank:
                     "gpx_rank_info")
         return {"rank": r.value, "nranks": n.value, "inflight": f.value, "transport": "rccl" if t.value else "file",
                 "rccl_version": v.value}
+
+    def collective_calls(self) -> int:
+        """RCCL collective / p2p calls issued by this rank so far (gpx_rank_collective_calls)."""
+        return int(self._lib.gpx_rank_collective_calls(self._rk))
 
     def device_pci(self) -> int:
         """(domain << 16) | (bus << 8) | device of the GPU this rank drives (gpx_rank_device_pci)."""

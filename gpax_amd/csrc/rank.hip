@@ -48,6 +48,12 @@ struct gpx_rank {
   double file_timeout_s = 600.0;
   std::string err;
   int64_t sweeps = 0;
+  // GPX_RANK_FORCE_COLLECTIVES=1 (diagnostic): a communicator of ONE rank still issues every RCCL call of the path —
+  // the flag all-reduce, the payload broadcast, a send / receive group (to itself) — instead of skipping them.  On a
+  // 1-GPU box this is as close as the code gets to its first multi-GPU run: argument validity, datatypes, counts, stream
+  // use and group nesting are all exercised (NCCL_DEBUG=INFO log: profiles/r04/rank1_rccl_nccl_debug.log).
+  bool force_coll = false;
+  int64_t coll_calls = 0; // RCCL collective / p2p calls issued so far
 };
 
 namespace {
@@ -133,7 +139,7 @@ int file_get(gpx_rank* rk, const std::string& name, void* data, size_t bytes) {
 int allreduce_max(gpx_rank* rk, double* v, int n) {
   if (n < 1 || n > 64) return rank_bad_arg(rk, "allreduce_max: 1..64 values");
   const uint64_t seq = rk->seq++;
-  if (rk->nranks == 1) return 0;
+  if (rk->nranks == 1 && !(rk->force_coll && rk->use_rccl)) return 0;
   if (!rk->use_rccl) {
     RANK_TRY(file_put(rk, file_name(rk, "red", seq, rk->rank), v, (size_t)n * sizeof(double)));
     double other[64];
@@ -151,6 +157,7 @@ int allreduce_max(gpx_rank* rk, double* v, int n) {
   std::memcpy(rk->pin_red.p, v, (size_t)n * sizeof(double));
   RANK_HIP(rk, hipMemcpyAsync(rk->red.p, rk->pin_red.p, (size_t)n * sizeof(double), hipMemcpyHostToDevice, rk->cs));
   RANK_NCCL(rk, rk->rccl.AllReduce(rk->red.p, rk->red.p, (size_t)n, ncclDouble, ncclMax, rk->comm, rk->cs));
+  rk->coll_calls += 1;
   RANK_HIP(rk, hipMemcpyAsync(rk->pin_red.p, rk->red.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, rk->cs));
   RANK_HIP(rk, hipStreamSynchronize(rk->cs));
   std::memcpy(v, rk->pin_red.p, (size_t)n * sizeof(double));
@@ -161,7 +168,7 @@ int allreduce_max(gpx_rank* rk, double* v, int n) {
 int bcast_host(gpx_rank* rk, double* buf, int64_t count) {
   if (count < 0 || (count > 0 && !buf)) return rank_bad_arg(rk, "bcast: buffer");
   const uint64_t seq = rk->seq++;
-  if (rk->nranks == 1 || count == 0) return 0;
+  if ((rk->nranks == 1 && !(rk->force_coll && rk->use_rccl)) || count == 0) return 0;
   const size_t bytes = (size_t)count * sizeof(double);
   if (!rk->use_rccl) {
     if (rk->rank == 0) return file_put(rk, file_name(rk, "bc", seq, 0), buf, bytes);
@@ -176,6 +183,7 @@ int bcast_host(gpx_rank* rk, double* buf, int64_t count) {
     RANK_HIP(rk, hipMemcpyAsync(rk->payload.p, rk->pin_in.p, bytes, hipMemcpyHostToDevice, rk->cs));
   }
   RANK_NCCL(rk, rk->rccl.Broadcast(rk->payload.p, rk->payload.p, (size_t)count, ncclDouble, 0, rk->comm, rk->cs));
+  rk->coll_calls += 1;
   if (rk->rank != 0) RANK_HIP(rk, hipMemcpyAsync(rk->pin_in.p, rk->payload.p, bytes, hipMemcpyDeviceToHost, rk->cs));
   RANK_HIP(rk, hipStreamSynchronize(rk->cs));
   if (rk->rank != 0) std::memcpy(buf, rk->pin_in.p, bytes);
@@ -222,6 +230,7 @@ int gpx_rank_init(int device, int rank, int nranks, const char* unique_id, const
   if (!rk->use_rccl) rk->file_dir = file_dir;
   if (rk->use_rccl && !unique_id) return rank_bad_arg(rk, "the rccl transport needs the unique id of rank 0");
   if (const char* e = getenv("GPX_RANK_FILE_TIMEOUT")) rk->file_timeout_s = atof(e) > 0 ? atof(e) : rk->file_timeout_s;
+  if (const char* e = getenv("GPX_RANK_FORCE_COLLECTIVES")) rk->force_coll = (e[0] == '1');
   if (inflight < 1) inflight = 1;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return rank_fail(rk, "no HIP device available");
@@ -278,6 +287,8 @@ int gpx_rank_info(const gpx_rank* rk, int* rank, int* nranks, int* inflight, int
   if (rccl_version) *rccl_version = rk->rccl_version;
   return 0;
 }
+
+int64_t gpx_rank_collective_calls(const gpx_rank* rk) { return rk ? rk->coll_calls : -1; }
 
 int gpx_rank_device_pci(const gpx_rank* rk, int* domain, int* bus, int* dev) {
   if (!rk || rk->device < 0) return -1;
@@ -361,8 +372,10 @@ int gpx_rank_predict_sweep(gpx_rank* rk, int kind, const double* X, int N, int d
   const size_t th_bytes = (size_t)(pl.total - pl.ells) * sizeof(double);
   if (rk->use_rccl) {
     if (root) RANK_HIP(rk, hipMemcpyAsync(rk->payload.p, hp, p_bytes, hipMemcpyHostToDevice, rk->cs));
-    if (G > 1)
+    if (G > 1 || rk->force_coll) {
       RANK_NCCL(rk, rk->rccl.Broadcast(rk->payload.p, rk->payload.p, (size_t)pl.total, ncclDouble, 0, rk->comm, rk->cs));
+      rk->coll_calls += 1;
+    }
     if (!root) // the theta table is host data of the sweep (every context builds its device table from it)
       RANK_HIP(rk, hipMemcpyAsync(hp + pl.ells, rk->payload.d() + pl.ells, th_bytes, hipMemcpyDeviceToHost, rk->cs));
   } else {
@@ -388,7 +401,8 @@ int gpx_rank_predict_sweep(gpx_rank* rk, int kind, const double* X, int N, int d
   }
   const int c_me = hi[(size_t)rk->rank] - lo[(size_t)rk->rank];
   const int64_t my_total = BlockLayout(c_me, n, M).total;
-  const int64_t need = root ? boff[(size_t)G] : my_total;
+  // (forced collectives with one rank: room for a copy of the block behind it — the receive side of the self send)
+  const int64_t need = (root ? boff[(size_t)G] : my_total) + ((rk->force_coll && G == 1) ? my_total : 0);
   RANK_HIP(rk, rk->out.ensure((size_t)(need > 0 ? need : 1) * sizeof(double)));
   // below N ~ 3000 one context's batched sweep already fills a GPU: one context there
   const int per_gpu = (N < 3000) ? 1 : (int)rk->ctxs.size();
@@ -421,16 +435,24 @@ int gpx_rank_predict_sweep(gpx_rank* rk, int kind, const double* X, int N, int d
   // ---- 3. gather on rank 0, one download -----------------------------------------------------------------------------
   RANK_HIP(rk, hipSetDevice(rk->device));
   if (rk->use_rccl) {
-    if (G > 1) {
+    if (G > 1 || (rk->force_coll && my_total > 0)) {
       ncclResult_t first = ncclSuccess; // the group is always closed, whatever a call inside it returns
       RANK_NCCL(rk, rk->rccl.GroupStart());
-      if (root) {
+      if (G == 1) { // forced: the block goes to this rank itself, into the spare room behind it; the results stay where they are
+        first = rk->rccl.Send(rk->out.p, (size_t)my_total, ncclDouble, 0, rk->comm, rk->cs);
+        if (first == ncclSuccess) first = rk->rccl.Recv(rk->out.d() + my_total, (size_t)my_total, ncclDouble, 0, rk->comm, rk->cs);
+        rk->coll_calls += 2;
+      } else if (root) {
         for (int r = 1; r < G && first == ncclSuccess; ++r) {
           const int64_t cnt = boff[(size_t)r + 1] - boff[(size_t)r];
-          if (cnt > 0) first = rk->rccl.Recv(rk->out.d() + boff[(size_t)r], (size_t)cnt, ncclDouble, r, rk->comm, rk->cs);
+          if (cnt > 0) {
+            first = rk->rccl.Recv(rk->out.d() + boff[(size_t)r], (size_t)cnt, ncclDouble, r, rk->comm, rk->cs);
+            rk->coll_calls += 1;
+          }
         }
       } else if (my_total > 0 && c_me > 0) {
         first = rk->rccl.Send(rk->out.p, (size_t)my_total, ncclDouble, 0, rk->comm, rk->cs);
+        rk->coll_calls += 1;
       }
       const ncclResult_t ge = rk->rccl.GroupEnd();
       if (first == ncclSuccess) first = ge;

@@ -232,6 +232,9 @@ int gpx_rank_info(const gpx_rank* rk, int* rank, int* nranks, int* inflight, int
 /* PCI address of the GPU this rank drives: what tells ranks that SHARE a device (a launcher whose LOCAL_RANK exceeds the
  * visible devices, a test box) from ranks on distinct GPUs — bench.py reports the number of distinct devices as n_gpus. */
 int gpx_rank_device_pci(const gpx_rank* rk, int* domain, int* bus, int* dev);
+/* RCCL collective / point-to-point calls this rank has issued so far (all-reduce, broadcast, send, receive).  With
+ * GPX_RANK_FORCE_COLLECTIVES=1 a communicator of ONE rank issues them too (diagnostic: the 1-GPU rehearsal of the path). */
+int64_t gpx_rank_collective_calls(const gpx_rank* rk);
 int gpx_rank_barrier(gpx_rank* rk);
 int gpx_rank_allreduce_max(gpx_rank* rk, double* v, int n);
 int gpx_rank_bcast(gpx_rank* rk, double* buf, int64_t count);

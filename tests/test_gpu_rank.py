@@ -42,6 +42,34 @@ def test_one_rank_over_rccl_equals_the_single_gpu_sweep(engine):
     rk.close()
 
 
+def test_one_rank_rehearses_every_rccl_call_of_the_path(engine, monkeypatch):
+    """ncclCommInitRank with > 1 rank cannot run on this box, but every RCCL CALL of the collective can —
+    GPX_RANK_FORCE_COLLECTIVES=1 makes a one-rank communicator issue the flag all-reduce, the payload broadcast and a
+    send / receive group instead of skipping them: datatypes, counts, streams and group nesting are RCCL-checked, and the
+    results are still the single-GPU sweep's, bit for bit."""
+    from gpax_amd import _lib
+    monkeypatch.setenv("GPX_RANK_FORCE_COLLECTIVES", "1")
+    rk = _lib.Rank(0, 0, 1, unique_id=_lib.rccl_unique_id(), inflight=2)
+    assert rk.collective_calls() == 0
+    rk.barrier()                                   # all-reduce
+    assert np.array_equal(rk.allreduce_max([3.0, -1.0]), [3.0, -1.0])
+    assert np.array_equal(rk.bcast(np.arange(7.0)), np.arange(7.0))
+    n0 = rk.collective_calls()
+    assert n0 == 3
+    X, y, Xn, _ = synthetic_problem(700, 2, 130, seed=0)
+    th = synthetic_theta_samples(9, 2, seed=1)
+    eps = np.random.default_rng(2).standard_normal((9, 2, 130))
+    got = rk.predict_sweep(1, 700, 2, 9, 130, 2, False, 1e-6, X=X, ells=th["k_length"], scales=th["k_scale"],
+                           noises=th["noise"], yres=y, Xnew=Xn, eps=eps, want_var=True)
+    # per sweep: argument-agreement all-reduce, broadcast, failure-flag all-reduce, send + receive
+    assert rk.collective_calls() - n0 == 5
+    engine.set_train(X)
+    want = engine.predict_sweep(1, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps, want_var=True)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+    rk.close()
+
+
 @pytest.mark.parametrize("ranks", [2, 3])
 def test_ranks_sharing_the_gpu_over_the_file_transport(ranks):
     from gpax_amd import launch

@@ -1,0 +1,32 @@
+"""The Gram build alone (gram_kernel<KIND, D>: the one HBM-bound kernel of the path, gpax/kernels/kernels.py:28-91) at the
+bench size: HIP-event time of the stand-alone stage, bytes the lower 32 x 512 tiles actually store and the 8 N^2 the
+symmetric build may claim, against the 8 TB/s HBM3E figure.  Run it plainly for the JSON line, or under
+`rocprofv3 --kernel-trace --pmc WRITE_SIZE` / `FETCH_SIZE` for the counters (tools/profile_round.sh)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.getcwd())
+from bench import gram_bytes_written  # noqa: E402
+from bench_inputs import synthetic_problem  # noqa: E402
+from gpax_amd import _lib  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+kind = 1  # Matern: C3
+X, y, Xn, p = synthetic_problem(N, 2, 8, seed=0)
+e = _lib.Engine(0)
+e.set_train(X)
+e.factor(kind, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+e.time_stage(_lib.STAGE_GRAM, 2)
+ms = [e.time_stage(_lib.STAGE_GRAM, 1) for _ in range(9)]
+t = float(np.median(ms)) * 1e-3
+Np = (N + 1 + 127) // 128 * 128
+written = gram_bytes_written(N, Np)
+print(json.dumps({"kernel": "gpx::gram_kernel<1, 2> (Matern-5/2, d = 2), lower 32 x 512 tiles", "N": N, "median_ms": t * 1e3,
+                  "runs_ms": ms, "bytes_written": written, "written_GBps": written / t / 1e9,
+                  "frac_of_8TBps_on_written_bytes": written / t / 8e12, "alg_bytes_8N2": 8.0 * N * N,
+                  "alg_GBps": 8.0 * N * N / t / 1e9, "bytes_read": 8.0 * 2 * N * 2,
+                  "note": "the upper half is never written: 'alg' credits the full matrix to the symmetric build as SURVEY 8d "
+                          "allows; the roofline figure to read is written_GBps"}))

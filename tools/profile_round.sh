@@ -1,13 +1,13 @@
 #!/bin/bash
 # Regenerate the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_round.sh r03
+#   bash tools/profile_round.sh r04
 #   kernel-trace + stats of the default bench command, separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*), the C4
 #   sweep (S = 1000) with its own kernel trace, and the round's bench line; summarised on the box (the rocpd sqlite
 #   databases stay in /tmp; only .md / .json summaries come back under gpurun_out/prof — copy them to profiles/<round>).
 # NOTE (round 1): a single pass with five TCC_* derived counters on `bench.py --steps 1` did not finish within 10
 # minutes on this pool — keep L2 counters out of this script.  --pmc passes carry --kernel-trace only (gpurun refuses
 # --pmc together with the hip / hsa / memory trace domains).
-RND=${1:-r03}
+RND=${1:-r04}
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/prof
@@ -61,6 +61,27 @@ python tools/c5_bench.py > $O/c5_sparse.json 2> $O/c5_sparse.err
 # ranks sharing the GPU over the file transport (control flow only: the two ranks halve the GPU between them)
 python bench.py --force-rank-path --steps 12 --warmup 3 > $O/bench_rank1_rccl.json 2> $O/bench_rank1_rccl.err
 python bench.py --gpus 2 --share-gpu --steps 8 --warmup 2 --c4-S 200 > $O/bench_2ranks_shared_gpu.json 2> $O/bench_2ranks_shared_gpu.err
+# round 4: the diagonal-block kernel inside the pipeline — per dispatch wait / execution from the kernel trace (default
+# kernel and the round-3 one), the in-kernel phase trace of the default kernel (trace build of the library), the Gram
+# build alone with its HBM counters, the fit step at the sizes gpax is mostly used at, and the RCCL calls one rank issues
+for m in slim chain; do
+  rm -rf /tmp/prof_pw_$m
+  GPX_POTF2=$m timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_pw_$m -- $B --steps 6 --warmup 1 --inflight 1 > /dev/null 2> $O/pw_$m.err
+  echo "## GPX_POTF2=$m: rocprofv3 --kernel-trace -- $B --steps 6 --warmup 1 --inflight 1" >> $O/potf2_wait.md
+  python tools/potf2_wait.py "$(find /tmp/prof_pw_$m -name '*.db' | head -1)" $O/potf2_wait.md > /dev/null 2>> $O/pw_$m.err
+done
+if [ -f gpax_amd/lib/libgpx_trace.so ]; then
+  GPX_LIB=gpax_amd/lib/libgpx_trace.so timeout 300 python tools/potf2_trace.py > $O/potf2_phase_trace.json 2> $O/potf2_phase_trace.err
+fi
+python tools/gram_bench.py > $O/gram.json 2> $O/gram.err
+run gram_write "python tools/gram_bench.py" --kernel-trace --pmc WRITE_SIZE
+run gram_fetch "python tools/gram_bench.py" --kernel-trace --pmc FETCH_SIZE
+for N in 128 512 2048; do
+  rm -rf /tmp/prof_sn$N
+  timeout 200 rocprofv3 --kernel-trace -d /tmp/prof_sn$N -- python tools/smalln_timeline.py run $N > $O/smalln_$N.txt 2>&1
+  python tools/smalln_timeline.py show "$(find /tmp/prof_sn$N -name '*.db' | head -1)" $O/smalln_timeline_$N.md > /dev/null 2>> $O/smalln_$N.txt
+done
+NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL,P2P python bench.py --force-rank-path --steps 4 --warmup 1 --c4-S 24 --no-node-record > $O/rank1_rccl_nccl_debug.json 2> $O/rank1_rccl_nccl_debug.log
 python bench.py > $O/bench_$RND.json 2> $O/bench_$RND.err
 cut -c1-400 $O/bench_$RND.json
 ls -la $O
