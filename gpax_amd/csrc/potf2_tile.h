@@ -52,8 +52,128 @@ __device__ __forceinline__ pd4_t mma_nn(pd4_t acc, const double* TA, const doubl
 }
 
 // One wave: factor the 16x16 tile D (lower read) in place -> L (zeros above), inverse -> Dinv.
-// Lane (r = lane & 15, q = lane >> 4) owns S[r][4q .. 4q+3]; fused update rule as potf2_block.
+// Lane (r = lane & 15, q = lane >> 4) owns S[r][4q .. 4q+3]; fused update rule as the column kernel of round 1:
+//     S[r][i] -= S[r][j] * S[i][j] / d_j      for i > j and (r >= i  or  r <= j)
+// (the strict upper triangle holds the forward-substitution residual of L X = I, transposed).
+//
+// Round 4: WHICH lanes take part in an update is a function of (j, t) and the lane number only — a compile-time 64-bit
+// lane mask.  The updates are therefore issued as ONE v_fma_f64 each under `s_mov_b64 exec, <constant>` (scalar unit)
+// instead of an unconditional fma + two v_cndmask_b32 per value behind lane masks that the compiler computed up front,
+// kept in ~100 SGPRs, spilled to VGPR lanes and fetched back with v_readlane inside the loop: 35 vector-ALU
+// instructions per column step became 16.  That matters beyond the instruction count: on gfx950 an fp64 MFMA occupies
+// the vector ALU of its SIMD for 64 cycles, so next to two resident trailing-update waves (where this wave runs in the
+// GEMM-bound part of a factorisation) EVERY vector instruction of this wave waits for an MFMA slot — the in-pipeline
+// time of the diagonal-block kernel is proportional to the vector instructions on its chain, not to their latency
+// (profiles/r04/potf2_phase_trace.json: diag16 2.4 us per tile alone, 10 us beside the GEMM).
+// Same operands, same operations, same order per element: bit-identical to the round-2/3 form.
+__host__ __device__ constexpr unsigned long long diag16_mask_on(int j, int t) {
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l) {
+    const int r = l & 15, i = 4 * (l >> 4) + t;
+    if (i > j && (r >= i || r <= j)) m |= 1ull << l;
+  }
+  return m;
+}
+__host__ __device__ constexpr unsigned long long diag16_mask_row(int j) { // lanes with r == j
+  return (1ull << j) | (1ull << (16 + j)) | (1ull << (32 + j)) | (1ull << (48 + j));
+}
+__host__ __device__ constexpr unsigned long long diag16_mask_group(int q) { // lanes with lane >> 4 == q
+  return 0xffffull << (16 * q);
+}
+// The mask is written into EXEC as two 32-bit IMMEDIATES of the instruction stream: handed over in SGPRs, the compiler
+// hoists all ~100 of them out of the panel loop, spills them to VGPR lanes and fetches them back with v_readlane — a
+// vector instruction again.
+// e = fma(-cr, cc, e) on the lanes of the mask M, the others untouched
+template <unsigned long long M>
+__device__ __forceinline__ void masked_fnma(double& e, double cr, double cc) {
+  asm volatile("s_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, %4\n\tv_fma_f64 %0, -%1, %2, %0\n\ts_mov_b64 exec, -1"
+               : "+v"(e)
+               : "v"(cr), "v"(cc), "i"((int)(unsigned)(M & 0xffffffffull)), "i"((int)(unsigned)(M >> 32)));
+}
+// dst = src on the lanes of M
+template <unsigned long long M>
+__device__ __forceinline__ void masked_mov(double& dst, double src) {
+  asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b64 %0, %1\n\ts_mov_b64 exec, -1"
+               : "+v"(dst)
+               : "v"(src), "i"((int)(unsigned)(M & 0xffffffffull)), "i"((int)(unsigned)(M >> 32)));
+}
+template <unsigned long long M>
+__device__ __forceinline__ void masked_one(double& dst) {
+  asm volatile("s_mov_b32 exec_lo, %1\n\ts_mov_b32 exec_hi, %2\n\tv_mov_b64 %0, 1.0\n\ts_mov_b64 exec, -1"
+               : "+v"(dst)
+               : "i"((int)(unsigned)(M & 0xffffffffull)), "i"((int)(unsigned)(M >> 32)));
+}
+
+template <int J>
+__device__ __forceinline__ void diag16_step(double (&e)[4], double (&mypiv)[4], double* col, int lane, int& bad, int base) {
+  const int r = lane & 15, q = lane >> 4;
+  double* cb = col + (J & 1) * 16;
+  if (q == (J >> 2)) cb[r] = e[J & 3];
+  // one wave: the LDS queue is in order, so the reads below see the write; the asm only stops the
+  // compiler from caching / reordering the accesses (no volatile: the six reads share one wait)
+  asm volatile("" ::: "memory");
+  const double dj = cb[J];
+  double cr = cb[r];
+  const double c0 = cb[4 * q + 0], c1 = cb[4 * q + 1], c2 = cb[4 * q + 2], c3 = cb[4 * q + 3];
+  asm volatile("" ::: "memory");
+  constexpr unsigned long long mrow = diag16_mask_row(J), mgrp = diag16_mask_group(J >> 2);
+  masked_one<mrow>(cr); // row r == j of the X half
+  double ip2 = __builtin_amdgcn_rcp(dj);
+  ip2 = fma(fma(-dj, ip2, 1.0), ip2, ip2);
+  ip2 = fma(fma(-dj, ip2, 1.0), ip2, ip2);
+  masked_mov<mgrp>(mypiv[J & 3], dj);
+  if (!(dj > 0.0) && bad == 0) bad = base + J + 1;
+  // (the masks must be constant expressions: evaluated at run time they are 64-iteration scalar loops)
+  constexpr unsigned long long m0 = diag16_mask_on(J, 0), m1 = diag16_mask_on(J, 1), m2 = diag16_mask_on(J, 2),
+                               m3 = diag16_mask_on(J, 3);
+  if constexpr (m0 != 0) masked_fnma<m0>(e[0], cr, c0 * ip2);
+  if constexpr (m1 != 0) masked_fnma<m1>(e[1], cr, c1 * ip2);
+  if constexpr (m2 != 0) masked_fnma<m2>(e[2], cr, c2 * ip2);
+  if constexpr (m3 != 0) masked_fnma<m3>(e[3], cr, c3 * ip2);
+}
+
+template <int J>
+__device__ __forceinline__ void diag16_steps(double (&e)[4], double (&mypiv)[4], double* col, int lane, int& bad, int base) {
+  diag16_step<J>(e, mypiv, col, lane, bad, base);
+  if constexpr (J < 15) diag16_steps<J + 1>(e, mypiv, col, lane, bad, base);
+}
+
 __device__ __forceinline__ void diag16(double* D, double* Dinv, double* col /* 2 x 16 */, int lane, int& bad,
+                                       int base) {
+  const int r = lane & 15, q = lane >> 4;
+  double e[4], mypiv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = 4 * q + t;
+    e[t] = (r >= i) ? D[r * TLD + i] : 0.0;
+    mypiv[t] = 1.0;
+  }
+  diag16_steps<0>(e, mypiv, col, lane, bad, base);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = 4 * q + t;
+    const double piv = sqrt(mypiv[t]);
+    const double ip = 1.0 / piv;
+    double lval, xval;
+    if (r > i) {
+      lval = e[t] * ip;
+      xval = 0.0;
+    } else if (r == i) {
+      lval = piv;
+      xval = ip;
+    } else {
+      lval = 0.0;
+      xval = e[t] * ip; // = Linv[i][r]
+    }
+    D[r * TLD + i] = lval;
+    Dinv[i * TLD + r] = xval;
+  }
+}
+
+// The round-2/3 form of diag16 (an unconditional fma + selects behind lane masks the compiler keeps in SGPRs): what
+// potf2_tile_kernel — the REFERENCE of the bit-identity tests — keeps running, so that the tests compare the round-4
+// form above (slim and chain kernels) against independently generated code, operation for operation.
+__device__ __forceinline__ void diag16_select(double* D, double* Dinv, double* col /* 2 x 16 */, int lane, int& bad,
                                        int base) {
   const int r = lane & 15, q = lane >> 4;
   double e[4], mypiv[4];
@@ -180,7 +300,7 @@ __device__ __forceinline__ void potf2_tile_body(double* A, int64_t lda, double* 
     GPX_TRACE(1 + 4 * p);
     // ---- B: diagonal tile -----------------------------------------------------------------------
     if (w == 0) {
-      diag16(Pbuf + p * TSZ, Dinv, col, lane, bad, p * TS);
+      diag16_select(Pbuf + p * TSZ, Dinv, col, lane, bad, p * TS);
       const int r = lane & 15, q = lane >> 4;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {

@@ -187,6 +187,10 @@ constexpr int SC_NV = 2 * GPX_MAX_DIM + 4;
 // Per block (64 rows x 64 cols) partials: [0..d) d/d ell, [d] d/d scale; the Xu-gradient is
 // accumulated per column in gxu_part[blockRow][col][m] (reduced over block rows afterwards in
 // fixed order => deterministic).
+// KIND / D > 0: kernel and input dimension as compile-time constants (the arrays below live in registers and the kernel
+// branch folds: C5's 16 316 x 2039 contraction 446 -> see profiles/r04/c5_sparse.json); D = 0: any d <= GPX_MAX_DIM
+// at run time.  Same operations in the same order either way.
+template <int KIND, int D>
 __global__ __launch_bounds__(256) void sgp_contract_kernel(KernelParams kp, const double* __restrict__ Pts,
                                                            int rows, const double* __restrict__ Xu, int M,
                                                            const double* __restrict__ G, int64_t ldg,
@@ -194,50 +198,78 @@ __global__ __launch_bounds__(256) void sgp_contract_kernel(KernelParams kp, cons
                                                            const double* __restrict__ mvec,
                                                            double* __restrict__ part,
                                                            double* __restrict__ gxu_part) {
+  constexpr int DM = D > 0 ? D : GPX_MAX_DIM;
   __shared__ double red[16];
-  __shared__ double colacc[4][64][GPX_MAX_DIM];
-  const int d = kp.d;
+  __shared__ double colacc[4][64][DM];
+  const int d = D > 0 ? D : kp.d;
+  const int kind = KIND >= 0 ? KIND : kp.kind;
   const int bj = blockIdx.x, bi = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = bj * 64 + lane; // column = inducing point index
-  double acc[GPX_MAX_DIM + 2];
-  double gx[GPX_MAX_DIM];
-  for (int c = 0; c < d + 2; ++c) acc[c] = 0.0;
-  for (int c = 0; c < d; ++c) gx[c] = 0.0;
+  double acc[DM + 2];
+  double gx[DM];
+#pragma unroll
+  for (int c = 0; c < DM + 2; ++c) acc[c] = 0.0;
+#pragma unroll
+  for (int c = 0; c < DM; ++c) gx[c] = 0.0;
   if (j < M) {
-    double xu[GPX_MAX_DIM];
-    for (int c = 0; c < d; ++c) xu[c] = Xu[(int64_t)j * d + c];
+    double xu[DM];
+#pragma unroll
+    for (int c = 0; c < DM; ++c) xu[c] = c < d ? Xu[(int64_t)j * d + c] : 0.0;
     const double mj = mvec[j];
+#pragma unroll 4
     for (int t = 0; t < 16; ++t) {
       const int i = bi * 64 + wave * 16 + t;
       if (i >= rows) break;
       const double g = fma(rcoef[i], mj, G[(int64_t)i * ldg + j]);
-      double r2 = 0.0, diff[GPX_MAX_DIM];
-      for (int c = 0; c < d; ++c) {
+      double r2 = 0.0, diff[DM];
+#pragma unroll
+      for (int c = 0; c < DM; ++c) {
+        if (c >= d) break;
         diff[c] = (xu[c] - Pts[(int64_t)i * d + c]) * kp.inv_ell[c]; // (xu - p)/ell
         r2 = fma(diff[c], diff[c], r2);
       }
       double kv, dk;
-      kval_dk(kp.kind, r2, kp.scale, kv, dk);
-      for (int c = 0; c < d; ++c) {
+      kval_dk(kind, r2, kp.scale, kv, dk);
+#pragma unroll
+      for (int c = 0; c < DM; ++c) {
+        if (c >= d) break;
         acc[c] += g * dk * (-2.0 * diff[c] * diff[c] * kp.inv_ell[c]);
         gx[c] += g * dk * (2.0 * diff[c] * kp.inv_ell[c]); // d k / d xu_c
       }
       acc[d] += g * kv / kp.scale;
     }
   }
-  for (int c = 0; c < d; ++c) colacc[wave][lane][c] = gx[c];
+#pragma unroll
+  for (int c = 0; c < DM; ++c)
+    if (c < d) colacc[wave][lane][c] = gx[c];
   __syncthreads();
   if (wave == 0 && j < M) {
-    for (int c = 0; c < d; ++c) {
+#pragma unroll
+    for (int c = 0; c < DM; ++c) {
+      if (c >= d) break;
       const double s = colacc[0][lane][c] + colacc[1][lane][c] + colacc[2][lane][c] + colacc[3][lane][c];
       gxu_part[((int64_t)bi * M + j) * GPX_MAX_DIM + c] = s;
     }
   }
   const int64_t bid = (int64_t)bi * gridDim.x + bj;
-  for (int c = 0; c < d + 2; ++c) {
+#pragma unroll
+  for (int c = 0; c < DM + 2; ++c) {
+    if (c >= d + 2) break;
     const double s = bsum(acc[c], red);
     if (threadIdx.x == 0) part[bid * SC_NV + c] = s;
+  }
+}
+
+typedef void (*sgp_contract_fn)(KernelParams, const double*, int, const double*, int, const double*, int64_t, const double*,
+                                const double*, double*, double*);
+static sgp_contract_fn pick_contract(const KernelParams& kp) {
+  const bool rbf = kp.kind == GPX_KERNEL_RBF;
+  switch (kp.d) {
+    case 1: return rbf ? sgp_contract_kernel<GPX_KERNEL_RBF, 1> : sgp_contract_kernel<GPX_KERNEL_MATERN52, 1>;
+    case 2: return rbf ? sgp_contract_kernel<GPX_KERNEL_RBF, 2> : sgp_contract_kernel<GPX_KERNEL_MATERN52, 2>;
+    case 3: return rbf ? sgp_contract_kernel<GPX_KERNEL_RBF, 3> : sgp_contract_kernel<GPX_KERNEL_MATERN52, 3>;
+    default: return sgp_contract_kernel<-1, 0>;
   }
 }
 
@@ -669,13 +701,14 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
   double* out_uf = sc + 32 + SC_NV;
   {
     dim3 g1(nbj, nbi_u);
-    sgp_contract_kernel<<<g1, 256, 0, ctx->s>>>(s->kp, s->Xu.d(), M, s->Xu.d(), M, s->B3.d(), s->ldu, s->rcoef_u.d(),
-                                                s->mvec.d(), s->cpart.d(), s->gxu_part.d());
+    const sgp_contract_fn contract = pick_contract(s->kp);
+    contract<<<g1, 256, 0, ctx->s>>>(s->kp, s->Xu.d(), M, s->Xu.d(), M, s->B3.d(), s->ldu, s->rcoef_u.d(),
+                                     s->mvec.d(), s->cpart.d(), s->gxu_part.d());
     sgp_reduce_kernel<<<64, 256, 0, ctx->s>>>(s->cpart.d(), nbj * nbi_u, d + 1, out_uu, s->gxu_part.d(), nbi_u, M, d,
                                               2.0, 0, s->gXu.d());
     dim3 g2(nbj, nbi_f);
-    sgp_contract_kernel<<<g2, 256, 0, ctx->s>>>(s->kp, ctx->X.d(), N, s->Xu.d(), M, s->T1.d(), s->ldw,
-                                                s->rcoef_f.d(), s->mvec.d(), s->cpart.d(), s->gxu_part.d());
+    contract<<<g2, 256, 0, ctx->s>>>(s->kp, ctx->X.d(), N, s->Xu.d(), M, s->T1.d(), s->ldw,
+                                     s->rcoef_f.d(), s->mvec.d(), s->cpart.d(), s->gxu_part.d());
     sgp_reduce_kernel<<<64, 256, 0, ctx->s>>>(s->cpart.d(), nbj * nbi_f, d + 1, out_uf, s->gxu_part.d(), nbi_f, M, d,
                                               1.0, 1, s->gXu.d());
     GPX_HIP(ctx, hipGetLastError());
