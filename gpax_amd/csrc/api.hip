@@ -168,7 +168,12 @@ int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
                                0, 0, K + (int64_t)Np * ctx->ldk, ctx->ldk, B, bp.k_bs, bp.th, 0, ts_new(ctx)));
   }
   GPX_HIP(ctx, hipMemsetAsync(bp.info_train, 0, (size_t)B * sizeof(int), ctx->stream));
-  GPX_TRY(potrf_lower(ctx, K, ctx->ldk, Np, extra, ctx->Linv.d(), bp.info_train, B, bp.k_bs, bp.linv_bs));
+  // N a multiple of 128 (every BASELINE size): the augmentation row opens a tile of its own (rows N .. N + 127 = [y | 1e300],
+  // identity padding).  Nothing in it needs factoring — what the path reads is w = y L^-T in row N — so that tile rides
+  // along below the square part like the k_pX rows instead of costing a diagonal-block step of the serial chain
+  // (potf2 + TRSM + update: 5 -> 4 steps at N = 512).  Same operations on row N either way: bit-identical.
+  const int Nf = ((N + TILE - 1) / TILE) * TILE; // order of the part that is factored
+  GPX_TRY(potrf_lower(ctx, K, ctx->ldk, Nf, extra + (Np - Nf) / TILE, ctx->Linv.d(), bp.info_train, B, bp.k_bs, bp.linv_bs));
   if (want_lml) GPX_TRY(launch_lml_terms(ctx, K, ctx->ldk, N, bp.scal + SC_QUAD, B, bp.k_bs, bp.scal_bs));
   ctx->factored = (B == 1);
   ctx->have_kinv = false;
