@@ -159,7 +159,7 @@ int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
     GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->X.d(), N, N, ctx->X.d(), N, Np,
                                ctx->noise + ctx->jitter, 1, 1, K, ctx->ldk, B, bp.k_bs, bp.th, 1, ts_train(ctx),
                                ctx->has_diag ? ctx->diagv.d() : nullptr));
-    GPX_TRY(launch_augment(ctx, K, ctx->ldk, N, Np, bp.yres, B, bp.k_bs, bp.y_bs, bp.y_mod));
+    GPX_TRY(launch_augment(ctx, K, ctx->ldk, N, Np, bp.yres, B, bp.k_bs, bp.y_bs, bp.y_mod, bp.info_train));
   }
   RoctxRange r_potrf(fused ? "gpx:potrf+trsm(k_pX ride-along)" : "gpx:potrf");
   if (fused) {
@@ -167,7 +167,7 @@ int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
     GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->Xnew.d(), ctx->M, ctx->Mp, ctx->X.d(), N, Np, 0.0,
                                0, 0, K + (int64_t)Np * ctx->ldk, ctx->ldk, B, bp.k_bs, bp.th, 0, ts_new(ctx)));
   }
-  GPX_HIP(ctx, hipMemsetAsync(bp.info_train, 0, (size_t)B * sizeof(int), ctx->stream));
+  // (the pivot report bp.info_train was cleared by the augmentation kernel)
   // N a multiple of 128 (every BASELINE size): the augmentation row opens a tile of its own (rows N .. N + 127 = [y | 1e300],
   // identity padding).  Nothing in it needs factoring — what the path reads is w = y L^-T in row N — so that tile rides
   // along below the square part like the k_pX rows instead of costing a diagonal-block step of the serial chain

@@ -317,7 +317,7 @@ int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, i
                        const ThetaDev* th = nullptr, int diag_sel = 0, TaskStride ts = TaskStride(),
                        const double* diag_vec = nullptr);
 int launch_augment(gpx_ctx* ctx, double* dK, int64_t ld, int N, int Np, const double* dy,
-                   int batch = 1, int64_t k_bs = 0, int64_t y_bs = 0, int y_mod = 0);
+                   int batch = 1, int64_t k_bs = 0, int64_t y_bs = 0, int y_mod = 0, int* dInfo = nullptr);
 int launch_pad_identity(gpx_ctx* ctx, double* dA, int64_t ld, int n, int np);
 
 // gemm_f64.hip

@@ -157,6 +157,12 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
   // fewer than `tail_tiles` tile rows behind it): one outer block per update.  Every combination gives the same bits.
   const int tail_tiles = ctx->tail_tiles;
   const int nouter = (nblk + OT - 1) / OT;
+  if (nouter == 1) {
+    // one outer block (N <= 512): nothing to look ahead over — the chain runs on the main stream, without the two
+    // cross-stream event waits of the look-ahead (~10 - 18 us each at this size)
+    ctx->s = ctx->stream;
+    return panel_block(ctx, dA, lda, nblk, extra_tiles, 0, nblk, dLinv, dInfo, bs);
+  }
   GPX_TRY(ensure_events(ctx, nouter));
   hipStream_t smain = ctx->stream, span = ctx->pstream;
   auto ob_of = [&](int k) { return k < nouter ? k * OT : nblk; }; // first tile column of outer block k (clamped)
