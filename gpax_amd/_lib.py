@@ -780,19 +780,47 @@ def concurrent_sweep(engines: list, X, kind: int, ells, scales, noises, yres, Xn
         return engines[0].predict_sweep(kind, ells, scales, noises, yres, Xnew, noiseless, jitter, eps,
                                         m_slice=m_slice)
     yres = np.asarray(yres, dtype=np.float64)
-    bounds = [(S * i) // n for i in range(n + 1)]
-    out: list = [None] * n
+    scales, noises = np.asarray(scales), np.asarray(noises)
+    eps_a = None if eps is None else np.asarray(eps)
+    # Guided self-scheduling: every context takes the next chunk of samples when it has finished its own — half of its
+    # fair share of what is left, never less than one launch batch B (the library reports the B it chose after the
+    # first chunk) — so all contexts stop within one batch of each other.  (Fixed blocks of S / n, rounds 1 - 3: the
+    # context the hardware favoured finished early and the last samples ran with fewer of them in flight.)  Results do
+    # not depend on the split: every sample's arithmetic is independent of its batch.
+    lock = threading.Lock()
+    state = {"next": 0, "min": 8}
+    pieces: list = []
     err: list = []
+
+    def take():
+        with lock:
+            lo = state["next"]
+            if lo >= S:
+                return None
+            left = S - lo
+            c = max(state["min"], -(-left // (2 * n)))
+            c = -(-c // state["min"]) * state["min"]  # whole launch batches
+            hi = min(S, lo + c)
+            state["next"] = hi
+            return lo, hi
 
     def work(i):
         try:
-            lo, hi = bounds[i], bounds[i + 1]
             e = engines[i]
             e.set_train(X)
-            yr = yres if yres.ndim == 1 else yres[lo:hi]
-            out[i] = e.predict_sweep(kind, ells[lo:hi], np.asarray(scales)[lo:hi], np.asarray(noises)[lo:hi], yr, Xnew,
-                                     noiseless, jitter, None if eps is None else np.asarray(eps)[lo:hi],
-                                     m_slice=m_slice)
+            while not err:
+                job = take()
+                if job is None:
+                    return
+                lo, hi = job
+                yr = yres if yres.ndim == 1 else yres[lo:hi]
+                res = e.predict_sweep(kind, ells[lo:hi], scales[lo:hi], noises[lo:hi], yr, Xnew, noiseless, jitter,
+                                      None if eps_a is None else eps_a[lo:hi], m_slice=m_slice)
+                b = int(e.sweep_stats()[2])
+                with lock:
+                    pieces.append((lo, res))
+                    if b > state["min"]:
+                        state["min"] = b
         except Exception as ex:  # surface worker failures in the caller
             err.append(ex)
 
@@ -803,5 +831,6 @@ def concurrent_sweep(engines: list, X, kind: int, ells, scales, noises, yres, Xn
         t.join()
     if err:
         raise err[0]
+    out = [res for _, res in sorted(pieces, key=lambda p: p[0])]
     return (np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out]),
             np.concatenate([o[2] for o in out]))

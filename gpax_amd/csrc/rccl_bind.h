@@ -143,6 +143,8 @@ inline void scatter_block(const double* blk, int c_r, int g0, int N, int M, int 
 
 } // namespace gpx
 
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -156,36 +158,70 @@ struct ShardJob {
   const double *ells, *scales, *noises; // HOST theta tables of all S samples (indexed by global sample)
 };
 
-// The block of c_r samples starting at global sample g_lo on ONE GPU: split again over (up to) per_gpu of the contexts
-// in flight there, one host thread each (ctypes / the caller holds no lock; every context has its own streams).
-// `payload` / `blk`: the device copies of the inputs and of this GPU's result block.  rc / cov-block slots: per_gpu each.
+// The block of c_r samples starting at global sample g_lo on ONE GPU, worked off by (up to) per_gpu of the contexts in
+// flight there, one host thread each (ctypes / the caller holds no lock; every context has its own streams).  The
+// contexts take CHUNKS from a shared cursor — half of a context's fair share of what is left, never less than one
+// launch batch B (what the library reports after a context's first chunk) — so they all stop within one batch of each
+// other.  (Fixed sub-blocks of c_r / per_gpu, rounds 1 - 3: the context the hardware favoured finished early and the
+// rest of the block ran with fewer samples in flight; bench.py saw +-4 % from that alone.)  Results do not depend on
+// the split.  `payload` / `blk`: the device copies of the inputs and of this GPU's result block.  rc / cov-block
+// slots: per_gpu each.
+struct ShardCursor {
+  std::mutex mu;
+  int next = 0, total = 0, parts = 1, min_chunk = 8;
+  bool take(int* lo, int* hi) {
+    std::lock_guard<std::mutex> g(mu);
+    if (next >= total) return false;
+    const int left = total - next;
+    int c = (left + 2 * parts - 1) / (2 * parts);
+    if (c < min_chunk) c = min_chunk;
+    c = (c + min_chunk - 1) / min_chunk * min_chunk; // whole launch batches
+    *lo = next;
+    *hi = next + c < total ? next + c : total;
+    next = *hi;
+    return true;
+  }
+  void saw_batch(int b) {
+    std::lock_guard<std::mutex> g(mu);
+    if (b > min_chunk) min_chunk = b;
+  }
+};
+
 inline void spawn_shard_sweep(std::vector<std::thread>& threads, const std::vector<gpx_ctx*>& ctxs, int per_gpu, int g_lo,
                               int c_r, const ShardJob& jb, const PayloadLayout& pl, const double* payload, double* blk,
                               int* rc_slots, int* cb_slots) {
   if (c_r <= 0) return;
   const BlockLayout bl(c_r, jb.n, jb.M);
   const int parts = per_gpu < c_r ? per_gpu : c_r;
+  auto cur = std::make_shared<ShardCursor>();
+  cur->total = c_r;
+  cur->parts = parts;
   for (int c = 0; c < parts; ++c) {
-    int slo, shi;
-    shard_range(c_r, c, parts, &slo, &shi);
     gpx_ctx* ctx = ctxs[(size_t)c];
-    const int g0 = g_lo + slo; // first global sample of this context
-    const int cnt = shi - slo;
     int* rc_slot = rc_slots + c;
     int* cb_slot = cb_slots + c;
     const ShardJob j = jb;
     const PayloadLayout p = pl;
+    *rc_slot = 0;
+    *cb_slot = j.M;
     threads.emplace_back([=]() {
-      int rc = sweep_device_io(
-          ctx, j.kind, cnt, j.ells + (int64_t)g0 * j.ne, j.scales + g0, j.noises + g0, payload + p.X, j.N, j.d,
-          payload + p.y + (j.yres_rows == 1 ? 0 : (int64_t)g0 * j.N), j.yres_rows == 1 ? 1 : cnt, payload + p.Xn, j.M,
-          j.noiseless, j.jitter, j.n > 0 ? payload + p.eps + (int64_t)g0 * j.n * j.M : nullptr, j.n,
-          blk + bl.means + (int64_t)slo * j.M, j.n > 0 ? blk + bl.draws + (int64_t)slo * j.n * j.M : nullptr,
-          reinterpret_cast<int*>(blk + bl.infos) + 2 * slo, j.want_vars ? blk + bl.vars + (int64_t)slo * j.M : nullptr,
-          j.m_slice);
-      if (rc == 0) rc = gpx_synchronize(ctx);
+      int slo = 0, shi = 0, rc = 0;
+      while (rc == 0 && cur->take(&slo, &shi)) {
+        const int g0 = g_lo + slo; // first global sample of this chunk
+        const int cnt = shi - slo;
+        rc = sweep_device_io(
+            ctx, j.kind, cnt, j.ells + (int64_t)g0 * j.ne, j.scales + g0, j.noises + g0, payload + p.X, j.N, j.d,
+            payload + p.y + (j.yres_rows == 1 ? 0 : (int64_t)g0 * j.N), j.yres_rows == 1 ? 1 : cnt, payload + p.Xn, j.M,
+            j.noiseless, j.jitter, j.n > 0 ? payload + p.eps + (int64_t)g0 * j.n * j.M : nullptr, j.n,
+            blk + bl.means + (int64_t)slo * j.M, j.n > 0 ? blk + bl.draws + (int64_t)slo * j.n * j.M : nullptr,
+            reinterpret_cast<int*>(blk + bl.infos) + 2 * slo, j.want_vars ? blk + bl.vars + (int64_t)slo * j.M : nullptr,
+            j.m_slice);
+        if (rc == 0) rc = gpx_synchronize(ctx);
+        int last = 0;
+        if (rc == 0 && gpx_sweep_stats(ctx, nullptr, nullptr, &last) == 0) cur->saw_batch(last);
+        *cb_slot = ctx_cov_block(ctx);
+      }
       *rc_slot = rc;
-      *cb_slot = ctx_cov_block(ctx);
     });
   }
 }
