@@ -222,7 +222,7 @@ def potf2_record(eng, a):
         rec["potf2_ms_per_predict"][mode] = ms
         eng.time_stage(_lib.STAGE_POTRF, 1)
         rec["potrf_ms"][mode] = float(np.median([eng.time_stage(_lib.STAGE_POTRF, 1) for _ in range(3)]))
-    rec["note"] = ("slim (csrc/potf2_slim.h): 88 VGPRs / 28 KB LDS, placed at once beside two resident trailing-update "
+    rec["note"] = ("slim (csrc/potf2_slim.h): 94 VGPRs / 28 KB LDS, placed at once beside two resident trailing-update "
                    "workgroups; chain (round 3): 344 VGPRs / 46 KB, waits for a drained CU; tile (round 2): the tests' "
                    "reference.  in_pipeline = HIP events around each launch on its stream, one theta in flight")
     return rec

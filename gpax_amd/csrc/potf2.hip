@@ -6,7 +6,7 @@
 // A non-positive pivot makes the factor NaN from there on (propagates, like JAX) and sets *info.
 //
 // Three kernels, one arithmetic (bit-identical outputs, tests/test_gpu_edges.py):
-//   potf2_slim_kernel  (potf2_slim.h, round 4, default)  88 VGPRs, 28 KB LDS: placed at once beside two resident
+//   potf2_slim_kernel  (potf2_slim.h, round 4, default)  94 VGPRs, 28 KB LDS: placed at once beside two resident
 //                      trailing-update workgroups; tiles memory-resident, visited in chunks
 //   potf2_chain_kernel (potf2_chain.h, round 3, GPX_POTF2=chain)  344 VGPRs, 46 KB: all tiles in registers; the
 //                      fastest stand-alone, but needs a drained CU
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void potf2_chain_kernel(double* A, int64_t 
 
 // the placeable form (potf2_slim.h): <= 112 VGPRs, 28.2 KB LDS — fits beside two resident trailing-update workgroups;
 // bit-identical to the two kernels above.  amdgpu_num_vgpr keeps the allocator out of the AGPR half of the unified
-// register file (without it: 88 VGPRs + 48 AGPRs = 136 allocated); tests/test_abi.py checks the emitted counts.
+// register file (without it: ~90 VGPRs + 48 AGPRs allocated); tests/test_abi.py checks the emitted counts.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112))) void potf2_slim_kernel(double* A, int64_t lda, double* Linv,
                                                                                            int* info, int info_base,
                                                                                            int64_t a_bs, int64_t linv_bs) {

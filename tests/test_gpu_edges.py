@@ -188,7 +188,7 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
 
 @pytest.mark.gpu
 def test_the_three_diagonal_block_kernels_are_bit_identical(monkeypatch):
-    """potf2_slim.h (default: memory-resident tiles, 88 VGPRs / 28 KB LDS, placed at once beside two resident
+    """potf2_slim.h (default: memory-resident tiles, 94 VGPRs / 28 KB LDS, placed at once beside two resident
     trailing-update workgroups), potf2_chain.h (round 3: every tile in registers) and potf2_tile.h (round 2, four phases)
     run tile for tile the same MFMA sequences: factors, block inverses (through the solves they feed), log-likelihood,
     gradient, posterior and the pivot report agree bit for bit — batched launches, a leading dimension that is not the
