@@ -288,20 +288,20 @@ __global__ __launch_bounds__(256) void sgp_reduce_kernel(const double* __restric
       if (threadIdx.x == 0) out[c] = t;
     }
   }
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < M * d; idx += gridDim.x * 256) {
+  // one WAVE per output (j, c): its lanes take the block rows b = lane, lane + 64, ... and a fixed-order butterfly adds
+  // them up (deterministic; a single thread walking the nbi = N / 64 partials, 130 KB apart, is a chain of dependent
+  // loads: C5 97 us for 4078 outputs)
+  const int lane = threadIdx.x & 63;
+  for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < M * d; idx += gridDim.x * 4) {
     const int j = idx / d, c = idx - j * d;
-    // four independent partial sums (b mod 4) in a fixed order: the loads are 130 KB apart and a single dependent chain
-    // of nbi = N / 64 of them is latency-bound (C5: 162 us for 4078 outputs)
-    double s4[4] = {0.0, 0.0, 0.0, 0.0};
-    int b = 0;
-    for (; b + 3 < nbi; b += 4) {
+    double s = 0.0;
+    for (int b = lane; b < nbi; b += 64) s += gxu_part[((int64_t)b * M + j) * GPX_MAX_DIM + c];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s4[u] += gxu_part[((int64_t)(b + u) * M + j) * GPX_MAX_DIM + c];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+      s *= factor;
+      gxu[idx] = accumulate ? gxu[idx] + s : s;
     }
-    for (int u = 0; b < nbi; ++b, ++u) s4[u] += gxu_part[((int64_t)b * M + j) * GPX_MAX_DIM + c];
-    double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-    s *= factor;
-    gxu[idx] = accumulate ? gxu[idx] + s : s;
   }
 }
 
@@ -704,12 +704,12 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
     const sgp_contract_fn contract = pick_contract(s->kp);
     contract<<<g1, 256, 0, ctx->s>>>(s->kp, s->Xu.d(), M, s->Xu.d(), M, s->B3.d(), s->ldu, s->rcoef_u.d(),
                                      s->mvec.d(), s->cpart.d(), s->gxu_part.d());
-    sgp_reduce_kernel<<<64, 256, 0, ctx->s>>>(s->cpart.d(), nbj * nbi_u, d + 1, out_uu, s->gxu_part.d(), nbi_u, M, d,
+    sgp_reduce_kernel<<<512, 256, 0, ctx->s>>>(s->cpart.d(), nbj * nbi_u, d + 1, out_uu, s->gxu_part.d(), nbi_u, M, d,
                                               2.0, 0, s->gXu.d());
     dim3 g2(nbj, nbi_f);
     contract<<<g2, 256, 0, ctx->s>>>(s->kp, ctx->X.d(), N, s->Xu.d(), M, s->T1.d(), s->ldw,
                                      s->rcoef_f.d(), s->mvec.d(), s->cpart.d(), s->gxu_part.d());
-    sgp_reduce_kernel<<<64, 256, 0, ctx->s>>>(s->cpart.d(), nbj * nbi_f, d + 1, out_uf, s->gxu_part.d(), nbi_f, M, d,
+    sgp_reduce_kernel<<<512, 256, 0, ctx->s>>>(s->cpart.d(), nbj * nbi_f, d + 1, out_uf, s->gxu_part.d(), nbi_f, M, d,
                                               1.0, 1, s->gXu.d());
     GPX_HIP(ctx, hipGetLastError());
   }
