@@ -81,7 +81,7 @@ for N in 128 512 2048; do
   timeout 200 rocprofv3 --kernel-trace -d /tmp/prof_sn$N -- python tools/smalln_timeline.py run $N > $O/smalln_$N.txt 2>&1
   python tools/smalln_timeline.py show "$(find /tmp/prof_sn$N -name '*.db' | head -1)" $O/smalln_timeline_$N.md > /dev/null 2>> $O/smalln_$N.txt
 done
-NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL,P2P python bench.py --force-rank-path --steps 4 --warmup 1 --c4-S 24 --no-node-record > $O/rank1_rccl_nccl_debug.json 2> $O/rank1_rccl_nccl_debug.log
+GPX_RANK_FORCE_COLLECTIVES=1 NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL,P2P NCCL_DEBUG_FILE=$O/rank1_rccl_nccl_debug.log python bench.py --force-rank-path --steps 4 --warmup 1 --c4-S 24 --no-node-record > $O/bench_rank1_rccl_forced_collectives.json 2> $O/rank1_rccl_forced.err
 python bench.py > $O/bench_$RND.json 2> $O/bench_$RND.err
 cut -c1-400 $O/bench_$RND.json
 ls -la $O
