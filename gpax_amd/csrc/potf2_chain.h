@@ -1,7 +1,9 @@
 // potf2_chain.h — the 128 x 128 diagonal-block factor + inverse (potf2.hip) as a WAVE-SPECIALISED kernel body:
 // wave 0 runs nothing but the dependent chain  diag16(p) -> L(p+1,p) -> D(p+1) = C(p+1,p+1) - L(p+1,p) L(p+1,p)^T ->
 // diag16(p+1)  out of LDS, waves 1 - 3 own all 36 Cholesky and 28 inverse-residual 16 x 16 tiles as MFMA accumulators
-// and do every other TRSM and update beside it.
+// and do every other TRSM and update beside it.  Round 3's default; since round 4 GPX_POTF2=chain — the default is the
+// same structure with memory-resident tiles (potf2_slim.h), which fits beside two resident trailing-update workgroups;
+// this one (344 VGPRs, 46 KB) needs a drained CU and stays as a reference of the bit-identity test.
 //
 // Why: potf2 is the serial kernel of the blocked Cholesky (one launch per 128 columns, on the critical path of the whole
 // panel chain: gpax/models/gp.py:160-164 -> jnp.linalg.cholesky).  In potf2_tile_body all four waves step through four
