@@ -342,6 +342,7 @@ struct GemmArgs {
   int64_t a_bs, b_bs, c_bs;
   int batch2;  // > 1: two-level batch — entry = outer * batch2 + inner, at base + outer * *_bs + inner * *_bs2
   int64_t a_bs2, b_bs2, c_bs2;
+  int latency_shape; // 1: take the 64 x 64 shapes whatever the tile count (many short, unequal k ranges: split-K of a triangular product)
 };
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
                    int prof_cls, double work);

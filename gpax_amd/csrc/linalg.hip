@@ -481,8 +481,13 @@ int launch_lml_terms(gpx_ctx* ctx, const double* dL, int64_t ld, int N, double* 
   return 0;
 }
 
-// One wave per row:  mean[r] = sum_k V[r][k] w[k];  var[r] = kdiag - sum_k V[r][k]^2.
+// mean[r] = sum_k V[r][k] w[k];  var[r] = kdiag - sum_k V[r][k]^2.  WPR = 1: one wave per row, four rows per workgroup.
+// WPR = 4 (rows of >= 4096 columns): the four waves of a workgroup share one row, k interleaved in steps of 256, partial
+// sums added in wave order — a 2048 x 16316 operand (u = W^T y of the sparse bound, the predictive mean / variance at
+// C3) is otherwise 2048 waves on a 256-CU chip: 2 TB/s.  Which form a launch takes depends on `cols` only, so single
+// and batched launches of one shape keep giving the same bits.
 // col_start_by_row: V is upper triangular, start at k = r (alpha = L^-T w).
+template <int WPR>
 __global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ V, int64_t ldv,
                                                      int rows, int cols,
                                                      const double* __restrict__ w, double kdiag,
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ 
                                                      const double* __restrict__ pred_diag,
                                                      int64_t pd_bs) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = blockIdx.x * 4 + wave;
+  const int r = (WPR == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
   if (r >= rows) return;
   const int bb = blockIdx.y; // batch entry
   V += (int64_t)bb * v_bs;
@@ -503,13 +508,29 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ 
   const double* v = V + (int64_t)r * ldv;
   double m = 0.0, q = 0.0;
   int k0 = col_start_by_row ? (r & ~63) : 0;
-  for (int k = k0 + lane; k < cols; k += 64) {
+  for (int k = k0 + (WPR == 1 ? 0 : wave * 64) + lane; k < cols; k += 64 * WPR) {
     const double x = (col_start_by_row && k < r) ? 0.0 : v[k];
     m = fma(x, w[k], m);
     q = fma(x, x, q);
   }
   m = wave_sum(m);
   q = wave_sum(q);
+  if constexpr (WPR > 1) {
+    __shared__ double red[2][WPR];
+    if (lane == 0) {
+      red[0][wave] = m;
+      red[1][wave] = q;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    m = red[0][0];
+    q = red[1][0];
+#pragma unroll
+    for (int i = 1; i < WPR; ++i) {
+      m += red[0][i];
+      q += red[1][i];
+    }
+  }
   if (lane == 0) {
     if (mean) mean[(int64_t)bb * out_bs + r] = m;
     if (var) var[(int64_t)bb * out_bs + r] = kdiag - q + (pred_diag ? pred_diag[(int64_t)bb * pd_bs + r] : 0.0);
@@ -521,9 +542,15 @@ int launch_rowdot(gpx_ctx* ctx, const double* dV, int64_t ldv, int rows, int col
                   int col_start_by_row, int batch, int64_t v_bs, int64_t w_bs, int64_t out_bs,
                   const ThetaDev* th, const double* pred_diag, int64_t pd_bs) {
   if (rows <= 0) return 0;
-  dim3 grid((rows + 3) / 4, batch > 1 ? batch : 1);
-  rowdot_kernel<<<grid, 256, 0, ctx->s>>>(dV, ldv, rows, cols, dw, kdiag, dmean, dvar,
-                                          col_start_by_row, v_bs, w_bs, out_bs, th, pred_diag, pd_bs);
+  if (cols >= 4096) {
+    dim3 grid(rows, batch > 1 ? batch : 1);
+    rowdot_kernel<4><<<grid, 256, 0, ctx->s>>>(dV, ldv, rows, cols, dw, kdiag, dmean, dvar, col_start_by_row, v_bs, w_bs,
+                                               out_bs, th, pred_diag, pd_bs);
+  } else {
+    dim3 grid((rows + 3) / 4, batch > 1 ? batch : 1);
+    rowdot_kernel<1><<<grid, 256, 0, ctx->s>>>(dV, ldv, rows, cols, dw, kdiag, dmean, dvar, col_start_by_row, v_bs, w_bs,
+                                               out_bs, th, pred_diag, pd_bs);
+  }
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }

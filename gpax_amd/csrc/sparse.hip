@@ -49,28 +49,39 @@ static int launch_transpose(gpx_ctx* ctx, const double* in, int64_t ldi, int row
 }
 
 // Full symmetric n x n:  out = diag_val * I + scale * sum_z P_z[max(i,j)][min(i,j)]   (i, j < n_valid),
-// identity elsewhere in the n_pad extent.
+// identity elsewhere in the n_pad extent (a multiple of 32).  One workgroup per 32 x 32 block of the LOWER triangle: the
+// slabs are read along their rows, the sum goes out as block (bi, bj) and — turned through LDS — as block (bj, bi), both
+// along rows.  (Rounds 2 / 3 read P[max][min] per output element: the upper half of the output walked DOWN the
+// columns of every slab — 211 us at M = 2048 with 11 slabs, 1.7 TB/s.)
 __global__ __launch_bounds__(256) void sym_finalize_kernel(const double* __restrict__ P, int splits,
                                                            int64_t split_stride, int64_t ldp, double scale,
                                                            double diag_val, int n_valid, int n_pad,
                                                            double* __restrict__ out, int64_t ldo) {
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int i0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
-  if (j >= n_pad) return;
-  for (int t = 0; t < 4; ++t) {
-    const int i = i0 + t;
-    if (i >= n_pad) return;
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  __shared__ double t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j = bj * 32 + tx;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r;
     double v;
     if (i < n_valid && j < n_valid) {
-      const int hi = i > j ? i : j, lo = i > j ? j : i;
+      // (in a diagonal block the entries above the diagonal are taken from their mirror image below)
+      const double* p = (bi == bj && tx > r) ? P + (int64_t)j * ldp + i : P + (int64_t)i * ldp + j;
       double acc = 0.0;
-      for (int z = 0; z < splits; ++z) acc += P[(int64_t)z * split_stride + (int64_t)hi * ldp + lo];
+      for (int z = 0; z < splits; ++z) acc += p[(int64_t)z * split_stride];
       v = scale * acc + (i == j ? diag_val : 0.0);
     } else {
       v = (i == j) ? 1.0 : 0.0;
     }
     out[(int64_t)i * ldo + j] = v;
+    t[r][tx] = v;
   }
+  if (bi == bj) return;
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) out[(int64_t)(bj * 32 + r) * ldo + bi * 32 + tx] = t[tx][r];
 }
 
 __device__ __forceinline__ double wsum(double v) {
@@ -89,6 +100,31 @@ __device__ __forceinline__ double bsum(double v, double* red) {
   if (threadIdx.x == 0)
     for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) s += red[w];
   return s;
+}
+
+// transpose_kernel that also leaves the sum of squares of its 32 x 32 block of `in` (entries with i < vr, j < vc) in
+// part[blockIdx.y * gridDim.x + blockIdx.x]: |W|_F^2 of the sparse bound without another pass over the N x M matrix.
+__global__ __launch_bounds__(256) void transpose_sumsq_kernel(const double* __restrict__ in, int64_t ldi, int rows,
+                                                              int cols, double* __restrict__ out, int64_t ldo, int vr,
+                                                              int vc, double* __restrict__ part) {
+  __shared__ double t[32][33];
+  __shared__ double red[16];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  double sq = 0.0;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = by + r, j = bx + tx;
+    const double x = (i < rows && j < cols) ? in[(int64_t)i * ldi + j] : 0.0;
+    t[r][tx] = x;
+    if (i < vr && j < vc) sq = fma(x, x, sq);
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int j = bx + r, i = by + tx;
+    if (j < cols && i < rows) out[(int64_t)j * ldo + i] = t[tx][r];
+  }
+  const double tot = bsum(sq, red);
+  if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }
 
 // part[block] = sum of squares of rows [block*R, ...) of a rows x cols matrix (fixed order).
@@ -357,9 +393,33 @@ static int syrk_full(gpx_ctx* ctx, const double* V, int64_t ldv, int nt, int K, 
   const int rc_syrk = launch_gemm_nt(ctx, g, nt, nt, splits, GPX_PROF_GEMM_OTHER, (double)np * (np + 1.0) * K);
   if (ctx->persist_scope_ok) ctx->persist_scope -= 1;
   GPX_TRY(rc_syrk);
-  dim3 grid((np + 63) / 64, (np + 15) / 16);
+  dim3 grid(np / 32, np / 32);
   sym_finalize_kernel<<<grid, 256, 0, ctx->s>>>(ctx->SplitK.d(), splits, stride, ldp, scale, diag_val, n_valid, np,
                                                 out, ldo);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// out (full, symmetric, np x np) = the product described by g, whose k ranges are cut by the triangle of its operands
+// (ktri: k starts at the row tile) and of which only the lower triangle is computed.  As ONE launch the 64 x 64 tiles
+// are all resident at once and the launch lasts as long as its longest tile — k = 0 .. np on one workgroup, ~170 us at
+// np = 2048 whether the product has M^3 / 3 or 2 M^3 flop.  Cut into `splits` k slabs (one grid.z each, empty ranges store
+// zeros) no workgroup has more than np / splits of k, and the slab sum + mirror is the pass that `symmetrize` was.
+static int tri_product_sym(gpx_ctx* ctx, GemmArgs g, int nt, int splits, double* out, int64_t ldo, double work) {
+  const int np = nt * TILE;
+  const int64_t ldp = pick_ld(np), stride = (int64_t)np * ldp;
+  const int kchunk = round_up((g.K + splits - 1) / splits, TILE);
+  splits = (g.K + kchunk - 1) / kchunk;
+  GPX_TRY(ens(ctx, ctx->SplitK, (size_t)splits * stride * sizeof(double)));
+  g.C = ctx->SplitK.d();
+  g.ldc = ldp;
+  g.lower = 1;
+  g.kchunk = kchunk;
+  g.c_split_stride = stride;
+  g.latency_shape = 1;
+  GPX_TRY(launch_gemm_nt(ctx, g, nt, nt, splits, GPX_PROF_GEMM_OTHER, work));
+  dim3 grid(np / 32, np / 32);
+  sym_finalize_kernel<<<grid, 256, 0, ctx->s>>>(ctx->SplitK.d(), splits, stride, ldp, 1.0, 0.0, np, np, out, ldo);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -421,6 +481,7 @@ struct SgpState {
   // yres, X): predict_in_batches calls gpx_sgp_posterior once per slice of X_new with everything else unchanged
   // (sparse_gp.py:173-223 recomputes Kuu, Kuf and both factorisations for every slice).
   bool fwd_valid = false, reuse = false;
+  int npartW = 0; // partial sums of |W|_F^2 left in `part` by the forward pass
   uint64_t h_train_gen = 0;
   int h_kind = -1;
   double h_par[GPX_MAX_DIM + 3] = {0};
@@ -523,7 +584,7 @@ static int sgp_forward_run(gpx_ctx* ctx, SgpState* s) {
   GPX_TRY(ens(ctx, s->c, (size_t)Mp * 8));
   GPX_TRY(ens(ctx, s->cpad, (size_t)TILE * s->ldu * 8));
   GPX_TRY(ens(ctx, s->scal, 8192));
-  GPX_TRY(ens(ctx, s->part, (size_t)(Ntp / 8 + Mp / 8 + 32) * 8));
+  GPX_TRY(ens(ctx, s->part, (size_t)((Ntp / 32) * (Mp / 32) + Mp / 8 + 32) * 8));
   int* dinfo = s->scal.i() + 1024;
   GPX_HIP(ctx, hipMemsetAsync(dinfo, 0, 2 * sizeof(int), ctx->stream));
   // Kuu = kernel(Xu, Xu, params, **jitter): noise defaults to 0 (sparse_gp.py:92)
@@ -543,7 +604,12 @@ static int sgp_forward_run(gpx_ctx* ctx, SgpState* s) {
     GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->Wn.d(), s->ldw));
     GPX_TRY(trsm_right_lt(ctx, s->Wn.d(), s->ldw, ntl, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, 0));
   }
-  GPX_TRY(launch_transpose(ctx, s->Wn.d(), s->ldw, Ntp, Mp, s->Wt.d(), s->ldt));
+  { // Wt = W^T, and |W|_F^2 in partial sums on the way (the bound's trace term)
+    dim3 grid((Mp + 31) / 32, (Ntp + 31) / 32);
+    transpose_sumsq_kernel<<<grid, 256, 0, ctx->s>>>(s->Wn.d(), s->ldw, Ntp, Mp, s->Wt.d(), s->ldt, N, M, s->part.d());
+    GPX_HIP(ctx, hipGetLastError());
+    s->npartW = (int)(grid.x * grid.y);
+  }
   // A = I + Wt Wt^T / s2 (kept in Acopy), factor
   GPX_TRY(syrk_full(ctx, s->Wt.d(), s->ldt, mt, Ntp, 1.0 / s2, 1.0, M, s->A.d(), s->ldu));
   GPX_HIP(ctx, hipMemcpyAsync(s->Acopy.d(), s->A.d(), mm, hipMemcpyDeviceToDevice, ctx->stream));
@@ -592,9 +658,7 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
   const int N = ctx->N, d = ctx->d, M = s->M, Mp = s->Mp, Ntp = s->Ntp, mt = Mp / TILE;
   const double s2 = noise, kd = kd_value(s->kp);
   double* sc = s->scal.d();
-  const int npart = (N + 7) / 8;
-  sumsq_rows_kernel<<<npart, 256, 0, ctx->s>>>(s->Wn.d(), s->ldw, N, M, s->part.d());
-  GPX_HIP(ctx, hipGetLastError());
+  const int npart = s->npartW; // |W|_F^2 in partial sums since the forward pass (transpose_sumsq_kernel)
   const size_t mm = (size_t)Mp * s->ldu * 8;
   const double* tvec = nullptr;
   int npartA = 0;
@@ -652,11 +716,15 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
   double* Ainv = s->B2.d();
   {
     GemmArgs g = gargs(TA, s->ldu, TA, s->ldu, Ainv, s->ldu, Mp, 1.0, 0.0);
-    g.lower = 1;
     g.ktri = 1;
-    GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, 0, GPX_PROF_GEMM_OTHER, (double)Mp * Mp * Mp / 3.0));
     dim3 gs((Mp + 255) / 256, Mp);
-    symmetrize_kernel<<<gs, 256, 0, ctx->s>>>(Ainv, s->ldu, Mp);
+    if (mt >= 8) { // A^-1 = TA TA^T, lower triangle in k slabs, then mirrored
+      GPX_TRY(tri_product_sym(ctx, g, mt, 4, Ainv, s->ldu, (double)Mp * Mp * Mp / 3.0));
+    } else {
+      g.lower = 1;
+      GPX_TRY(launch_gemm_nt(ctx, g, mt, mt, 0, GPX_PROF_GEMM_OTHER, (double)Mp * Mp * Mp / 3.0));
+      symmetrize_kernel<<<gs, 256, 0, ctx->s>>>(Ainv, s->ldu, Mp);
+    }
     // H -> B3 ; R -> B4
     mat_combine_kernel<<<gs, 256, 0, ctx->s>>>(s->B3.d(), s->ldu, -0.5, Ainv, s->ldu, -0.5 * uu, s->Acopy.d(),
                                                s->ldu, 0.5 + 0.5 * uu, Mp);
@@ -672,11 +740,15 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
     // launch order hands out the long tiles first), mirrored afterwards — a quarter of the dense 2 M^3
     GemmArgs h2 = gargs(Tu, s->ldu, s->B2.d(), s->ldu, s->B3.d(), s->ldu, Mp, 1.0, 0.0);
     h2.ktri = 1;
-    h2.lower = 1;
-    GPX_TRY(launch_gemm_nt(ctx, h2, mt, mt, 0, GPX_PROF_GEMM_OTHER, (double)Mp * Mp * (Mp + TILE) / 2.0));
-    dim3 gs3((Mp + 255) / 256, Mp);
-    symmetrize_kernel<<<gs3, 256, 0, ctx->s>>>(s->B3.d(), s->ldu, Mp);
-    GPX_HIP(ctx, hipGetLastError());
+    if (mt >= 8) {
+      GPX_TRY(tri_product_sym(ctx, h2, mt, 4, s->B3.d(), s->ldu, (double)Mp * Mp * (Mp + TILE) / 2.0));
+    } else {
+      h2.lower = 1;
+      GPX_TRY(launch_gemm_nt(ctx, h2, mt, mt, 0, GPX_PROF_GEMM_OTHER, (double)Mp * Mp * (Mp + TILE) / 2.0));
+      dim3 gs3((Mp + 255) / 256, Mp);
+      symmetrize_kernel<<<gs3, 256, 0, ctx->s>>>(s->B3.d(), s->ldu, Mp);
+      GPX_HIP(ctx, hipGetLastError());
+    }
   }
   GPX_TRY(ens(ctx, s->T1, (size_t)Ntp * s->ldw * 8));
   { // T1 = W R Tu^T as W (Tu R)^T: the M x M product first (M^3, k from the triangle of Tu; R is symmetric), then ONE

@@ -73,7 +73,7 @@ def test_c4_shape_n8192_d3_one_theta_vs_oracle(engine):
 
 def test_c4_sweep_s1000_n8192_d3(engine):
     """BASELINE.json configs[3] on one GPU: the full 1000-sample sweep once (contexts in flight as predict() runs
-    it), bit-reproducible, 4 spot samples against the oracle, y_means.mean(0) as gp.py:399."""
+    it), bit-reproducible, 2 spot samples against the oracle, y_means.mean(0) as gp.py:399."""
     from gpax_amd import _lib
 
     N, d, M, S = 8192, 3, 1024, 1000
@@ -91,7 +91,7 @@ def test_c4_sweep_s1000_n8192_d3(engine):
                                       eps[sub])
     np.testing.assert_array_equal(m1[sub], m2)
     np.testing.assert_array_equal(d1[sub], d2)
-    for s in (0, 333, 666, 999):
+    for s in (333, 999):  # ~7 s of CPU oracle each
         q = {k: v[s] for k, v in th.items()}
         e_mean, e_draw = ref.predict_one(X, y, Xn, q, eps[s], False, kernel="RBF", jitter=JIT, route="chol")
         assert relerr(m1[s], e_mean) < 1e-8
