@@ -651,7 +651,10 @@ int gpx_init(int device, gpx_ctx** out) {
     }
     if (const char* e = getenv("GPX_OUTER_TILES")) {
       const int ot = atoi(e);
-      if (ot >= 1 && ot <= 32) ctx->outer_tiles = ot;
+      if (ot >= 1 && ot <= 32) {
+        ctx->outer_tiles = ot;
+        ctx->outer_tiles_set = true;
+      }
     }
     if (const char* e = getenv("GPX_TAIL_TILES")) ctx->tail_tiles = atoi(e);
     GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, lo));

@@ -16,6 +16,11 @@ namespace gpx {
 constexpr int GPX_TILE_COUNTERS = 1024;
 constexpr int TILE = 128;      // MFMA GEMM block tile and diagonal-block size
 constexpr int OUTER_TILES = 4; // default outer blocking of the right-looking sweeps (4*128 = 512); ctx->outer_tiles
+// A single-sample Cholesky of up to this many tile rows runs as ONE outer block (plain right-looking, K = 128 updates of
+// everything to the right, one stream): up to N = 4096 the look-ahead's cross-stream waits and the chain work it puts
+// BEFORE the next diagonal block cost more than its larger K returns (round 4, one box: potrf N = 1024 0.439 -> 0.377 ms,
+// 2048 0.950 -> 0.812, 4096 2.207 -> 1.995).  Batched sweeps keep the blocked schedule: B times the update, GEMM-bound.
+constexpr int ONE_BLOCK_TILES = 32;
 constexpr double AUG_BIG = 1e300;
 constexpr double SQRT5 = 2.23606797749978969641;
 constexpr double MATERN_EPS = 1e-12; // gpax/kernels/kernels.py:20-21
@@ -174,6 +179,7 @@ struct gpx_ctx {
   int lazy_group = 2; // GPX_LAZY_GROUP: outer blocks whose far (bulk) trailing update is applied in one launch while the
                       // factorisation is GEMM-bound (linalg.hip): K = 1024 at the default outer block of 512 columns
   int outer_tiles = gpx::OUTER_TILES; // GPX_OUTER_TILES (experiments): K of the trailing update = 128 * outer_tiles
+  bool outer_tiles_set = false;       // ... given explicitly: no ONE_BLOCK_TILES rule
   unsigned func_attr_mask = 0; // kernels whose dynamic-LDS attribute this context has set on ITS device (bit per variant)
 
   // ---- training state -------------------------------------------------------------------

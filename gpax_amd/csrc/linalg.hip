@@ -148,7 +148,8 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
   const BatchStrides bs{batch > 1 ? batch : 1, a_bs, linv_bs};
   const int nblk = np / TILE;
   ctx->small_bk_now = ctx->small_bk != 0 ? ctx->small_bk : ((bs.batch == 1 && nblk + extra_tiles <= SMALL_BK_ROWS) ? 32 : 16);
-  const int OT = ctx->outer_tiles;
+  const bool one_block = !ctx->outer_tiles_set && bs.batch == 1 && nblk <= ONE_BLOCK_TILES && nblk + extra_tiles <= ONE_BLOCK_TILES + 8;
+  const int OT = one_block ? nblk : ctx->outer_tiles;
   const int G = ctx->lazy_group > 0 ? ctx->lazy_group : 1;
   // ADAPTIVE schedule (the timeline of one C3 factorisation, profiles/r02/timeline_c3.md): while the remaining matrix is
   // large the trailing updates follow each other without gaps and the panel chain hides behind them (GEMM-bound
@@ -158,7 +159,7 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
   const int tail_tiles = ctx->tail_tiles;
   const int nouter = (nblk + OT - 1) / OT;
   if (nouter == 1) {
-    // one outer block (N <= 512): nothing to look ahead over — the chain runs on the main stream, without the two
+    // one outer block (N <= 512, and single-sample factorisations up to ONE_BLOCK_TILES tile rows): nothing to look ahead over — the chain runs on the main stream, without the two
     // cross-stream event waits of the look-ahead (~10 - 18 us each at this size)
     ctx->s = ctx->stream;
     return panel_block(ctx, dA, lda, nblk, extra_tiles, 0, nblk, dLinv, dInfo, bs);
@@ -186,6 +187,19 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
   for (int k = 0; k < nouter && rc >= 0; ++k) {
     const int ob = ob_of(k), oe = ob_of(k + 1);
     const int gs = gfirst[(size_t)k], ge = glast[(size_t)k];
+    // The END of a large single-sample factorisation is a mid-size one: once no more than ONE_BLOCK_TILES tile rows are
+    // left and block k starts a group (its columns have every update from the blocks before it through the U1
+    // launches, the columns behind it through the far updates issued so far), the rest runs as one outer block on the
+    // panel stream, behind whatever the main stream still has in flight — as a factorisation of that size would.
+    if (k > 0 && k == gs && !ctx->outer_tiles_set && bs.batch == 1 && nblk - ob <= ONE_BLOCK_TILES &&
+        nblk - ob + extra_tiles <= ONE_BLOCK_TILES + 8) {
+      GPX_HIP(ctx, hipEventRecord(ctx->evD, smain));
+      GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evD, 0));
+      ctx->s = span;
+      if (ctx->small_bk == 0) ctx->small_bk_now = 32;
+      rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, nblk, dLinv, dInfo, bs);
+      break;
+    }
     // P(k) on the panel stream (it follows U1(k-1) there, in stream order)
     ctx->s = span;
     rc = panel_block(ctx, dA, lda, nblk, extra_tiles, ob, oe, dLinv, dInfo, bs);

@@ -155,15 +155,19 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
     eps = np.random.default_rng(1).standard_normal((2, 1, M))
     ells = np.stack([p["k_length"], 1.1 * p["k_length"]])
     outs = []
-    variants = [dict(), dict(GPX_TAIL_TILES="12", GPX_LAZY_GROUP="2"), dict(GPX_TAIL_TILES="9"),
-                dict(GPX_LAZY_GROUP="3", GPX_TAIL_TILES="14"), dict(GPX_LAZY_GROUP="1"), dict(GPX_LAZY_GROUP="3"),
-                dict(GPX_LAZY_GROUP="4", GPX_TAIL_TILES="0"), dict(GPX_OUTER_TILES="2"),
+    # (no switch: 22 tile rows run as ONE outer block since round 4 — common.h ONE_BLOCK_TILES; an explicit
+    # GPX_OUTER_TILES brings back the blocked look-ahead schedule the lazy groups and the tail rule belong to)
+    variants = [dict(), dict(GPX_OUTER_TILES="4"), dict(GPX_OUTER_TILES="4", GPX_TAIL_TILES="12", GPX_LAZY_GROUP="2"),
+                dict(GPX_OUTER_TILES="4", GPX_TAIL_TILES="9"),
+                dict(GPX_OUTER_TILES="4", GPX_LAZY_GROUP="3", GPX_TAIL_TILES="14"), dict(GPX_OUTER_TILES="4", GPX_LAZY_GROUP="1"),
+                dict(GPX_OUTER_TILES="4", GPX_LAZY_GROUP="3"),
+                dict(GPX_OUTER_TILES="4", GPX_LAZY_GROUP="4", GPX_TAIL_TILES="0"), dict(GPX_OUTER_TILES="2"),
                 dict(GPX_LAZY_GROUP="2", GPX_OUTER_TILES="3"), dict(GPX_OUTER_TILES="8", GPX_LAZY_GROUP="1"),
                 dict(GPX_OUTER_TILES="1"),
                 # big-tile GEMMs of the sweeps as plain launches instead of persistent ones
                 dict(GPX_PERSIST_SCOPE="0"),
                 # k-step of the latency shapes, the diagonal-block kernels
-                dict(GPX_SMALL_BK="32"), dict(GPX_SMALL_BK="16", GPX_LAZY_GROUP="3"), dict(GPX_POTF2="chain"),
+                dict(GPX_SMALL_BK="32"), dict(GPX_SMALL_BK="16", GPX_LAZY_GROUP="3", GPX_OUTER_TILES="4"), dict(GPX_POTF2="chain"),
                 dict(GPX_POTF2="tile", GPX_OUTER_TILES="2")]
     switches = ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_PERSIST_SCOPE", "GPX_TAIL_TILES", "GPX_SMALL_BK", "GPX_POTF2")
     for env in variants:
