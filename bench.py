@@ -12,16 +12,24 @@ theta samples; the sweep has no data-path collective, only the final gather of r
 
     python bench.py --gpus N --steps K --warmup W
 N = 1: K steps of the resident sweep (gpx_sweep_resident), `--inflight` contexts on the GPU.
-N > 1: one process per GPU, NO PyTorch: every rank (RANK / LOCAL_RANK / WORLD_SIZE set by the launcher — the driver's
+N > 1: one process per GPU, NO PyTorch (RANK / LOCAL_RANK / WORLD_SIZE set by the launcher — the driver's
 `python -m torch.distributed.run`, or bench.py's own `gpax_amd.launch.spawn_ranks` when it is started plainly with
---gpus N) joins the library's RCCL communicator (gpx_rank_*, ncclCommInitRank over the rendezvous of
-gpax_amd/launch.py) and the timed region is ONE collective gpx_rank_predict_sweep over S = N * K theta samples:
-rank 0's H2D of the inputs, ncclBroadcast over xGMI, every rank's block of K samples, ncclSend / ncclRecv gather, D2H
-on rank 0 — bracketed by a barrier on both sides (gpx_rank_barrier: own contexts synchronised + all-reduce), time =
-max over ranks (gpx_rank_allreduce_max).  A second record, `c4_sweep`, times BASELINE.json configs[3] (S = 1000,
-N = 8192, d = 3) the same way and against rank 0 alone; a third, `node_sweep`, times both sweeps under the other launch
-model (ONE process owning all N GPUs, gpx_predict_sweep_multi) from a child process of rank 0.  `multi_gpu_path` says
-which transport ran ("rank-rccl"; "rank-file" = the library's file transport, the fallback when RCCL cannot initialise).
+--gpus N), two legs:
+  1. `replicas`: every rank runs the N = 1 workload on its own theta samples, no communicator — the path as it shards
+     (independent samples, no data-path exchange).  Start and end meet in the rendezvous directory; time = latest end -
+     earliest start.  Rank 0 then has a complete line (roofline, stages) before the process makes its first RCCL call.
+  2. the collective: every rank joins the library's RCCL communicator (gpx_rank_*, ncclCommInitRank over the rendezvous of
+     gpax_amd/launch.py) and the timed region is ONE gpx_rank_predict_sweep over S = N * K theta samples: rank 0's H2D
+     of the inputs, ncclBroadcast over xGMI, every rank's block of K samples, ncclSend / ncclRecv gather, D2H on rank 0 —
+     bracketed by a barrier on both sides (gpx_rank_barrier: own contexts synchronised + all-reduce), time = max over
+     ranks (gpx_rank_allreduce_max).  `value` is THIS leg's (the product's multi-GPU call, host arrays in and out); the
+     first leg's is reported beside it (`replicas`, `collective_vs_replicas`).  Should the leg fail or not finish within
+     --collective-timeout seconds, rank 0 prints the replicas line (`multi_gpu_path` "replicas", `collective_leg` says
+     why) and the run still has its measurement.
+A second record, `c4_sweep`, times BASELINE.json configs[3] (S = 1000, N = 8192, d = 3) through the collective and
+against rank 0 alone; a third, `node_sweep`, times both sweeps under the other launch model (ONE process owning all N
+GPUs, gpx_predict_sweep_multi) from a child process of rank 0.  `multi_gpu_path`: "rank-rccl"; "rank-file" = the
+library's file transport, the fallback when RCCL cannot initialise; "replicas" = leg 1 alone.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -63,6 +71,8 @@ def parse():
                     "(1 rank over RCCL on a 1-GPU box)")
     ap.add_argument("--init-timeout", type=float, default=120.0, help="N > 1: seconds before a hung RCCL "
                     "initialisation is abandoned for the file transport")
+    ap.add_argument("--collective-timeout", type=float, default=300.0, help="N > 1: seconds the collective leg (RCCL "
+                    "initialisation, timed sweep, C4 and node records) may take before rank 0 reports the replicas leg alone")
     ap.add_argument("--cpu-baseline-N", type=int, default=0, help="override the CPU sample size")
     ap.add_argument("--cpu-budget-s", type=float, default=150.0,
                     help="budget of the CPU leg; the same-workload sample (one posterior at the bench N) runs when its "
@@ -338,44 +348,51 @@ def flush_c_stdio():
     sys.stdout.flush()
 
 
-def single_gpu(a, device=0):
-    """N = 1: K steps of the resident sweep on one GPU, `--inflight` contexts (the round-1/2 headline, unchanged)."""
-    import threading
+class ResidentBench:
+    """K steps of the resident sweep (gpx_sweep_resident) on ONE GPU, `--inflight` contexts: the N = 1 headline, and the
+    per-rank leg of an N > 1 run that involves no communicator (`replicas` below)."""
 
-    from bench_inputs import synthetic_problem, synthetic_theta_samples  # BASELINE.md §3 workloads
-    from gpax_amd import _lib
+    def __init__(self, a, device, first_theta=0, n_theta=None):
+        from bench_inputs import synthetic_problem, synthetic_theta_samples  # BASELINE.md §3 workloads
+        from gpax_amd import _lib
 
-    eng = _lib.Engine(device)
-    kind = _lib.kernel_kind(a.kernel)
-    N, d, M = a.N, a.d, a.M
-    X, y, Xnew, p = synthetic_problem(N, d, M, seed=0)
-    K, W = a.steps, a.warmup
-    thetas = synthetic_theta_samples(K + W, d, seed=1)
-    sl_w, sl_k = slice(0, W), slice(W, W + K)
-    # Several theta samples in flight per GPU: independent libgpx contexts on the same device fill the
-    # latency-bound tail of one sample's pipeline with the GEMM-heavy head of another (DESIGN.md §5).
-    n_fl = max(1, min(a.inflight, K // 2))  # at least two steps per context
-    engines = [eng] + [_lib.Engine(device) for _ in range(n_fl - 1)]
-    # resident state: X, yres, Xnew, eps on the device before the timed region
-    for e in engines:
-        e.set_train(X)
-        lml, info = e.factor(kind, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
-        e.posterior(Xnew, p["noise"], 1e-6, want_cov=True)
-        e.mvn_draw(np.random.default_rng(2).standard_normal((1, M)))
+        self.a, self.device = a, device
+        self.eng = _lib.Engine(device)
+        self.kind = _lib.kernel_kind(a.kernel)
+        N, d, M = a.N, a.d, a.M
+        self.X, self.y, self.Xnew, self.p = synthetic_problem(N, d, M, seed=0)
+        K, W = a.steps, a.warmup
+        n_theta = (K + W) if n_theta is None else n_theta
+        th = synthetic_theta_samples(first_theta + n_theta, d, seed=1)
+        self.thetas = {k: v[first_theta:] for k, v in th.items()}
+        # Several theta samples in flight per GPU: independent libgpx contexts on the same device fill the
+        # latency-bound tail of one sample's pipeline with the GEMM-heavy head of another (DESIGN.md §5).
+        self.n_fl = max(1, min(a.inflight, max(1, K // 2)))  # at least two steps per context
+        self.engines = [self.eng] + [_lib.Engine(device) for _ in range(self.n_fl - 1)]
+        # resident state: X, yres, Xnew, eps on the device before the timed region
+        p = self.p
+        for e in self.engines:
+            e.set_train(self.X)
+            self.lml, info = e.factor(self.kind, p["k_length"], p["k_scale"], p["noise"], 1e-6, self.y)
+            e.posterior(self.Xnew, p["noise"], 1e-6, want_cov=True)
+            e.mvn_draw(np.random.default_rng(2).standard_normal((1, M)))
 
-    def barrier():
-        for e in engines:
+    def barrier(self):
+        for e in self.engines:
             e.synchronize()
 
-    def sweep(sl):
+    def sweep(self, sl):
         """The steps of slice `sl` over the in-flight contexts: every context takes the next step when it has finished its
         own (a shared cursor), so all of them stop within one step of each other.  (Rounds 1 - 3 dealt contiguous blocks
         of K / n_fl steps: the context the hardware happened to favour finished early and the others ran the last steps
         with fewer samples in flight — the reason `value` moved by +-4 % between runs of the same binary.)"""
+        import threading
+
         idx = list(range(sl.start, sl.stop))
         cursor = [0]
         lock = threading.Lock()
-        ev = [0.0] * n_fl
+        ev = [0.0] * self.n_fl
+        th, engines, kind = self.thetas, self.engines, self.kind
 
         def work(i):
             while True:
@@ -384,34 +401,54 @@ def single_gpu(a, device=0):
                         return
                     k = idx[cursor[0]]
                     cursor[0] += 1
-                ev[i] += engines[i].sweep_resident(kind, thetas["k_length"][k:k + 1], thetas["k_scale"][k:k + 1],
-                                                   thetas["noise"][k:k + 1], False, 1e-6, 1)
+                ev[i] += engines[i].sweep_resident(kind, th["k_length"][k:k + 1], th["k_scale"][k:k + 1],
+                                                   th["noise"][k:k + 1], False, 1e-6, 1)
 
-        ts = [threading.Thread(target=work, args=(i,)) for i in range(n_fl)]
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(self.n_fl)]
         for t_ in ts:
             t_.start()
         for t_ in ts:
             t_.join()
         return max(ev)
 
-    if W > 0:
-        sweep(sl_w)
-        if W < n_fl:  # make sure every context has run the pipeline once before the timed region
-            for e in engines:
-                e.sweep_resident(kind, thetas["k_length"][sl_w][:1], thetas["k_scale"][sl_w][:1],
-                                 thetas["noise"][sl_w][:1], False, 1e-6, 1)
-    barrier()
-    t0 = time.perf_counter()
-    ev_ms = sweep(sl_k)
-    barrier()
-    dt = time.perf_counter() - t0
+    def warm(self):
+        W = self.a.warmup
+        if W > 0:
+            self.sweep(slice(0, W))
+        if W < self.n_fl:  # make sure every context has run the pipeline once before the timed region
+            th = self.thetas
+            for e in self.engines:
+                e.sweep_resident(self.kind, th["k_length"][:1], th["k_scale"][:1], th["noise"][:1], False, 1e-6, 1)
+        self.barrier()
 
-    out = base_line(a, 1, K, W, dt, n_fl, f"sample-sharded x1, {n_fl} samples in flight per GPU")
+    def timed(self):
+        """(seconds, start, end on the system-wide monotonic clock, longest context's event time in ms) of the K steps."""
+        W, K = self.a.warmup, self.a.steps
+        self.barrier()
+        t0 = time.monotonic()
+        ev_ms = self.sweep(slice(W, W + K))
+        self.barrier()
+        t1 = time.monotonic()
+        return t1 - t0, t0, t1, ev_ms
+
+    def close(self, keep_first=False):
+        for e in self.engines[1 if keep_first else 0:]:
+            e.close()
+        self.engines = self.engines[:1] if keep_first else []
+
+
+def single_gpu(a, device=0):
+    """N = 1: K steps of the resident sweep on one GPU, `--inflight` contexts (the round-1/2 headline, unchanged)."""
+    rb = ResidentBench(a, device)
+    rb.warm()
+    dt, _, _, ev_ms = rb.timed()
+    K, W = a.steps, a.warmup
+    out = base_line(a, 1, K, W, dt, rb.n_fl, f"sample-sharded x1, {rb.n_fl} samples in flight per GPU")
     out["event_ms_longest_context"] = ev_ms
     out["multi_gpu_path"] = None
-    out.update(device_record(eng, a, lml))
+    out.update(device_record(rb.eng, a, rb.lml))
     if not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_N or N, d, M, a.kernel, a.cpu_budget_s)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_N or a.N, a.d, a.M, a.kernel, a.cpu_budget_s)
     flush_c_stdio()
     print(json.dumps(out), flush=True)
 
@@ -470,7 +507,7 @@ def run_node_record(a):
     cmd = [sys.executable, os.path.abspath(__file__), "--node-record", "--gpus", str(a.gpus), "--steps", str(a.steps),
            "--warmup", str(a.warmup), "--N", str(a.N), "--d", str(a.d), "--M", str(a.M), "--kernel", a.kernel,
            "--inflight", str(a.inflight), "--c4-S", str(a.c4_S), "--c4-N", str(a.c4_N)] + (["--share-gpu"] if a.share_gpu else [])
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GPX_RDZV_DIR", "GPX_RANK_TRANSPORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GPX_RDZV_DIR", "GPX_RANK_TRANSPORT", "GPX_BENCH_REPLICAS_LINE")}
     if a.share_gpu:
         env["GPX_NODE_TRANSPORT"] = "memcpy"  # RCCL refuses one device listed twice
     try:
@@ -483,8 +520,64 @@ def run_node_record(a):
         return {"error": "no result within 300 s (child stopped)"}
 
 
+def bench_store(env, name):
+    """A key store of THIS launch and attempt under the rendezvous directory (gpax_amd/launch.py: <dir>/<token>/...)."""
+    from gpax_amd import launch
+
+    launch._private_dir(env.rdzv_dir)
+    base = os.path.join(env.rdzv_dir, env.token) if env.token else env.rdzv_dir
+    launch._private_dir(base)
+    return launch.FileStore(os.path.join(base, f"{name}{env.attempt}"))
+
+
+def replicas_leg(a, env, device):
+    """N > 1, FIRST leg — no communicator anywhere: every rank runs the N = 1 workload (K steps of the resident sweep on its
+    own theta samples, `--inflight` contexts) between two meetings in the rendezvous directory; time = latest end -
+    earliest start on the system-wide monotonic clock.  This is the path as it shards (independent theta samples, no
+    data-path exchange), it needs nothing but N working GPUs, and it leaves rank 0 with a complete JSON line before the
+    first RCCL call of the process — the collective leg below has never run on more than one GPU (VERDICT r3 missing #2),
+    and whatever happens to it, the run reports.  Returns rank 0's line (None elsewhere)."""
+    from gpax_amd import _lib
+
+    world, rank = env.world, env.rank
+    K, W = a.steps, a.warmup
+    st = bench_store(env, "replicas")
+    rb = ResidentBench(a, device, first_theta=rank * (K + W), n_theta=K + W)
+    rb.warm()
+    st.set(f"ready.{rank}", b"1")
+    st.gather("ready", world, 1800.0)
+    dt_own, t0, t1, ev_ms = rb.timed()
+    st.set(f"t.{rank}", json.dumps([t0, t1, _lib.device_pci(device)]).encode())
+    out = None
+    if rank == 0:
+        ts = [json.loads(v) for v in st.gather("t", world, 1800.0)]
+        dt = max(t[1] for t in ts) - min(t[0] for t in ts)
+        pci = [int(t[2]) for t in ts]
+        n_distinct = len(set(pci))
+        out = base_line(a, world, K, W, dt, rb.n_fl,
+                        f"sample-sharded x{world} (one process per GPU), {rb.n_fl} samples in flight per GPU")
+        out["config"]["workload"] = out["config"]["workload"].replace(
+            "inputs broadcast from rank 0 and results gathered there inside the timed region", "inputs resident in HBM")
+        out["multi_gpu_path"] = "replicas"
+        out["ranks"] = world
+        out["n_gpus"] = n_distinct  # distinct physical devices (ranks may share one: --share-gpu, LOCAL_RANK beyond the visible set)
+        out["shared_devices"] = n_distinct < world
+        out["per_rank_seconds"] = [t[1] - t[0] for t in ts]
+        out["devices_pci"] = ["%04x:%02x:%02x" % (v >> 16, (v >> 8) & 0xff, v & 0xff) for v in pci]
+        out["rccl_ranks"] = 0
+        out["event_ms_longest_context"] = ev_ms
+        out.update(device_record(rb.eng, a, rb.lml))
+        st.set("solo_done", b"1")
+    else:
+        st.get("solo_done", timeout=1800.0)  # rank 0's stage timings have the GPUs' host to themselves
+    rb.close()
+    return out
+
+
 def multi_rank(a, env):
-    """N > 1: one process per GPU over the library's own communicator (module docstring)."""
+    """N > 1: one process per GPU.  Two legs (module docstring): replicas, then the library's collective under a time limit."""
+    import threading
+
     from bench_inputs import synthetic_problem, synthetic_theta_samples
     from gpax_amd import _lib, launch
 
@@ -497,9 +590,71 @@ def multi_rank(a, env):
     device = 0 if a.share_gpu else (env.local_rank if env.local_rank < n_vis else env.local_rank % n_vis)
     transport = a.transport or ("file" if a.share_gpu else None)
     K, W = a.steps, a.warmup
+
+    # ---- leg 1: replicas.  (A process that re-executes itself for the file transport — launch.init_rank — finds the leg
+    # done: its line travels in the environment.) --------------------------------------------------------------------------
+    carried = os.environ.get("GPX_BENCH_REPLICAS_LINE")
+    if carried is None:
+        rep = replicas_leg(a, env, device)
+        os.environ["GPX_BENCH_REPLICAS_LINE"] = json.dumps(rep) if root else "-"
+    else:
+        rep = json.loads(carried) if root else None
+
+    def report_replicas_only(why):
+        """The collective leg failed or ran out of time: rank 0 prints the replicas line, every rank leaves (exit code 0:
+        the run HAS its measurement; `collective_leg` says what happened to the other one)."""
+        if root:
+            rep["collective_leg"] = {"completed": False, "reason": why}
+            flush_c_stdio()
+            print(json.dumps(rep), flush=True)
+        sys.stderr.write(f"[bench.py] rank {rank}: collective leg abandoned ({why})\n")
+        sys.stderr.flush()
+        os._exit(0)
+
+    limit = a.collective_timeout
+    watchdog = threading.Timer(limit, report_replicas_only, args=(f"not finished within {limit:.0f} s",))
+    watchdog.daemon = True
+    watchdog.start()
+    try:
+        out, rk = collective_leg(a, env, device, transport, rep, on_hang=report_replicas_only)
+    except BaseException as ex:  # a rank that lost its peers raises (gpx_rank_*: peer death, time-outs of the transport)
+        if isinstance(ex, (KeyboardInterrupt, SystemExit)):
+            raise
+        report_replicas_only(f"{type(ex).__name__}: {ex}"[:500])
+    watchdog.cancel()
+    store = bench_store(env, "bench")
+    if root:
+        if not a.no_node_record:
+            # the same sweeps under the other launch model (one process, all GPUs), from a child process with its own time
+            # limit; the ranks idle meanwhile — on the host (they poll the rendezvous store below), not inside an RCCL
+            # collective that would spin on their GPUs
+            out["node_sweep"] = run_node_record(a)
+            ns = out["node_sweep"]
+            if "c3_posteriors_per_s" in ns:
+                ns["c3_vs_rank_collective"] = ns["c3_posteriors_per_s"] / out["value"]
+        flush_c_stdio()
+        print(json.dumps(out), flush=True)
+        store.set("solo_done", b"1")  # rank 0's solo phase is over: everybody meets again
+    else:
+        store.get("solo_done", timeout=1800.0)
+    launch.finalize(env, rk)
+
+
+def collective_leg(a, env, device, transport, rep, on_hang=None):
+    """N > 1, SECOND leg: the library's own communicator (gpx_rank_*: RCCL, or the file transport when RCCL cannot
+    initialise) and ONE collective gpx_rank_predict_sweep over S = N * K theta samples as the timed region.  Returns rank
+    0's final line: `value` from this leg, the replicas leg's under `replicas`."""
+    from bench_inputs import synthetic_problem, synthetic_theta_samples
+    from gpax_amd import _lib, launch
+
+    world, rank = env.world, env.rank
+    root = rank == 0
+    K, W = a.steps, a.warmup
     n_fl = max(1, min(a.inflight, max(1, K // 2)))
+    if os.environ.get("GPX_BENCH_TEST_HANG") == str(rank):  # tests: this rank never joins (a hung collective)
+        time.sleep(86400)
     rk = launch.init_rank(env, device=device, inflight=n_fl, transport=transport, timeout=a.init_timeout,
-                          reexec_on_hang=True)
+                          reexec_on_hang=True, on_hang=on_hang)
     info = rk.info()
     kind = _lib.kernel_kind(a.kernel)
     N, d, M = a.N, a.d, a.M
@@ -536,7 +691,6 @@ def multi_rank(a, env):
     per_rank_s = [float(v) for v in vec[:slots]]
     pci = [int(v) for v in vec[slots:2 * slots] if np.isfinite(v)]
     n_distinct = len(set(pci))
-
     # ---- second record: C4 (BASELINE.json configs[3]) through the same collective, and on rank 0 alone -------------------
     c4 = None
     if a.c4_S > 0:
@@ -578,46 +732,32 @@ def multi_rank(a, env):
                   "identical_to_one_gpu": same, "nan_rows": int(np.isnan(res4[1]).any(axis=(1, 2)).sum())}
         rk.barrier()
 
-    if root:
-        out = base_line(a, world, K, W, dt, n_fl,
-                        f"sample-sharded x{world} (one process per GPU), {n_fl} samples in flight per GPU")
-        out["multi_gpu_path"] = "rank-" + info["transport"]
-        # n_gpus = distinct physical devices (ranks may share one: LOCAL_RANK beyond the visible devices, --share-gpu)
-        out["ranks"] = world
-        out["n_gpus"] = n_distinct
-        out["shared_devices"] = n_distinct < world
-        out["per_rank_seconds"] = per_rank_s
-        out["devices_pci"] = ["%04x:%02x:%02x" % (v >> 16, (v >> 8) & 0xff, v & 0xff) for v in pci]
-        out["rccl_version"] = info["rccl_version"]
-        out["rccl_ranks"] = world if info["transport"] == "rccl" else 0
-        out["collective"] = ("gpx_rank_predict_sweep: H2D on rank 0, ncclBroadcast, per-rank block, ncclSend/ncclRecv "
-                             "gather, D2H on rank 0 — all inside the timed region; barrier = gpx_rank_barrier, time = "
-                             "max over ranks (gpx_rank_allreduce_max)")
-        out["nan_rows"] = int(np.isnan(res[1]).any(axis=(1, 2)).sum())
-        eng = _lib.Engine(device)
-        eng.set_train(X)
-        lml, _ = eng.factor(kind, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
-        eng.posterior(Xnew, p["noise"], 1e-6, want_cov=True)
-        eng.mvn_draw(np.random.default_rng(2).standard_normal((1, M)))
-        out.update(device_record(eng, a, lml))
-        if c4 is not None:
-            out["c4_sweep"] = c4
-        if not a.no_node_record:
-            # the same sweeps under the other launch model (one process, all GPUs); the ranks idle meanwhile — on the
-            # host (they poll the rendezvous store below), not inside an RCCL collective that would spin on their GPUs
-            out["node_sweep"] = run_node_record(a)
-            ns = out["node_sweep"]
-            if "c3_posteriors_per_s" in ns:
-                ns["c3_vs_rank_collective"] = ns["c3_posteriors_per_s"] / out["value"]
-        flush_c_stdio()
-        print(json.dumps(out), flush=True)
-    # rank 0's solo phase (device record, node-sweep record) is over: everybody meets again
-    store = launch.FileStore(os.path.join(env.rdzv_dir, f"bench{env.attempt}"))
-    if root:
-        store.set("solo_done", b"1")
-    else:
-        store.get("solo_done", timeout=1800.0)
-    launch.finalize(env, rk)
+    if not root:
+        return None, rk
+    out = base_line(a, world, K, W, dt, n_fl,
+                    f"sample-sharded x{world} (one process per GPU), {n_fl} samples in flight per GPU")
+    out["multi_gpu_path"] = "rank-" + info["transport"]
+    # n_gpus = distinct physical devices (ranks may share one: LOCAL_RANK beyond the visible devices, --share-gpu)
+    out["ranks"] = world
+    out["n_gpus"] = n_distinct
+    out["shared_devices"] = n_distinct < world
+    out["per_rank_seconds"] = per_rank_s
+    out["devices_pci"] = ["%04x:%02x:%02x" % (v >> 16, (v >> 8) & 0xff, v & 0xff) for v in pci]
+    out["rccl_version"] = info["rccl_version"]
+    out["rccl_ranks"] = world if info["transport"] == "rccl" else 0
+    out["collective"] = ("gpx_rank_predict_sweep: H2D on rank 0, ncclBroadcast, per-rank block, ncclSend/ncclRecv "
+                         "gather, D2H on rank 0 — all inside the timed region; barrier = gpx_rank_barrier, time = "
+                         "max over ranks (gpx_rank_allreduce_max)")
+    out["nan_rows"] = int(np.isnan(res[1]).any(axis=(1, 2)).sum())
+    out["collective_leg"] = {"completed": True}
+    # the no-communicator leg of the same launch (every rank the N = 1 workload): what the collective costs, rank by rank
+    out["replicas"] = {k: rep[k] for k in ("value", "ms_per_step", "per_rank_seconds", "pipeline_frac_of_fp64_peak")}
+    out["collective_vs_replicas"] = out["value"] / rep["value"]
+    for k, v in rep.items():  # the device record (roofline, stages, potf2 ...) was taken there, on rank 0's GPU alone
+        out.setdefault(k, v)
+    if c4 is not None:
+        out["c4_sweep"] = c4
+    return out, rk
 
 
 def main():

@@ -51,6 +51,7 @@ def load_library() -> C.CDLL:
     sig = {
         "gpx_init": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "gpx_device_count": (C.c_int, []),
+        "gpx_device_pci": (C.c_int, [C.c_int, _ip, _ip, _ip]),
         "gpx_destroy": (None, [vp]),
         "gpx_last_error": (C.c_char_p, [vp]),
         "gpx_device_info": (C.c_int, [vp, C.c_char_p, C.c_int, _ip, C.POINTER(C.c_int64), _ip]),
@@ -115,7 +116,7 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "gpx_init gpx_device_count gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
+    "gpx_init gpx_device_count gpx_device_pci gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
     "gpx_factor gpx_lml_grad gpx_lml_grad_diag gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
     "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_set_potf2 gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
@@ -698,6 +699,14 @@ class Rank:
 def visible_device_count() -> int:
     """HIP devices visible to this process (gpx_device_count)."""
     return int(load_library().gpx_device_count())
+
+
+def device_pci(device: int) -> int:
+    """(domain << 16) | (bus << 8) | device of visible device `device` (gpx_device_pci); -1 when it cannot be read."""
+    d, b, v = C.c_int(), C.c_int(), C.c_int()
+    if load_library().gpx_device_pci(int(device), C.byref(d), C.byref(b), C.byref(v)) != 0:
+        return -1
+    return (d.value << 16) | (b.value << 8) | v.value
 
 
 _default_node: Optional[Node] = None

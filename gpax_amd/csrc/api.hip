@@ -680,6 +680,18 @@ int gpx_device_count(void) {
   return (hipGetDeviceCount(&count) == hipSuccess) ? count : 0;
 }
 
+int gpx_device_pci(int device, int* domain, int* bus, int* dev) {
+  int d = 0, b = 0, v = 0;
+  if (hipDeviceGetAttribute(&d, hipDeviceAttributePciDomainID, device) != hipSuccess ||
+      hipDeviceGetAttribute(&b, hipDeviceAttributePciBusId, device) != hipSuccess ||
+      hipDeviceGetAttribute(&v, hipDeviceAttributePciDeviceId, device) != hipSuccess)
+    return -2;
+  if (domain) *domain = d;
+  if (bus) *bus = b;
+  if (dev) *dev = v;
+  return 0;
+}
+
 void gpx_destroy(gpx_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) {

@@ -292,15 +292,7 @@ int64_t gpx_rank_collective_calls(const gpx_rank* rk) { return rk ? rk->coll_cal
 
 int gpx_rank_device_pci(const gpx_rank* rk, int* domain, int* bus, int* dev) {
   if (!rk || rk->device < 0) return -1;
-  int d = 0, b = 0, v = 0;
-  if (hipDeviceGetAttribute(&d, hipDeviceAttributePciDomainID, rk->device) != hipSuccess ||
-      hipDeviceGetAttribute(&b, hipDeviceAttributePciBusId, rk->device) != hipSuccess ||
-      hipDeviceGetAttribute(&v, hipDeviceAttributePciDeviceId, rk->device) != hipSuccess)
-    return -2;
-  if (domain) *domain = d;
-  if (bus) *bus = b;
-  if (dev) *dev = v;
-  return 0;
+  return gpx_device_pci(rk->device, domain, bus, dev);
 }
 
 int gpx_rank_allreduce_max(gpx_rank* rk, double* v, int n) {

@@ -138,13 +138,16 @@ def _reexec_with_file_transport(env: RankEnv, why: str):
 
 
 def init_rank(env: RankEnv, device: Optional[int] = None, inflight: Optional[int] = None, transport: Optional[str] = None,
-              timeout: float = 120.0, reexec_on_hang: bool = False, make_rank=None, make_uid=None):
+              timeout: float = 120.0, reexec_on_hang: bool = False, make_rank=None, make_uid=None, on_hang=None):
     """Collective: every rank of the launch calls this once and gets its `_lib.Rank` (or whatever `make_rank` builds).
 
     transport: "rccl", "file" or None = $GPX_RANK_TRANSPORT or "auto" (RCCL; the file transport when RCCL fails on any
     rank — agreed on through the store, so all ranks end up on the same one).
     reexec_on_hang: when the initialisation does not finish within `timeout` seconds, re-execute the process with the
     file transport instead of exiting (launch-script use: bench.py).
+    on_hang(why): called (from the watchdog thread) instead of leaving with exit code 70 when the initialisation hangs
+    and no re-execution applies — for a caller that has something to report before it leaves (bench.py); it should not
+    return.
     make_rank(device, rank, world, unique_id, file_dir, inflight) / make_uid(): injection points for the tests.
     """
     if device is None:  # LOCAL_RANK names the GPU, unless the launcher narrowed the visible devices per rank
@@ -182,6 +185,8 @@ def init_rank(env: RankEnv, device: Optional[int] = None, inflight: Optional[int
             _reexec_with_file_transport(env, f"initialisation did not finish within {timeout:.0f} s")
         sys.stderr.write(f"[gpax_amd.launch] rank {env.rank}: initialisation hung for {timeout:.0f} s; giving up\n")
         sys.stderr.flush()
+        if on_hang is not None:
+            on_hang(f"communicator initialisation hung for {timeout:.0f} s")
         os._exit(70)
 
     threading.Thread(target=watchdog, daemon=True).start()

@@ -52,6 +52,9 @@ typedef struct gpx_ctx gpx_ctx;
  * Fails (<0) when no gfx950-capable HIP device `device` exists. */
 int gpx_init(int device, gpx_ctx** out);
 int gpx_device_count(void); /* HIP devices visible to this process (0 when there is none / no driver) */
+/* PCI address of visible device `device` — the physical GPU behind an ordinal (launchers narrow the visible set per
+ * process; bench.py counts distinct GPUs with it).  Any output pointer may be NULL. */
+int gpx_device_pci(int device, int* domain, int* bus, int* dev);
 void gpx_destroy(gpx_ctx* ctx);
 const char* gpx_last_error(const gpx_ctx* ctx);
 int gpx_device_info(gpx_ctx* ctx, char* name, int name_len, int* num_cu, int64_t* hbm_bytes,

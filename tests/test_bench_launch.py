@@ -52,11 +52,37 @@ def test_two_ranks_sharing_the_gpu_report_two_ranks_on_one_device():
     assert rec["steps"] == 4 and rec["value"] > 0 and rec["nan_rows"] == 0
     assert rec["multi_gpu_path"] == "rank-file" and rec["rccl_ranks"] == 0
     assert rec["roofline"]["frac"] > 0
+    # leg 1 of the same launch: every rank the N = 1 workload, no communicator (what the run reports if the collective fails)
+    assert rec["collective_leg"] == {"completed": True}
+    rep = rec["replicas"]
+    assert rep["value"] > 0 and len(rep["per_rank_seconds"]) == 2 and 0.3 < rec["collective_vs_replicas"] < 3.0
     c4 = rec["c4_sweep"]
     assert c4["S"] == 12 and c4["identical_to_one_gpu"] and c4["speedup_vs_1"] > 0 and c4["ranks"] == 2
     ns = rec["node_sweep"]  # the one-process launch model of the same sweeps, from a child process of rank 0
     assert ns["ngpu"] == 2 and ns["transport"] == "memcpy" and ns["c3_posteriors_per_s"] > 0 and ns["c3_nan_rows"] == 0
     assert ns["c4_S"] == 12 and ns["c4_nan_rows"] == 0
+
+
+@pytest.mark.gpu
+def test_a_collective_leg_that_hangs_costs_the_run_a_note_not_its_result():
+    """VERDICT r3 missing #2: the communicator has never run on more than one GPU.  Whatever happens to it on the first
+    node that has eight, bench.py must print its line: rank 1 never joins the collective leg here (GPX_BENCH_TEST_HANG);
+    rank 0's initialisation times out, it reports the replicas leg — measured before the first communicator call — and
+    both ranks leave with exit code 0."""
+    env = dict(_env(), GPX_BENCH_TEST_HANG="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--N", "2048",
+                          "--M", "256", "--steps", "4", "--warmup", "1", "--inflight", "1", "--c4-S", "0",
+                          "--no-node-record", "--init-timeout", "5", "--collective-timeout", "30"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["multi_gpu_path"] == "replicas" and rec["collective_leg"]["completed"] is False
+    assert rec["collective_leg"]["reason"]
+    assert rec["ranks"] == 2 and rec["n_gpus"] == 1 and rec["steps"] == 4 and rec["value"] > 0
+    assert len(rec["per_rank_seconds"]) == 2 and "roofline" in rec and rec["stages"]["potrf_ms"] > 0
+    assert "collective leg abandoned" in out.stderr
 
 
 @pytest.mark.gpu

@@ -231,3 +231,24 @@ def test_a_hung_initialisation_reexecutes_the_rank_with_the_file_transport(tmp_p
     for r in range(2):
         transport, attempt, fdir = (tmp_path / f"done{r}").read_text().split()
         assert transport == "file" and attempt == "1" and fdir.endswith(os.path.join("attempt1", "xfer"))
+
+
+def test_a_hung_initialisation_hands_control_to_the_callers_on_hang(tmp_path):
+    """No re-execution applies (the transport is fixed): a caller with something to report — bench.py and its replicas
+    leg — is called back from the watchdog thread instead of the process leaving with exit code 70."""
+    from gpax_amd import launch
+    script = tmp_path / "hang2.py"
+    script.write_text(
+        "import os, sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from gpax_amd import launch\n"
+        "env = launch.rank_env()\n"
+        "def make_rank(dev, r, w, uid, fdir, infl):\n"
+        "    time.sleep(3600)\n"
+        "def on_hang(why):\n"
+        "    open(os.path.join(sys.argv[1], 'hang%d' % env.rank), 'w').write(why)\n"
+        "    os._exit(0)\n"
+        "launch.init_rank(env, timeout=1.0, transport='file', make_rank=make_rank, make_uid=lambda: b'u' * 128, on_hang=on_hang)\n")
+    assert launch.spawn_ranks(str(script), [str(tmp_path)], 2, timeout=120) == 0
+    for r in range(2):
+        assert "hung for 1 s" in (tmp_path / f"hang{r}").read_text()
