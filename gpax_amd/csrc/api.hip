@@ -651,7 +651,7 @@ int gpx_init(int device, gpx_ctx** out) {
     }
     if (const char* e = getenv("GPX_OUTER_TILES")) {
       const int ot = atoi(e);
-      if (ot >= 1 && ot <= 32) {
+      if (ot >= 1 && ot <= 128) {
         ctx->outer_tiles = ot;
         ctx->outer_tiles_set = true;
       }

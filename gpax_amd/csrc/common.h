@@ -17,10 +17,13 @@ constexpr int GPX_TILE_COUNTERS = 1024;
 constexpr int TILE = 128;      // MFMA GEMM block tile and diagonal-block size
 constexpr int OUTER_TILES = 4; // default outer blocking of the right-looking sweeps (4*128 = 512); ctx->outer_tiles
 // A single-sample Cholesky of up to this many tile rows runs as ONE outer block (plain right-looking, K = 128 updates of
-// everything to the right, one stream): up to N = 4096 the look-ahead's cross-stream waits and the chain work it puts
+// everything to the right, one stream): up to N = 5120 the look-ahead's cross-stream waits and the chain work it puts
 // BEFORE the next diagonal block cost more than its larger K returns (round 4, one box: potrf N = 1024 0.439 -> 0.377 ms,
-// 2048 0.950 -> 0.812, 4096 2.207 -> 1.995).  Batched sweeps keep the blocked schedule: B times the update, GEMM-bound.
-constexpr int ONE_BLOCK_TILES = 32;
+// 2048 0.950 -> 0.812, 4096 2.207 -> 1.995, 5120 2.96 -> 2.88; 6144 3.90 -> 4.00: the blocked schedule from there on).
+// Batched sweeps keep the blocked schedule: B times the update, GEMM-bound.  FINISH_...: the END of a larger
+// factorisation is finished the same way once no more rows than this are left (linalg.hip; N = 8192 potrf -1 %).
+constexpr int ONE_BLOCK_TILES = 40;
+constexpr int FINISH_ONE_BLOCK_TILES = 32;
 constexpr double AUG_BIG = 1e300;
 constexpr double SQRT5 = 2.23606797749978969641;
 constexpr double MATERN_EPS = 1e-12; // gpax/kernels/kernels.py:20-21

@@ -187,12 +187,12 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
   for (int k = 0; k < nouter && rc >= 0; ++k) {
     const int ob = ob_of(k), oe = ob_of(k + 1);
     const int gs = gfirst[(size_t)k], ge = glast[(size_t)k];
-    // The END of a large single-sample factorisation is a mid-size one: once no more than ONE_BLOCK_TILES tile rows are
+    // The END of a large single-sample factorisation is a mid-size one: once no more than FINISH_ONE_BLOCK_TILES tile rows are
     // left and block k starts a group (its columns have every update from the blocks before it through the U1
     // launches, the columns behind it through the far updates issued so far), the rest runs as one outer block on the
     // panel stream, behind whatever the main stream still has in flight — as a factorisation of that size would.
-    if (k > 0 && k == gs && !ctx->outer_tiles_set && bs.batch == 1 && nblk - ob <= ONE_BLOCK_TILES &&
-        nblk - ob + extra_tiles <= ONE_BLOCK_TILES + 8) {
+    if (k > 0 && k == gs && !ctx->outer_tiles_set && bs.batch == 1 && nblk - ob <= FINISH_ONE_BLOCK_TILES &&
+        nblk - ob + extra_tiles <= FINISH_ONE_BLOCK_TILES + 8) {
       GPX_HIP(ctx, hipEventRecord(ctx->evD, smain));
       GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evD, 0));
       ctx->s = span;

@@ -38,9 +38,9 @@ def test_gpus_1_does_not_relaunch():
 
 @pytest.mark.gpu
 def test_two_ranks_sharing_the_gpu_report_two_ranks_on_one_device():
-    # (N = 5120: 40 tile rows, the smallest size whose factorisation has trailing-update launches — the roofline's
-    # kernel; up to N = 4096 a single-sample Cholesky runs as one outer block, common.h ONE_BLOCK_TILES)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--N", "5120",
+    # (N = 6144: 48 tile rows — a factorisation with trailing-update launches, the roofline's kernel; up to 40 tile
+    # rows a single-sample Cholesky runs as one outer block, common.h ONE_BLOCK_TILES)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--N", "6144",
                           "--M", "256", "--steps", "4", "--warmup", "1", "--inflight", "1", "--c4-S", "12", "--c4-N",
                           "1024"], capture_output=True, text=True, env=_env(), timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
