@@ -22,10 +22,11 @@ N > 1: one process per GPU, NO PyTorch (RANK / LOCAL_RANK / WORLD_SIZE set by th
      gpax_amd/launch.py) and the timed region is ONE gpx_rank_predict_sweep over S = N * K theta samples: rank 0's H2D
      of the inputs, ncclBroadcast over xGMI, every rank's block of K samples, ncclSend / ncclRecv gather, D2H on rank 0 —
      bracketed by a barrier on both sides (gpx_rank_barrier: own contexts synchronised + all-reduce), time = max over
-     ranks (gpx_rank_allreduce_max).  `value` is THIS leg's (the product's multi-GPU call, host arrays in and out); the
-     first leg's is reported beside it (`replicas`, `collective_vs_replicas`).  Should the leg fail or not finish within
-     --collective-timeout seconds, rank 0 prints the replicas line (`multi_gpu_path` "replicas", `collective_leg` says
-     why) and the run still has its measurement.
+     ranks (gpx_rank_allreduce_max).  This is the product's multi-GPU call with host arrays in and out, i.e. a PCIe- and
+     xGMI-inclusive rate: it is reported as the `collective` record, never as `value` — `value` is leg 1's (inputs
+     resident in HBM when the timed region starts, as at N = 1).  Should the leg fail or not finish within
+     --collective-timeout seconds, the line says so (`multi_gpu_path` "replicas", `collective_leg` = why) and the run
+     still has its measurement.
 A second record, `c4_sweep`, times BASELINE.json configs[3] (S = 1000, N = 8192, d = 3) through the collective and
 against rank 0 alone; a third, `node_sweep`, times both sweeps under the other launch model (ONE process owning all N
 GPUs, gpx_predict_sweep_multi) from a child process of rank 0.  `multi_gpu_path`: "rank-rccl"; "rank-file" = the
@@ -328,8 +329,7 @@ def base_line(a, world, K, W, dt, n_fl, parallelism):
         "data": "synthetic",
         "config": {"workload": f"C3: ExactGP {a.kernel} N={N} d={d} M={M}, 1 MVN draw per theta sample "
                                "(BASELINE.json configs[2]); theta samples sharded over the GPUs, "
-                               + ("inputs resident in HBM" if world == 1 else
-                                  "inputs broadcast from rank 0 and results gathered there inside the timed region"),
+                               "inputs resident in HBM",
                    "parallelism": parallelism},
         "inflight_per_gpu": n_fl,
         "pipeline_tflops": world * post_flops / (dt / K) / 1e12,
@@ -556,8 +556,6 @@ def replicas_leg(a, env, device):
         n_distinct = len(set(pci))
         out = base_line(a, world, K, W, dt, rb.n_fl,
                         f"sample-sharded x{world} (one process per GPU), {rb.n_fl} samples in flight per GPU")
-        out["config"]["workload"] = out["config"]["workload"].replace(
-            "inputs broadcast from rank 0 and results gathered there inside the timed region", "inputs resident in HBM")
         out["multi_gpu_path"] = "replicas"
         out["ranks"] = world
         out["n_gpus"] = n_distinct  # distinct physical devices (ranks may share one: --share-gpu, LOCAL_RANK beyond the visible set)
@@ -631,7 +629,7 @@ def multi_rank(a, env):
             out["node_sweep"] = run_node_record(a)
             ns = out["node_sweep"]
             if "c3_posteriors_per_s" in ns:
-                ns["c3_vs_rank_collective"] = ns["c3_posteriors_per_s"] / out["value"]
+                ns["c3_vs_rank_collective"] = ns["c3_posteriors_per_s"] / out["collective"]["value"]
         flush_c_stdio()
         print(json.dumps(out), flush=True)
         store.set("solo_done", b"1")  # rank 0's solo phase is over: everybody meets again
@@ -643,7 +641,7 @@ def multi_rank(a, env):
 def collective_leg(a, env, device, transport, rep, on_hang=None):
     """N > 1, SECOND leg: the library's own communicator (gpx_rank_*: RCCL, or the file transport when RCCL cannot
     initialise) and ONE collective gpx_rank_predict_sweep over S = N * K theta samples as the timed region.  Returns rank
-    0's final line: `value` from this leg, the replicas leg's under `replicas`."""
+    0's final line: the replicas leg's, with this leg's rate under `collective`."""
     from bench_inputs import synthetic_problem, synthetic_theta_samples
     from gpax_amd import _lib, launch
 
@@ -734,27 +732,22 @@ def collective_leg(a, env, device, transport, rep, on_hang=None):
 
     if not root:
         return None, rk
-    out = base_line(a, world, K, W, dt, n_fl,
-                    f"sample-sharded x{world} (one process per GPU), {n_fl} samples in flight per GPU")
+    # `value` stays the replicas leg's: inputs resident in HBM when the timed region starts, the N = 1 workload on every
+    # GPU (the contract of this file's docstring).  The collective — host arrays in on rank 0, host arrays out — is the
+    # PCIe- and xGMI-inclusive rate of the product's multi-GPU call, reported beside it.
+    out = dict(rep)
     out["multi_gpu_path"] = "rank-" + info["transport"]
-    # n_gpus = distinct physical devices (ranks may share one: LOCAL_RANK beyond the visible devices, --share-gpu)
-    out["ranks"] = world
-    out["n_gpus"] = n_distinct
-    out["shared_devices"] = n_distinct < world
-    out["per_rank_seconds"] = per_rank_s
-    out["devices_pci"] = ["%04x:%02x:%02x" % (v >> 16, (v >> 8) & 0xff, v & 0xff) for v in pci]
     out["rccl_version"] = info["rccl_version"]
     out["rccl_ranks"] = world if info["transport"] == "rccl" else 0
-    out["collective"] = ("gpx_rank_predict_sweep: H2D on rank 0, ncclBroadcast, per-rank block, ncclSend/ncclRecv "
-                         "gather, D2H on rank 0 — all inside the timed region; barrier = gpx_rank_barrier, time = "
-                         "max over ranks (gpx_rank_allreduce_max)")
-    out["nan_rows"] = int(np.isnan(res[1]).any(axis=(1, 2)).sum())
     out["collective_leg"] = {"completed": True}
-    # the no-communicator leg of the same launch (every rank the N = 1 workload): what the collective costs, rank by rank
-    out["replicas"] = {k: rep[k] for k in ("value", "ms_per_step", "per_rank_seconds", "pipeline_frac_of_fp64_peak")}
-    out["collective_vs_replicas"] = out["value"] / rep["value"]
-    for k, v in rep.items():  # the device record (roofline, stages, potf2 ...) was taken there, on rank 0's GPU alone
-        out.setdefault(k, v)
+    out["collective"] = {
+        "what": ("gpx_rank_predict_sweep over S = ranks x steps theta samples: H2D on rank 0, ncclBroadcast, per-rank block, "
+                 "ncclSend/ncclRecv gather, D2H on rank 0 — all inside the timed region; barrier = gpx_rank_barrier, time = "
+                 "max over ranks (gpx_rank_allreduce_max)"),
+        "value": world * K / dt, "unit": "posteriors/s", "ms_per_step": dt / K * 1e3, "per_rank_seconds": per_rank_s,
+        "vs_replicas": (world * K / dt) / rep["value"], "transport": info["transport"], "n_gpus": n_distinct,
+        "devices_pci": ["%04x:%02x:%02x" % (v >> 16, (v >> 8) & 0xff, v & 0xff) for v in pci],
+        "nan_rows": int(np.isnan(res[1]).any(axis=(1, 2)).sum())}
     if c4 is not None:
         out["c4_sweep"] = c4
     return out, rk

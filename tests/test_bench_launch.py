@@ -48,14 +48,16 @@ def test_two_ranks_sharing_the_gpu_report_two_ranks_on_one_device():
     rec = json.loads(line)
     # n_gpus counts distinct physical devices (by PCI address), `ranks` the processes
     assert rec["ranks"] == 2 and rec["n_gpus"] == 1 and rec["shared_devices"] is True and len(rec["devices_pci"]) == 2
+    # `value`: the replicas leg — every rank the N = 1 workload on resident inputs, no communicator
     assert len(rec["per_rank_seconds"]) == 2 and all(0 < t <= rec["ms_per_step"] * rec["steps"] / 1e3 * 1.5 for t in rec["per_rank_seconds"])
-    assert rec["steps"] == 4 and rec["value"] > 0 and rec["nan_rows"] == 0
+    assert rec["steps"] == 4 and rec["value"] > 0
     assert rec["multi_gpu_path"] == "rank-file" and rec["rccl_ranks"] == 0
     assert rec["roofline"]["frac"] > 0
-    # leg 1 of the same launch: every rank the N = 1 workload, no communicator (what the run reports if the collective fails)
+    # the collective leg (the product's sharded sweep, host arrays in and out) beside it
     assert rec["collective_leg"] == {"completed": True}
-    rep = rec["replicas"]
-    assert rep["value"] > 0 and len(rep["per_rank_seconds"]) == 2 and 0.3 < rec["collective_vs_replicas"] < 3.0
+    col = rec["collective"]
+    assert col["value"] > 0 and len(col["per_rank_seconds"]) == 2 and col["nan_rows"] == 0 and 0.3 < col["vs_replicas"] < 3.0
+    assert col["transport"] == "file" and col["n_gpus"] == 1
     c4 = rec["c4_sweep"]
     assert c4["S"] == 12 and c4["identical_to_one_gpu"] and c4["speedup_vs_1"] > 0 and c4["ranks"] == 2
     ns = rec["node_sweep"]  # the one-process launch model of the same sweeps, from a child process of rank 0
