@@ -545,7 +545,12 @@ def replicas_leg(a, env, device):
     rb = ResidentBench(a, device, first_theta=rank * (K + W), n_theta=K + W)
     rb.warm()
     st.set(f"ready.{rank}", b"1")
-    st.gather("ready", world, 1800.0)
+    if rank == 0:  # everybody is ready: a common start time on the system-wide monotonic clock (the store is polled in
+        st.gather("ready", world, 1800.0)  # steps of up to 20 ms — too coarse a start line for a region of ~0.5 s)
+        st.set("go", repr(time.monotonic() + 0.2).encode())
+    t_go = float(st.get("go", 1800.0))
+    while time.monotonic() < t_go:
+        pass
     dt_own, t0, t1, ev_ms = rb.timed()
     st.set(f"t.{rank}", json.dumps([t0, t1, _lib.device_pci(device)]).encode())
     out = None
