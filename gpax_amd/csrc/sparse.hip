@@ -453,17 +453,20 @@ static int solve_by_inverse(gpx_ctx* ctx, const double* B, int64_t ldb, int rows
 
 using namespace gpx;
 
-// H = a * Ainv + b * Acopy + dval * I   (n x n, full)
+// C = a * A + (b0 + b1 u) * B + (d0 + d1 u) * I   (n x n, full; B may be null), u = [thresh - flag[0] > 0]: the
+// bound's clipped-trace switch (jnp.clip(trace_term, a_min=0)) decided ON THE DEVICE from the reduced |W|_F^2 in flag[0]
+// — the gradient's launches follow the forward pass without a host round trip in between.
 __global__ __launch_bounds__(256) void mat_combine_kernel(double* __restrict__ C, int64_t ldc, double a,
-                                                          const double* __restrict__ A, int64_t lda, double b,
-                                                          const double* __restrict__ B, int64_t ldb, double dval,
-                                                          int n) {
+                                                          const double* __restrict__ A, int64_t lda, double b0, double b1,
+                                                          const double* __restrict__ B, int64_t ldb, double d0, double d1,
+                                                          const double* __restrict__ flag, double thresh, int n) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int i = blockIdx.y;
   if (j < n) {
+    const double u = (thresh - flag[0] > 0.0) ? 1.0 : 0.0;
     double v = a * A[(int64_t)i * lda + j];
-    if (B) v += b * B[(int64_t)i * ldb + j];
-    if (i == j) v += dval;
+    if (B) v += (b0 + b1 * u) * B[(int64_t)i * ldb + j];
+    if (i == j) v += d0 + d1 * u;
     C[(int64_t)i * ldc + j] = v;
   }
 }
@@ -481,6 +484,7 @@ struct SgpState {
   // yres, X): predict_in_batches calls gpx_sgp_posterior once per slice of X_new with everything else unchanged
   // (sparse_gp.py:173-223 recomputes Kuu, Kuf and both factorisations for every slice).
   bool fwd_valid = false, reuse = false;
+  hipEvent_t evFork = nullptr, evJoin = nullptr; // the Kfu Gram build on the panel stream beside the Cholesky of Kuu
   int npartW = 0; // partial sums of |W|_F^2 left in `part` by the forward pass
   uint64_t h_train_gen = 0;
   int h_kind = -1;
@@ -502,6 +506,8 @@ void sgp_release(gpx_ctx* ctx) {
                     &s->rcoef_u, &s->rcoef_f, &s->gxu_part, &s->cpart, &s->gXu, &s->T1a, &s->T1, &s->Xs, &s->V1,
                     &s->V2, &s->mean, &s->var, &s->var2, &s->Cov, &s->Vu, &s->VA, &s->Tscr, &s->Kfu};
   for (DevBuf* b : bufs) b->release();
+  if (s->evFork) (void)hipEventDestroy(s->evFork);
+  if (s->evJoin) (void)hipEventDestroy(s->evJoin);
   delete s;
   ctx->sgp = nullptr;
 }
@@ -587,6 +593,22 @@ static int sgp_forward_run(gpx_ctx* ctx, SgpState* s) {
   GPX_TRY(ens(ctx, s->part, (size_t)((Ntp / 32) * (Mp / 32) + Mp / 8 + 32) * 8));
   int* dinfo = s->scal.i() + 1024;
   GPX_HIP(ctx, hipMemsetAsync(dinfo, 0, 2 * sizeof(int), ctx->stream));
+  if (ctx->sgp_inverse) {
+    // Kfu = k(X, Xu) waits for nothing of the Kuu branch: on the panel stream, beside the latency-bound Cholesky chain
+    // of Kuu (a 16-step chain at M = 2048 that leaves the chip idle), joined again before the solve that reads it
+    if (!s->evFork) {
+      GPX_HIP(ctx, hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming));
+      GPX_HIP(ctx, hipEventCreateWithFlags(&s->evJoin, hipEventDisableTiming));
+    }
+    GPX_TRY(ens(ctx, s->Kfu, (size_t)Ntp * s->ldw * 8));
+    GPX_HIP(ctx, hipEventRecord(s->evFork, ctx->stream)); // Xu, X, theta are in place
+    GPX_HIP(ctx, hipStreamWaitEvent(ctx->pstream, s->evFork, 0));
+    ctx->s = ctx->pstream;
+    const int rc_kfu = launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->Kfu.d(), s->ldw);
+    ctx->s = ctx->stream;
+    GPX_TRY(rc_kfu);
+    GPX_HIP(ctx, hipEventRecord(s->evJoin, ctx->pstream));
+  }
   // Kuu = kernel(Xu, Xu, params, **jitter): noise defaults to 0 (sparse_gp.py:92)
   GPX_TRY(launch_gram_padded(ctx, s->kp, s->Xu.d(), M, Mp, s->Xu.d(), M, Mp, s->jitter, 1, 1, s->Kuu.d(), s->ldu));
   GPX_TRY(launch_pad_identity(ctx, s->Kuu.d(), s->ldu, M, Mp));
@@ -596,9 +618,8 @@ static int sgp_forward_run(gpx_ctx* ctx, SgpState* s) {
     GPX_TRY(ens(ctx, s->B0, mm));
     GPX_TRY(ens(ctx, s->Vu, mm));
     GPX_TRY(ens(ctx, s->Tscr, mm));
-    GPX_TRY(ens(ctx, s->Kfu, (size_t)Ntp * s->ldw * 8));
     GPX_TRY(build_linv_t(ctx, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, s->B0.d(), s->ldu, s->Tscr.d(), s->Vu.d())); // Tu, Luu^-1
-    GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->Kfu.d(), s->ldw));
+    GPX_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->evJoin, 0)); // Kfu (built on the panel stream, above)
     GPX_TRY(solve_by_inverse(ctx, s->Kfu.d(), s->ldw, ntl, s->Vu.d(), s->ldu, mt, s->Wn.d(), s->ldw));
   } else {
     GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->Wn.d(), s->ldw));
@@ -693,24 +714,32 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
                                                ctx->yres.d(), 0, nullptr, sc + 8);
   GPX_HIP(ctx, hipGetLastError());
   double h[16];
-  GPX_HIP(ctx, hipMemcpyAsync(h, sc, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   int bad = 0;
-  GPX_TRY(read_info(ctx, s, &bad));
-  const double wF2 = h[0], sumlogLA = h[1], cc = h[2], yy = h[3], yt = h[4], tt = h[5], trAinv = h[8];
-  const double trace_raw = N * kd - wF2;
-  const bool unclipped = trace_raw > 0.0; // jnp.clip(trace_term, a_min=0): zero value AND zero gradient when clipped
-  if (info) *info = bad;
-  if (bound) {
-    *bound = bad ? NAN
-                 : (-0.5 * N * 1.83787706640934548356 - 0.5 * N * std::log(s2) - sumlogLA - 0.5 * yy / s2 +
-                    0.5 * cc - (unclipped ? 0.5 * trace_raw / s2 : 0.0));
-  }
-  if (!want_grad) return 0;
+  double wF2 = 0.0, yy = 0.0, yt = 0.0, tt = 0.0, trAinv = 0.0, trace_raw = 0.0;
+  bool unclipped = false;
+  // The reduced scalars and the pivot reports reach the host with ONE synchronisation: right here for a bound-only call,
+  // behind the gradient's launches otherwise — those need nothing from the host (the clipped-trace switch is evaluated
+  // on the device, mat_combine_kernel), so they queue up behind the forward pass without a round trip in between.
+  auto fetch_scalars = [&]() -> int {
+    GPX_HIP(ctx, hipMemcpyAsync(h, sc, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GPX_TRY(read_info(ctx, s, &bad));
+    const double sumlogLA = h[1], cc = h[2];
+    wF2 = h[0], yy = h[3], yt = h[4], tt = h[5], trAinv = h[8];
+    trace_raw = N * kd - wF2;
+    unclipped = trace_raw > 0.0; // jnp.clip(trace_term, a_min=0): zero value AND zero gradient when clipped
+    if (info) *info = bad;
+    if (bound) {
+      *bound = bad ? NAN
+                   : (-0.5 * N * 1.83787706640934548356 - 0.5 * N * std::log(s2) - sumlogLA - 0.5 * yy / s2 +
+                      0.5 * cc - (unclipped ? 0.5 * trace_raw / s2 : 0.0));
+    }
+    return 0;
+  };
+  if (!want_grad) return fetch_scalars();
 
   // ---- matrix adjoints in whitened form ------------------------------------------------------
   //   G_uu  = Tu H Tu^T - m m^T / (2 s2^2),   H = -Ainv/2 + (1/2 + [u]/2) I - [u] A/2
   //   G_uf^T = W (Tu R)^T + rcoef_f m^T,        R = ([u] I - Ainv)/s2,  rcoef_f = y/s2^2 - t/s2^3
-  const double uu = unclipped ? 1.0 : 0.0;
   double* Tu = s->B0.d();
   double* TA = s->B1.d();
   double* Ainv = s->B2.d();
@@ -726,10 +755,11 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
       symmetrize_kernel<<<gs, 256, 0, ctx->s>>>(Ainv, s->ldu, Mp);
     }
     // H -> B3 ; R -> B4
-    mat_combine_kernel<<<gs, 256, 0, ctx->s>>>(s->B3.d(), s->ldu, -0.5, Ainv, s->ldu, -0.5 * uu, s->Acopy.d(),
-                                               s->ldu, 0.5 + 0.5 * uu, Mp);
-    mat_combine_kernel<<<gs, 256, 0, ctx->s>>>(s->B4.d(), s->ldu, -1.0 / s2, Ainv, s->ldu, 0.0, nullptr, 0, uu / s2,
-                                               Mp);
+    // ([u] = 1 unless the trace term is clipped: N kd - |W|_F^2 > 0, with |W|_F^2 = sc[0] reduced above)
+    mat_combine_kernel<<<gs, 256, 0, ctx->s>>>(s->B3.d(), s->ldu, -0.5, Ainv, s->ldu, 0.0, -0.5, s->Acopy.d(), s->ldu,
+                                               0.5, 0.5, sc, N * kd, Mp);
+    mat_combine_kernel<<<gs, 256, 0, ctx->s>>>(s->B4.d(), s->ldu, -1.0 / s2, Ainv, s->ldu, 0.0, 0.0, nullptr, 0, 0.0,
+                                               1.0 / s2, sc, N * kd, Mp);
     GPX_HIP(ctx, hipGetLastError());
   }
   { // E1 = Tu H -> B2 (Ainv dead) ; G0 = E1 Tu^T -> B3 (H dead after E1)
@@ -794,7 +824,8 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
     GPX_TRY(launch_axpby(ctx, s->rcoef_f.d(), -1.0 / s2, ctx->yres.d(), 1.0 / (s2 * s2), s->tvec.d(), N));
     GPX_HIP(ctx, hipMemcpyAsync(dyres, s->rcoef_f.d(), (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
   }
-  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  GPX_TRY(fetch_scalars()); // (synchronises the stream: everything copied above has arrived)
+  const double uu = unclipped ? 1.0 : 0.0;
   if (grad_ell)
     for (int c = 0; c < d; ++c) grad_ell[c] = hu[c] + hf[c];
   if (grad_scale) *grad_scale = hu[d] + hf[d] - uu * 0.5 * N / s2 * (kd / scale);
