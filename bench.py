@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--cpu-budget-s", type=float, default=150.0,
                     help="budget of the CPU leg; the same-workload sample (one posterior at the bench N) runs when its "
                          "estimate fits, else N is halved")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the records of the other BASELINE configs "
+                    "(C1, C2, C4, C5: bench_configs.py)")
+    ap.add_argument("--configs-timeout", type=float, default=240.0, help="seconds the configs child process may take")
     ap.add_argument("--dry-launch", action="store_true",
                     help="print the launch bench.py --gpus N performs when started without a launcher, and exit")
     return ap.parse_args()
@@ -208,14 +211,14 @@ def potf2_record(eng, a):
     """The diagonal-block kernel of the blocked Cholesky, so that a slow box explains itself: HIP-event
     time per launch stand-alone (potrf of one 128 x 128 block: nothing else on the chip) and inside this workload's
     pipeline (average over the launches of one predict pass: placement + execution beside the trailing update), for
-    the default kernel and — switched in THIS process and context (gpx_debug_set_potf2; all three give the same bits)
-    — the two it replaced, with the potrf stage time each gives."""
+    the default kernel and — switched in THIS process and context (gpx_debug_set_potf2; both give the same bits)
+    — the round-2 kernel kept as the tests' reference, with the potrf stage time each gives."""
     from gpax_amd import _lib
     rng = np.random.default_rng(0)
     A = rng.standard_normal((128, 128))
     A = A @ A.T + 128 * np.eye(128)
     rec = {"default": "slim", "standalone_us": {}, "in_pipeline_us": {}, "potf2_ms_per_predict": {}, "potrf_ms": {}}
-    for mode in ("chain", "tile", "slim"):  # the default last: the context is left on it
+    for mode in ("tile", "slim"):  # the default last: the context is left on it
         eng.set_potf2(mode)
         for _ in range(3):
             eng.potrf(A)
@@ -234,8 +237,8 @@ def potf2_record(eng, a):
         eng.time_stage(_lib.STAGE_POTRF, 1)
         rec["potrf_ms"][mode] = float(np.median([eng.time_stage(_lib.STAGE_POTRF, 1) for _ in range(3)]))
     rec["note"] = ("slim (csrc/potf2_slim.h): 94 VGPRs / 28 KB LDS, placed at once beside two resident trailing-update "
-                   "workgroups; chain (round 3): 344 VGPRs / 46 KB, waits for a drained CU; tile (round 2): the tests' "
-                   "reference.  in_pipeline = HIP events around each launch on its stream, one theta in flight")
+                   "workgroups; tile (round 2): the tests' reference (round 3's register-resident kernel: "
+                   "tools/exp/potf2_chain.h).  in_pipeline = HIP events around each launch on its stream, one theta in flight")
     return rec
 
 
@@ -437,8 +440,31 @@ class ResidentBench:
         self.engines = self.engines[:1] if keep_first else []
 
 
+def configs_record(a, device=0):
+    """The other BASELINE.json configs (C1, C2, C4, C5), measured live in this run on the same GPU: bench_configs.py as a
+    CHILD process under a time limit, so that whatever happens there costs the headline a note, not its result."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GPX_RDZV_DIR")}
+    if device:
+        env["HIP_VISIBLE_DEVICES"] = str(device)
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench_configs.py")], env=env, capture_output=True,
+                             text=True, timeout=a.configs_timeout)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if out.returncode == 0 and lines:
+            rec = json.loads(lines[-1])
+        else:
+            rec = {"error": f"exit code {out.returncode}", "stderr_tail": out.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        rec = {"error": f"no result within {a.configs_timeout:.0f} s (child stopped)"}
+    rec["child_wall_s"] = time.perf_counter() - t0
+    return rec
+
+
 def single_gpu(a, device=0):
-    """N = 1: K steps of the resident sweep on one GPU, `--inflight` contexts (the round-1/2 headline, unchanged)."""
+    """N = 1: K steps of the resident sweep on one GPU, `--inflight` contexts (the round-1/2 headline, unchanged), then
+    the CPU-baseline leg, then — GPU legs last — the records of the other BASELINE configs (bench_configs.py)."""
     rb = ResidentBench(a, device)
     rb.warm()
     dt, _, _, ev_ms = rb.timed()
@@ -447,8 +473,11 @@ def single_gpu(a, device=0):
     out["event_ms_longest_context"] = ev_ms
     out["multi_gpu_path"] = None
     out.update(device_record(rb.eng, a, rb.lml))
+    rb.close()
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_N or a.N, a.d, a.M, a.kernel, a.cpu_budget_s)
+    if not a.no_configs and (a.N, a.d, a.M) == (16384, 2, 1024):  # the driver's default run; test-sized runs skip it
+        out["configs"] = configs_record(a, device)
     flush_c_stdio()
     print(json.dumps(out), flush=True)
 
@@ -524,7 +553,7 @@ def bench_store(env, name):
     """A key store of THIS launch and attempt under the rendezvous directory (gpax_amd/launch.py: <dir>/<token>/...)."""
     from gpax_amd import launch
 
-    launch._private_dir(env.rdzv_dir)
+    launch._private_dir(env.rdzv_dir, parent=True)
     base = os.path.join(env.rdzv_dir, env.token) if env.token else env.rdzv_dir
     launch._private_dir(base)
     return launch.FileStore(os.path.join(base, f"{name}{env.attempt}"))

@@ -430,8 +430,8 @@ class Engine:
         return b.value
 
     def set_potf2(self, mode: str) -> None:
-        """Diagonal-block kernel of the blocked Cholesky for the following calls: 'slim' (default), 'chain', 'tile' —
-        the same bits from all three (gpx_debug_set_potf2; bench.py's in-process A/B)."""
+        """Diagonal-block kernel of the blocked Cholesky for the following calls: 'slim' (default) or 'tile' —
+        the same bits from both (gpx_debug_set_potf2; bench.py's in-process A/B)."""
         self._check(self._lib.gpx_debug_set_potf2(self._ctx, mode.encode()), "gpx_debug_set_potf2")
 
     def time_stage(self, stage: int, reps: int) -> float:
@@ -797,7 +797,7 @@ def concurrent_sweep(engines: list, X, kind: int, ells, scales, noises, yres, Xn
     # context the hardware favoured finished early and the last samples ran with fewer of them in flight.)  Results do
     # not depend on the split: every sample's arithmetic is independent of its batch.
     lock = threading.Lock()
-    state = {"next": 0, "min": 8}
+    state = {"next": 0, "min": 1}  # "min": the launch batch B once a context has reported it
     pieces: list = []
     err: list = []
 
@@ -809,6 +809,7 @@ def concurrent_sweep(engines: list, X, kind: int, ells, scales, noises, yres, Xn
             left = S - lo
             c = max(state["min"], -(-left // (2 * n)))
             c = -(-c // state["min"]) * state["min"]  # whole launch batches
+            c = min(c, -(-S // n))  # ... but never more than the fair share: every context gets work when S >= n
             hi = min(S, lo + c)
             state["next"] = hi
             return lo, hi

@@ -659,13 +659,15 @@ int gpx_init(int device, gpx_ctx** out) {
     if (const char* e = getenv("GPX_TAIL_TILES")) ctx->tail_tiles = atoi(e);
     GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, lo));
     GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->pstream, hipStreamNonBlocking, hi));
+    GPX_HIP(ctx, hipStreamCreateWithPriority(&ctx->xstream, hipStreamNonBlocking, lo));
     GPX_HIP(ctx, hipEventCreateWithFlags(&ctx->evD, hipEventDisableTiming));
     if (const char* e = getenv("GPX_POTF2")) {
       if (gpx_debug_set_potf2(ctx, e) != 0) return -1;
     }
     if (const char* e = getenv("GPX_SMALL_BK")) ctx->small_bk = (atoi(e) == 32) ? 32 : (atoi(e) == 16 ? 16 : 0);
     if (const char* e = getenv("GPX_LINVT")) ctx->linvt_tree = (std::strcmp(e, "sweep") == 0) ? 0 : 1;
-    if (const char* e = getenv("GPX_SGP_SOLVE")) ctx->sgp_inverse = (std::strcmp(e, "sweep") == 0) ? 0 : 1;
+    if (const char* e = getenv("GPX_SGP_SOLVE"))
+      ctx->sgp_inverse = (std::strcmp(e, "sweep") == 0) ? 0 : ((std::strcmp(e, "inverse") == 0) ? 1 : 2);
     ctx->s = ctx->stream;
   }
   GPX_HIP(ctx, hipEventCreate(&ctx->ev0));
@@ -716,6 +718,7 @@ void gpx_destroy(gpx_ctx* ctx) {
       if (e) (void)hipEventDestroy(e);
     if (ctx->evD) (void)hipEventDestroy(ctx->evD);
     if (ctx->pstream) (void)hipStreamDestroy(ctx->pstream);
+    if (ctx->xstream) (void)hipStreamDestroy(ctx->xstream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   }
   delete ctx;
@@ -1179,9 +1182,8 @@ int gpx_debug_set_potf2(gpx_ctx* ctx, const char* mode) {
   if (!ctx || !mode) return -1;
   const std::string v(mode);
   if (v == "slim") ctx->potf2_mode = gpx::GPX_POTF2_SLIM;
-  else if (v == "chain") ctx->potf2_mode = gpx::GPX_POTF2_CHAIN;
   else if (v == "tile") ctx->potf2_mode = gpx::GPX_POTF2_TILE;
-  else return bad_arg(ctx, "potf2 kernel: slim | chain | tile");
+  else return bad_arg(ctx, "potf2 kernel: slim | tile");
   return 0;
 }
 

@@ -31,7 +31,7 @@ constexpr double MATERN_EPS = 1e-12; // gpax/kernels/kernels.py:20-21
 constexpr int SMALL_BK_ROWS = 40;
 // tile rows below which the single-sample far update of the Cholesky waits for U1 of the same block (linalg.hip)
 constexpr int FAR_AFTER_U1 = 40;
-enum { GPX_POTF2_SLIM = 0, GPX_POTF2_CHAIN = 1, GPX_POTF2_TILE = 2 }; // gpx_ctx::potf2_mode
+enum { GPX_POTF2_SLIM = 0, GPX_POTF2_TILE = 2 }; // gpx_ctx::potf2_mode
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -154,9 +154,11 @@ struct gpx_ctx {
   int device = -1;
   hipStream_t stream = nullptr;  // main stream (API copies, trailing updates)
   hipStream_t pstream = nullptr; // high-priority panel stream (lookahead)
+  hipStream_t xstream = nullptr; // side stream, lowest priority: work with time to spare beside a chain (the L^-T trees of
+                                 // the sparse path while the next factorisation's chain or the tall solve runs; sparse.hip)
   hipStream_t s = nullptr;       // stream the launch helpers currently target
   // diagonal-block kernel (potf2.hip): GPX_POTF2 = slim (default: placed at once beside two resident trailing-update
-  // workgroups) | chain (round 3: all tiles in registers, needs a drained CU) | tile (round 2: the tests' reference)
+  // workgroups) | tile (round 2: the tests' reference)
   int potf2_mode = gpx::GPX_POTF2_SLIM;
   // k-step of the latency shapes: GPX_SMALL_BK = 16 | 32 forces it; default 0 = per driver call (small_bk_now): 32 for
   // SINGLE-SAMPLE sweeps over matrices of up to SMALL_BK_ROWS tile rows — nothing saturates the chip there and the
@@ -194,7 +196,10 @@ struct gpx_ctx {
   gpx::DevBuf K;     // Np x ldk : Gram -> L (lower) -> K^-1 (lower)
   gpx::DevBuf W;     // Np x ldk : L^-T (upper), allocated on first gradient
   gpx::DevBuf Wscr;  // Np x ldk : scratch of the L^-T tree (linalg.hip: T and the transposed C blocks of one level)
-  int sgp_inverse = 1; // GPX_SGP_SOLVE=inverse|sweep: sparse-GP solves with many right-hand sides as GEMMs against L^-1 (sparse.hip)
+  // GPX_SGP_SOLVE = ride (2, default, round 5: W = Kfu Luu^-T as a blocked solve that follows the Cholesky chain of Kuu
+  // group by group, the L^-T trees on the side stream) | inverse (1, round 3 / 4: factor, tree, then ONE GEMM against
+  // Luu^-1) | sweep (0, round 2: right-looking sweeps)  (sparse.hip)
+  int sgp_inverse = 2;
   int linvt_tree = 1; // GPX_LINVT=tree|sweep: L^-T by the block-recursive inverse (default) or the right-looking sweep
   gpx::DevBuf Linv;  // (Np/128) x 128 x 128 inverses of the diagonal blocks of L
   gpx::DevBuf yres;  // N
@@ -352,6 +357,7 @@ struct GemmArgs {
   int batch2;  // > 1: two-level batch — entry = outer * batch2 + inner, at base + outer * *_bs + inner * *_bs2
   int64_t a_bs2, b_bs2, c_bs2;
   int latency_shape; // 1: take the 64 x 64 shapes whatever the tile count (many short, unequal k ranges: split-K of a triangular product)
+  int big_shape;     // 1: take the 128 x 128 throughput shape whatever the tile count (tall operands: 256 tiles of K >= 256 fill the chip once)
 };
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
                    int prof_cls, double work);
@@ -364,6 +370,9 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
 // linalg.hip
 int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,
                 int* dInfo, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0);
+// diagonal blocks kb0 .. kb1-1 of a plain right-looking factorisation of nblk tile rows (potf2 + inverse, panel TRSM, K = 128
+// update of everything to the right), queued on ctx->s: a caller that pipelines other work behind the chain (sparse.hip)
+int potrf_steps(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int kb0, int kb1, double* dLinv, int* dInfo);
 int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_p, const double* dL,
                   int64_t ldl, const double* dLinv, int nblk, int upper_rows, int batch = 1,
                   int64_t b_bs = 0, int64_t l_bs = 0, int64_t linv_bs = 0);

@@ -246,6 +246,7 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   // the panel stream would find no room: everything there takes the shapes that fit next to two resident workgroups
   const bool on_panel = ctx->persist_scope > 0 && ctx->s != ctx->stream;
   constexpr double small_max = 400.0; // launches with fewer 128x128 tiles take the latency shapes (profiles/r02/chain_experiments.md)
+  if (g.big_shape && g.C != g.A && !on_panel) return launch_big<0>(ctx, g, tiles_m, tiles_n, splits);
   if (tiles < small_max || on_panel || g.latency_shape) {
     if (g.C == g.A) { // in-place (panel TRSM): one workgroup must own the whole row width
       // 32x128 strip, single LDS buffer: 22 KB and < 80 VGPRs, i.e. it fits in what two resident trailing-update

@@ -62,8 +62,9 @@ static inline void set_batch(GemmArgs& g, int batch, int64_t a_bs, int64_t b_bs,
 // the block read and written once instead of (kb - ob) times; bit-identical — potrf 29.1 -> 29.3 ms at C3, the fit
 // step at N = 512 0.565 -> 0.609 ms: the longer update sits on the chain right before the potf2.  Not kept.)
 static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob, int oe,
-                       double* dLinv, int* dInfo, const BatchStrides& bs) {
-  for (int kb = ob; kb < oe; ++kb) {
+                       double* dLinv, int* dInfo, const BatchStrides& bs, int kb_end = -1) {
+  if (kb_end < 0) kb_end = oe; // (kb_end < oe: the first steps of the block only — potrf_steps)
+  for (int kb = ob; kb < kb_end; ++kb) {
     double* Akk = dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE;
     double* Li = dLinv + (int64_t)kb * TILE * TILE;
     GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs));
@@ -244,6 +245,12 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
   GPX_HIP(ctx, hipStreamWaitEvent(smain, ctx->evP[nouter], 0));
   ctx->s = smain;
   return rc;
+}
+
+int potrf_steps(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int kb0, int kb1, double* dLinv, int* dInfo) {
+  const BatchStrides bs{1, 0, 0};
+  ctx->small_bk_now = ctx->small_bk != 0 ? ctx->small_bk : (nblk <= SMALL_BK_ROWS ? 32 : 16);
+  return panel_block(ctx, dA, lda, nblk, 0, kb0, nblk, dLinv, dInfo, bs, kb1 < nblk ? kb1 : nblk);
 }
 
 // ---- right-looking solve of  X * L^T = B  in place (B: rows_t*128 x nblk*128) --------------

@@ -5,17 +5,16 @@
 // The inverse of the diagonal block turns every panel TRSM into an MFMA GEMM.
 // A non-positive pivot makes the factor NaN from there on (propagates, like JAX) and sets *info.
 //
-// Three kernels, one arithmetic (bit-identical outputs, tests/test_gpu_edges.py):
+// Two kernels, one arithmetic (bit-identical outputs, tests/test_gpu_edges.py):
 //   potf2_slim_kernel  (potf2_slim.h, round 4, default)  94 VGPRs, 28 KB LDS: placed at once beside two resident
 //                      trailing-update workgroups; tiles memory-resident, visited in chunks
-//   potf2_chain_kernel (potf2_chain.h, round 3, GPX_POTF2=chain)  344 VGPRs, 46 KB: all tiles in registers; the
-//                      fastest stand-alone, but needs a drained CU
 //   potf2_tile_kernel  (potf2_tile.h, round 2, GPX_POTF2=tile)    the four-phase form, the reference of the tests
+// (Round 3's wave-specialised kernel with every tile in registers — 344 VGPRs, 46 KB, needs a drained CU — left the
+// library in round 5: tools/exp/potf2_chain.h.)
 // (Round 1's column-by-column kernel and round 2's blocked 16 x 16 diagonal factor were measured slower and removed:
 // profiles/r02/chain_experiments.md.)
 #include "common.h"
 #include "potf2_tile.h"
-#include "potf2_chain.h"
 #include "potf2_slim.h"
 
 // =================================================================================================
@@ -44,19 +43,8 @@ __global__ __launch_bounds__(256, 1) void potf2_tile_kernel(double* A, int64_t l
   potf2_tile_body(A, lda, Linv, info, info_base, lds);
 }
 
-// the wave-specialised form (potf2_chain.h): default; bit-identical to potf2_tile_kernel<false>
-__global__ __launch_bounds__(256, 1) void potf2_chain_kernel(double* A, int64_t lda, double* Linv, int* info, int info_base,
-                                                             int64_t a_bs, int64_t linv_bs) {
-  A += (int64_t)blockIdx.x * a_bs; // one workgroup per batch entry
-  Linv += (int64_t)blockIdx.x * linv_bs;
-  if (info != nullptr) info += blockIdx.x;
-  __builtin_amdgcn_s_setprio(3);
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  potf2_chain_body(A, lda, Linv, info, info_base, lds);
-}
-
 // the placeable form (potf2_slim.h): <= 112 VGPRs, 28.2 KB LDS — fits beside two resident trailing-update workgroups;
-// bit-identical to the two kernels above.  amdgpu_num_vgpr keeps the allocator out of the AGPR half of the unified
+// bit-identical to the kernel above.  amdgpu_num_vgpr keeps the allocator out of the AGPR half of the unified
 // register file (without it: ~90 VGPRs + 48 AGPRs allocated); tests/test_abi.py checks the emitted counts.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112))) void potf2_slim_kernel(double* A, int64_t lda, double* Linv,
                                                                                            int* info, int info_base,
@@ -80,8 +68,6 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
     ProfScope ps(ctx, GPX_PROF_POTF2, nb * 2.0 * PB * (double)PB * PB / 3.0);
     if (ctx->potf2_mode == GPX_POTF2_SLIM)
       potf2_slim_kernel<<<nb, 256, POTF2_SLIM_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
-    else if (ctx->potf2_mode == GPX_POTF2_CHAIN)
-      potf2_chain_kernel<<<nb, 256, POTF2_CHAIN_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
     else
       potf2_tile_kernel<<<nb, 256, POTF2_TILE_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
   }

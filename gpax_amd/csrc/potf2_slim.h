@@ -30,7 +30,7 @@
 #pragma once
 #include <utility>
 
-#include "potf2_chain.h"
+#include "potf2_tile.h"
 
 namespace gpx {
 

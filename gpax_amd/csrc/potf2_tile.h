@@ -28,6 +28,13 @@ __device__ __forceinline__ void acc_to_lds(const pd4_t& a, double* T, int lane) 
 }
 
 // acc += sgn * TA * TB^T   (TA[m][k], TB[n][k], 16x16 row-major tiles with leading dimension TLD)
+__device__ __forceinline__ pd4_t lds_to_acc(const double* T, int lane) {
+  pd4_t a;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) a[r] = T[((lane >> 4) + 4 * r) * TLD + (lane & 15)];
+  return a;
+}
+
 __device__ __forceinline__ pd4_t mma_nt(pd4_t acc, const double* TA, const double* TB, int lane, double sgn) {
   const int fr = lane & 15, fk = lane >> 4;
 #pragma unroll

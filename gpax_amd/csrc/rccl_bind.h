@@ -76,6 +76,21 @@ inline bool load_rccl(RcclApi& r, std::string& err) {
   GPX_SYM(GroupEnd, "ncclGroupEnd")
   GPX_SYM(GetVersion, "ncclGetVersion")
 #undef GPX_SYM
+  // The enumerators and the by-value unique id above are restated from the NCCL 2.x ABI (RCCL 2.27 here): refuse a
+  // library that reports another major version instead of calling it with constants that may have moved.
+  int ver = 0;
+  if (r.GetVersion(&ver) != ncclSuccess || ver <= 0) {
+    err = "ncclGetVersion failed: cannot check the RCCL ABI";
+    r.handle = nullptr;
+    return false;
+  }
+  const int major = ver >= 10000 ? ver / 10000 : ver / 1000; // NCCL_VERSION_CODE: X*10000 + Y*100 + Z from 2.9 on
+  if (major != 2) {
+    err = "unsupported RCCL major version " + std::to_string(major) + " (version code " + std::to_string(ver) +
+          "): gpax_amd/csrc/rccl_bind.h restates the NCCL 2.x ABI (ncclDouble = 8, ncclMax = 2, 128-byte unique id by value)";
+    r.handle = nullptr;
+    return false;
+  }
   return true;
 }
 
@@ -168,7 +183,10 @@ struct ShardJob {
 // slots: per_gpu each.
 struct ShardCursor {
   std::mutex mu;
-  int next = 0, total = 0, parts = 1, min_chunk = 8;
+  // min_chunk: the launch batch B once a context has reported it (1 until then: at N >= 8192 a launch holds B <= 8
+  // samples and a chunk rounded up to 8 would leave a short sweep to the first one or two contexts); no chunk exceeds the
+  // fair share ceil(total / parts), so every context gets work whenever there are at least `parts` samples
+  int next = 0, total = 0, parts = 1, min_chunk = 1;
   bool take(int* lo, int* hi) {
     std::lock_guard<std::mutex> g(mu);
     if (next >= total) return false;
@@ -176,6 +194,8 @@ struct ShardCursor {
     int c = (left + 2 * parts - 1) / (2 * parts);
     if (c < min_chunk) c = min_chunk;
     c = (c + min_chunk - 1) / min_chunk * min_chunk; // whole launch batches
+    const int fair = (total + parts - 1) / parts;
+    if (c > fair) c = fair;
     *lo = next;
     *hi = next + c < total ? next + c : total;
     next = *hi;

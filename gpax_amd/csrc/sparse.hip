@@ -478,6 +478,8 @@ struct SgpState {
   gpx::DevBuf B0, B1, B2, B3, B4, vvec, tvec, mvec, rcoef_u, rcoef_f, gxu_part, cpart, gXu, T1a, T1;
   gpx::DevBuf Xs, V1, V2, mean, var, var2, Cov;
   gpx::DevBuf Vu, VA, Tscr, Kfu; // Luu^-1, LA^-1 (lower), scratch of the L^-T tree, Kfu before the solve
+  gpx::DevBuf TscrU;             // scratch of the Luu^-T tree when it runs on the side stream beside the LA chain / tree
+  std::vector<hipEvent_t> evG;   // ride-along forward pass: per column group [chain done, inverse block done] + joins
   gpx::KernelParams kp{};
   double noise = 0, jitter = 0;
   // The forward pass of the last call, kept while the next call brings the very same inputs (kernel, theta, jitter, Xu,
@@ -504,8 +506,9 @@ void sgp_release(gpx_ctx* ctx) {
   DevBuf* bufs[] = {&s->Xu, &s->Kuu, &s->LinvU, &s->Wn, &s->Wt, &s->A, &s->Acopy, &s->LinvA, &s->u, &s->c, &s->cpad,
                     &s->scal, &s->part, &s->B0, &s->B1, &s->B2, &s->B3, &s->B4, &s->vvec, &s->tvec, &s->mvec,
                     &s->rcoef_u, &s->rcoef_f, &s->gxu_part, &s->cpart, &s->gXu, &s->T1a, &s->T1, &s->Xs, &s->V1,
-                    &s->V2, &s->mean, &s->var, &s->var2, &s->Cov, &s->Vu, &s->VA, &s->Tscr, &s->Kfu};
+                    &s->V2, &s->mean, &s->var, &s->var2, &s->Cov, &s->Vu, &s->VA, &s->Tscr, &s->Kfu, &s->TscrU};
   for (DevBuf* b : bufs) b->release();
+  for (hipEvent_t e : s->evG) (void)hipEventDestroy(e);
   if (s->evFork) (void)hipEventDestroy(s->evFork);
   if (s->evJoin) (void)hipEventDestroy(s->evJoin);
   delete s;
@@ -574,6 +577,158 @@ static int sgp_forward(gpx_ctx* ctx, SgpState* s) {
   s->fwd_valid = true;
   return 0;
 }
+// ---- round 5: Kuu = Luu Luu^T and W = Kfu Luu^-T in ONE pipelined pass -------------------------------------------------
+// Rounds 3 / 4 factored Kuu (a 16-step chain at M = 2048: 0.92 ms with 255 CUs idle), built Luu^-T by the tree (0.27 ms)
+// and only then formed W as one N x M x M GEMM against Luu^-1 (1.12 ms) — three stages in sequence
+// (profiles/r04/c5_step_timeline.md).  W is the right-looking solve X Luu^T = Kfu (what the reference does:
+// solve_triangular, sparse_gp.py:94), and column group g of that solve needs only the FIRST columns of Luu:
+//   chain  (panel stream)  plain right-looking steps of Kuu (potrf_steps), an event after every column group [a, b)
+//   tree   (side stream)   the inverse of the group's diagonal block Luu[a:b, a:b] — a 2- or 4-tile L^-T tree, transposed
+//   main                   W[:, a:b] = R[:, a:b] inv(Luu[a:b, a:b])^T  (ONE GEMM, k range cut at the column tile), then the
+//                          far update R[:, b:] -= W[:, a:b] Luu[b:, a:b]^T (K = 256 / 512, the throughput shape)
+// R starts as Kfu and is updated in place; every tile of R receives its groups in ascending order on ONE stream (bit-
+// reproducible).  Groups of 2, 2, 4, 4, ... tile columns: the tall solve starts after two chain steps and then always has
+// a group's worth of work queued while the chain (57 us per step) runs ahead of it.  The FULL Luu^-T tree (the gradient's
+// Tu, the posterior's Luu^-1) is no longer on the path to W: it runs on the side stream beside the chain of the second
+// factorisation (sgp_forward_run).
+static int sgp_events(gpx_ctx* ctx, SgpState* s, size_t n) {
+  while (s->evG.size() < n) {
+    hipEvent_t e;
+    GPX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    s->evG.push_back(e);
+  }
+  return 0;
+}
+
+// events of the ride-along pass: evG[0 .. 4] = start / A ready / LA chain done / the two joins, then two per column group
+enum { SGP_EV_START = 0, SGP_EV_A = 1, SGP_EV_CHAIN = 2, SGP_EV_JOIN1 = 3, SGP_EV_JOIN2 = 4, SGP_EV_GROUPS = 5 };
+
+static std::vector<int> sgp_groups(int mt) { // boundaries of the column groups: 2, 2, 4, 4, ... tile columns
+  std::vector<int> gb(1, 0);
+  for (int a = 0, k = 0; a < mt; ++k) {
+    a += (k < 2) ? 2 : 4;
+    gb.push_back(a < mt ? a : mt);
+  }
+  return gb;
+}
+
+static int sgp_factor_ride(gpx_ctx* ctx, SgpState* s, int* dinfo) {
+  const int Mp = s->Mp, Ntp = s->Ntp, mt = Mp / TILE, ntl = Ntp / TILE;
+  hipStream_t smain = ctx->stream, schain = ctx->pstream, sside = ctx->xstream;
+  const std::vector<int> gb = sgp_groups(mt);
+  const int ng = (int)gb.size() - 1;
+  GPX_TRY(sgp_events(ctx, s, (size_t)SGP_EV_GROUPS + 2 * ng));
+  hipEvent_t evStart = s->evG[SGP_EV_START];
+  // chain and side stream start behind what the main stream holds (Xu, Kuu, its identity padding)
+  GPX_HIP(ctx, hipEventRecord(evStart, smain));
+  GPX_HIP(ctx, hipStreamWaitEvent(schain, evStart, 0));
+  GPX_HIP(ctx, hipStreamWaitEvent(sside, evStart, 0));
+  double* Tu = s->B0.d();
+  GPX_HIP(ctx, hipMemsetAsync(Tu, 0, (size_t)Mp * s->ldu * sizeof(double), sside)); // zero below the diagonal: Tu enters full GEMMs
+  // R = Kfu on the main stream, beside the first chain steps
+  ctx->s = smain;
+  GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), ctx->N, Ntp, s->Xu.d(), s->M, Mp, 0.0, 0, 0, s->Kfu.d(), s->ldw));
+  int rc = 0;
+  for (int g = 0; g < ng && rc >= 0; ++g) {
+    const int a = gb[(size_t)g], b = gb[(size_t)g + 1], w = b - a;
+    hipEvent_t evC = s->evG[(size_t)SGP_EV_GROUPS + 2 * g], evT = s->evG[(size_t)SGP_EV_GROUPS + 2 * g + 1];
+    const int64_t dg = (int64_t)a * TILE * (s->ldu + 1); // the group's diagonal block in an M x M matrix
+    ctx->s = schain;
+    rc = potrf_steps(ctx, s->Kuu.d(), s->ldu, mt, a, b, s->LinvU.d(), dinfo);
+    if (rc < 0) break;
+    GPX_HIP(ctx, hipEventRecord(evC, schain));
+    ctx->s = sside;
+    GPX_HIP(ctx, hipStreamWaitEvent(sside, evC, 0));
+    rc = linv_t_tree(ctx, Tu + dg, s->ldu, s->Kuu.d() + dg, s->ldu, s->LinvU.d() + (int64_t)a * TILE * TILE, w,
+                     s->TscrU.d() + dg, s->ldu);
+    if (rc < 0) break;
+    rc = launch_transpose(ctx, Tu + dg, s->ldu, w * TILE, w * TILE, s->Vu.d() + dg, s->ldu);
+    if (rc < 0) break;
+    GPX_HIP(ctx, hipEventRecord(evT, sside));
+    ctx->s = smain;
+    GPX_HIP(ctx, hipStreamWaitEvent(smain, evT, 0)); // (evT follows evC: the group's columns of Luu are final as well)
+    {
+      GemmArgs q = gargs(s->Kfu.d() + (int64_t)a * TILE, s->ldw, s->Vu.d() + dg, s->ldu, s->Wn.d() + (int64_t)a * TILE,
+                         s->ldw, w * TILE, 1.0, 0.0);
+      q.kupper = 1;
+      q.big_shape = 1;
+      rc = launch_gemm_nt(ctx, q, ntl, w, 0, GPX_PROF_GEMM_OTHER, (double)Ntp * TILE * TILE * w * (w + 1.0));
+      if (rc < 0) break;
+    }
+    if (b < mt) {
+      GemmArgs q = gargs(s->Wn.d() + (int64_t)a * TILE, s->ldw, s->Kuu.d() + (int64_t)b * TILE * s->ldu + (int64_t)a * TILE,
+                         s->ldu, s->Kfu.d() + (int64_t)b * TILE, s->ldw, w * TILE, -1.0, 1.0);
+      q.big_shape = 1;
+      rc = launch_gemm_nt(ctx, q, ntl, mt - b, 0, GPX_PROF_GEMM_OTHER, 2.0 * Ntp * (double)(mt - b) * TILE * w * TILE);
+    }
+  }
+  ctx->s = smain;
+  return rc;
+}
+
+// Whatever path leaves the forward pass — a launch error included — the main stream waits for what the panel and side
+// streams still hold: the next call rewrites Xu / Kuu / the tree buffers on the main stream.
+struct SgpJoin {
+  gpx_ctx* ctx;
+  hipEvent_t e1, e2;
+  ~SgpJoin() {
+    if (hipEventRecord(e1, ctx->pstream) == hipSuccess) (void)hipStreamWaitEvent(ctx->stream, e1, 0);
+    if (hipEventRecord(e2, ctx->xstream) == hipSuccess) (void)hipStreamWaitEvent(ctx->stream, e2, 0);
+    ctx->s = ctx->stream;
+  }
+};
+
+static int sgp_forward_ride(gpx_ctx* ctx, SgpState* s) {
+  const int N = ctx->N, M = s->M, Mp = s->Mp, Ntp = s->Ntp;
+  const int mt = Mp / TILE;
+  const double s2 = s->noise;
+  const size_t mm = (size_t)Mp * s->ldu * 8;
+  int* dinfo = s->scal.i() + 1024;
+  GPX_TRY(ens(ctx, s->Kfu, (size_t)Ntp * s->ldw * 8));
+  GPX_TRY(ens(ctx, s->B0, mm));
+  GPX_TRY(ens(ctx, s->B1, mm));
+  GPX_TRY(ens(ctx, s->Vu, mm));
+  GPX_TRY(ens(ctx, s->VA, mm));
+  GPX_TRY(ens(ctx, s->Tscr, mm));
+  GPX_TRY(ens(ctx, s->TscrU, mm));
+  GPX_TRY(sgp_events(ctx, s, (size_t)SGP_EV_GROUPS + 2 * (sgp_groups(mt).size() - 1)));
+  SgpJoin join{ctx, s->evG[SGP_EV_JOIN1], s->evG[SGP_EV_JOIN2]};
+  hipEvent_t evA = s->evG[SGP_EV_A], evChain = s->evG[SGP_EV_CHAIN];
+  // Kuu = kernel(Xu, Xu, params, **jitter): noise defaults to 0 (sparse_gp.py:92)
+  GPX_TRY(launch_gram_padded(ctx, s->kp, s->Xu.d(), M, Mp, s->Xu.d(), M, Mp, s->jitter, 1, 1, s->Kuu.d(), s->ldu));
+  GPX_TRY(launch_pad_identity(ctx, s->Kuu.d(), s->ldu, M, Mp));
+  GPX_TRY(sgp_factor_ride(ctx, s, dinfo));
+  { // Wt = W^T, and |W|_F^2 in partial sums on the way (the bound's trace term)
+    dim3 grid((Mp + 31) / 32, (Ntp + 31) / 32);
+    transpose_sumsq_kernel<<<grid, 256, 0, ctx->s>>>(s->Wn.d(), s->ldw, Ntp, Mp, s->Wt.d(), s->ldt, N, M, s->part.d());
+    GPX_HIP(ctx, hipGetLastError());
+    s->npartW = (int)(grid.x * grid.y);
+  }
+  // A = I + Wt Wt^T / s2 (kept in Acopy)
+  GPX_TRY(syrk_full(ctx, s->Wt.d(), s->ldt, mt, Ntp, 1.0 / s2, 1.0, M, s->A.d(), s->ldu));
+  GPX_HIP(ctx, hipMemcpyAsync(s->Acopy.d(), s->A.d(), mm, hipMemcpyDeviceToDevice, ctx->stream));
+  GPX_HIP(ctx, hipEventRecord(evA, ctx->stream));
+  // ... factored on the PANEL stream, while the side stream — idle since the last group's inverse block — builds the full
+  // Luu^-T (the gradient's Tu) and Luu^-1 (the posterior's) beside that chain, and the main stream forms u = Wt y
+  GPX_HIP(ctx, hipStreamWaitEvent(ctx->pstream, evA, 0));
+  ctx->s = ctx->pstream;
+  GPX_TRY(potrf_steps(ctx, s->A.d(), s->ldu, mt, 0, mt, s->LinvA.d(), dinfo + 1));
+  GPX_HIP(ctx, hipEventRecord(evChain, ctx->pstream));
+  GPX_HIP(ctx, hipStreamWaitEvent(ctx->xstream, evA, 0)); // (the tall solve has read the last group's block of Luu^-1 by then)
+  ctx->s = ctx->xstream;
+  GPX_TRY(linv_t_tree(ctx, s->B0.d(), s->ldu, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, s->TscrU.d(), s->ldu));
+  GPX_TRY(launch_transpose(ctx, s->B0.d(), s->ldu, Mp, Mp, s->Vu.d(), s->ldu));
+  ctx->s = ctx->stream;
+  // u = Wt y ; then, behind the chain: TA = LA^-T, LA^-1 and c = LA^-1 u / s2 as one matrix-vector product
+  GPX_TRY(launch_rowdot(ctx, s->Wt.d(), s->ldt, M, N, ctx->yres.d(), 0.0, s->u.d(), nullptr, 0));
+  GPX_HIP(ctx, hipMemsetAsync(s->c.d(), 0, (size_t)Mp * 8, ctx->stream));
+  GPX_TRY(launch_axpby(ctx, s->cpad.d(), 1.0 / s2, s->u.d(), 0.0, nullptr, M)); // cpad[0 .. M) = u / s2
+  GPX_HIP(ctx, hipStreamWaitEvent(ctx->stream, evChain, 0));
+  GPX_TRY(build_linv_t(ctx, s->A.d(), s->ldu, s->LinvA.d(), mt, s->B1.d(), s->ldu, s->Tscr.d(), s->VA.d()));
+  GPX_TRY(launch_rowdot(ctx, s->VA.d(), s->ldu, M, M, s->cpad.d(), 0.0, s->c.d(), nullptr, 0));
+  return 0;
+}
+
 static int sgp_forward_run(gpx_ctx* ctx, SgpState* s) {
   const int N = ctx->N, M = s->M, Mp = s->Mp, Ntp = s->Ntp;
   const int mt = Mp / TILE, ntl = Ntp / TILE;
@@ -593,8 +748,9 @@ static int sgp_forward_run(gpx_ctx* ctx, SgpState* s) {
   GPX_TRY(ens(ctx, s->part, (size_t)((Ntp / 32) * (Mp / 32) + Mp / 8 + 32) * 8));
   int* dinfo = s->scal.i() + 1024;
   GPX_HIP(ctx, hipMemsetAsync(dinfo, 0, 2 * sizeof(int), ctx->stream));
+  if (ctx->sgp_inverse == 2) return sgp_forward_ride(ctx, s);
   if (ctx->sgp_inverse) {
-    // Kfu = k(X, Xu) waits for nothing of the Kuu branch: on the panel stream, beside the latency-bound Cholesky chain
+    // (round 4, GPX_SGP_SOLVE=inverse) Kfu = k(X, Xu) waits for nothing of the Kuu branch: on the panel stream, beside the latency-bound Cholesky chain
     // of Kuu (a 16-step chain at M = 2048 that leaves the chip idle), joined again before the solve that reads it
     if (!s->evFork) {
       GPX_HIP(ctx, hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming));

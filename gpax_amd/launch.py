@@ -54,12 +54,18 @@ def launch_token(environ=None) -> str:
     except (OSError, IndexError):
         pass
     run = "".join(c if c.isalnum() else "_" for c in e.get("TORCHELASTIC_RUN_ID", ""))[:32]
-    return f"p{ppid}_{start}_{e.get('MASTER_PORT', '0')}_{run}"
+    # an elastic agent that restarts its workers keeps its PID, port and run id: the restart count tells the
+    # incarnations apart (a restarted rank must not read the dead incarnation's unique id and wait for its peers)
+    restart = "".join(c for c in e.get("TORCHELASTIC_RESTART_COUNT", "0") if c.isdigit())[:8] or "0"
+    return f"p{ppid}_{start}_{e.get('MASTER_PORT', '0')}_{run}_r{restart}"
 
 
-def _private_dir(path: str) -> None:
-    """Create `path` for this user only and refuse one that somebody else could have planted (another owner, group /
-    world access, a symbolic link): the directory carries the 128-byte RCCL bootstrap id."""
+def _private_dir(path: str, parent: bool = False) -> None:
+    """Create `path` for this user only and refuse one that somebody else could have planted (another owner, a symbolic
+    link, write access for group / others): the directory carries the 128-byte RCCL bootstrap id.
+    parent = True: `path` is the rendezvous directory itself, possibly handed over by the user (GPX_RDZV_DIR made by hand
+    under umask 002 is 0775): only owner and not-a-symlink are checked there — the ids live in the <token>/attempt
+    subdirectories this module creates itself, and those are held to the write-bit rule."""
     os.makedirs(path, mode=0o700, exist_ok=True)
     st = os.lstat(path)
     import stat as _stat
@@ -67,7 +73,7 @@ def _private_dir(path: str) -> None:
         raise PermissionError(f"rendezvous directory {path} is not a plain directory")
     if hasattr(os, "geteuid") and st.st_uid != os.geteuid():
         raise PermissionError(f"rendezvous directory {path} belongs to uid {st.st_uid}, not to this user")
-    if st.st_mode & 0o022:
+    if not parent and st.st_mode & 0o022:
         raise PermissionError(f"rendezvous directory {path} is writable by others (mode {oct(st.st_mode & 0o777)})")
 
 
@@ -169,7 +175,7 @@ def init_rank(env: RankEnv, device: Optional[int] = None, inflight: Optional[int
     t_start = time.time()
     # <directory>/<launch token>/attempt<k>: nothing an earlier launch left in the directory is visible from here, neither
     # store keys nor the file transport's transfer files (their names restart at sequence 0 in every process)
-    _private_dir(env.rdzv_dir)
+    _private_dir(env.rdzv_dir, parent=True)
     base = os.path.join(env.rdzv_dir, env.token) if env.token else env.rdzv_dir
     _private_dir(base)
     store = FileStore(os.path.join(base, f"attempt{env.attempt}"), fresh_after=t_start - 300.0)

@@ -265,8 +265,8 @@ int gpx_profile_read(gpx_ctx* ctx, int cls, int64_t* launches, double* total_ms,
  * updates (8 B when beta == 0) — the per-launch figure bench.py's roofline block quotes beside the PMC traffic. */
 int gpx_profile_read_bytes(gpx_ctx* ctx, int cls, double* total_bytes);
 /* Diagnostic: select the diagonal-block kernel of the blocked Cholesky for the following calls on this context —
- * "slim" (default, csrc/potf2_slim.h), "chain" (round 3, csrc/potf2_chain.h) or "tile" (round 2, the reference of the
- * bit-identity tests).  All three produce the same bits; bench.py uses it for the in-process A/B of the potf2 class.
+ * "slim" (default, csrc/potf2_slim.h) or "tile" (round 2, csrc/potf2_tile.h: the reference of the bit-identity
+ * tests).  Both produce the same bits; bench.py uses it for the in-process A/B of the potf2 class.
  * The environment variable GPX_POTF2 sets the same thing at gpx_init. */
 int gpx_debug_set_potf2(gpx_ctx* ctx, const char* mode);
 

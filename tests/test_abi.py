@@ -81,7 +81,6 @@ def test_chain_kernels_fit_beside_two_resident_trailing_update_workgroups():
     assert alloc(slim) <= free_vgpr, (slim["vgpr_count"], free_vgpr)
     assert int(slim["vgpr_spill_count"]) == 0 and int(slim["private_segment_fixed_size"]) == 0
     assert (13 * 16 * 17 + 64) * 8 <= free_lds  # POTF2_SLIM_LDS (dynamic LDS: csrc/potf2_slim.h)
-    chain = find("potf2_chain_kernel")
-    assert alloc(chain) > free_vgpr  # why it waited 80 - 155 us per launch for a drained CU
+    assert not [n for n in rows if "potf2_chain_kernel" in n]  # round 3's 344-VGPR kernel left the product (tools/exp/)
     for shape in ("gemm_nt_kernelILi0ELi2ELi2ELi16E", "gemm_nt_kernelILi0ELi1ELi4ELi16E"):  # 64x64, 32x128 strips
         assert alloc(find(shape)) <= free_vgpr

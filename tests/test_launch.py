@@ -148,6 +148,30 @@ def test_a_reused_directory_never_shows_an_earlier_launch(tmp_path):
     assert t == launch.launch_token({"MASTER_PORT": "29511", "TORCHELASTIC_RUN_ID": "run/../7"})
     assert t.startswith(f"p{os.getppid()}_") and "/" not in t and ".." not in t
     assert launch.launch_token({"MASTER_PORT": "29512"}) != t
+    # an elastic agent restarting its workers keeps PID, port and run id — the restart count tells the
+    # incarnations apart
+    base = {"MASTER_PORT": "29511", "TORCHELASTIC_RUN_ID": "r7"}
+    assert launch.launch_token(dict(base, TORCHELASTIC_RESTART_COUNT="1")) != launch.launch_token(base)
+    assert launch.launch_token(dict(base, TORCHELASTIC_RESTART_COUNT="0")) == launch.launch_token(base)
+
+
+def test_a_hand_made_rendezvous_directory_with_group_write_is_accepted_but_its_subdirectories_are_private(tmp_path):
+    """GPX_RDZV_DIR made by hand under umask 002 is 0775; only owner and not-a-symlink are checked on the
+    directory the user hands over — the ids live in the <token>/attempt subdirectories the module creates (0700)."""
+    from gpax_amd import launch
+    rdzv = tmp_path / "by_hand"
+    rdzv.mkdir()
+    os.chmod(rdzv, 0o775)
+    env = launch.rank_env({"RANK": "0", "WORLD_SIZE": "1", "GPX_RDZV_DIR": str(rdzv), "GPX_RDZV_TOKEN": "t"})
+    rk = launch.init_rank(env, transport="file", timeout=10.0, make_rank=FakeRank, make_uid=lambda: b"x" * 128)
+    fdir = rk.args["file_dir"]
+    assert fdir.startswith(str(rdzv)) and (os.stat(fdir).st_mode & 0o777) == 0o700
+    assert (os.stat(os.path.join(str(rdzv), "t")).st_mode & 0o777) == 0o700
+    link = tmp_path / "link"
+    os.symlink(rdzv, link)
+    env2 = launch.rank_env({"RANK": "0", "WORLD_SIZE": "1", "GPX_RDZV_DIR": str(link), "GPX_RDZV_TOKEN": "t"})
+    with pytest.raises(PermissionError, match="not a plain directory"):
+        launch.init_rank(env2, transport="file", timeout=10.0, make_rank=FakeRank, make_uid=lambda: b"x" * 128)
 
 
 def test_the_rendezvous_directory_must_be_private(tmp_path):

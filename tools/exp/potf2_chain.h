@@ -1,3 +1,6 @@
+// (round 5: left the product library — VERDICT r4 weak #11: ONE bit-identity reference, potf2_tile.h, stays compiled in.
+// Last commit that built it into libgpx.so: 1a89af6.  The kernel wrapper and the launch branch that used it are quoted at the
+// end of this file.)
 // potf2_chain.h — the 128 x 128 diagonal-block factor + inverse (potf2.hip) as a WAVE-SPECIALISED kernel body:
 // wave 0 runs nothing but the dependent chain  diag16(p) -> L(p+1,p) -> D(p+1) = C(p+1,p+1) - L(p+1,p) L(p+1,p)^T ->
 // diag16(p+1)  out of LDS, waves 1 - 3 own all 36 Cholesky and 28 inverse-residual 16 x 16 tiles as MFMA accumulators
@@ -28,7 +31,7 @@
 // Arithmetic: tile for tile the MFMA sequences of potf2_tile_body (k ascending, the same operands, the same signs), so
 // L, L^-1 and the pivots are bit-identical to it (tests/test_gpu_edges.py).
 #pragma once
-#include "potf2_tile.h"
+#include "../../gpax_amd/csrc/potf2_tile.h"
 
 namespace gpx {
 
@@ -46,12 +49,6 @@ __host__ __device__ constexpr int st_c(int idx) { return idx - st_i(idx) * (st_i
 
 constexpr int PC_NC = 12, PC_NR = 10; // tiles per worker: C idx = 3 t + W - 1 (t < 12), R idx = 3 u + W - 1 (< 28)
 
-__device__ __forceinline__ pd4_t lds_to_acc(const double* T, int lane) {
-  pd4_t a;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) a[r] = T[((lane >> 4) + 4 * r) * TLD + (lane & 15)];
-  return a;
-}
 
 // ---- workers -----------------------------------------------------------------------------------------------------------
 // window B1(P) .. B2(P): this worker's column-P tiles become L(i,P) (i > P + 1; the chain makes i = P + 1), its row-P
@@ -270,3 +267,13 @@ __device__ __forceinline__ void potf2_chain_body(double* A, int64_t lda, double*
 }
 
 } // namespace gpx
+
+// ---- what potf2.hip held for this body until round 4 -------------------------------------------------------------------
+// __global__ __launch_bounds__(256, 1) void potf2_chain_kernel(double* A, int64_t lda, double* Linv, int* info, int info_base,
+//                                                              int64_t a_bs, int64_t linv_bs) {
+//   A += (int64_t)blockIdx.x * a_bs; Linv += (int64_t)blockIdx.x * linv_bs; if (info != nullptr) info += blockIdx.x;
+//   __builtin_amdgcn_s_setprio(3);
+//   extern __shared__ __attribute__((aligned(16))) double lds[];
+//   potf2_chain_body(A, lda, Linv, info, info_base, lds);
+// }
+// launch: potf2_chain_kernel<<<nb, 256, POTF2_CHAIN_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, a_bs, linv_bs);
