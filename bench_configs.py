@@ -59,19 +59,23 @@ def c1():
     s = m.get_samples()
     nl = int(sum(int(np.sum(st["n_leapfrog"])) for st in m.mcmc.get_extra_fields()))
     truth = np.prod(np.sin(Xn + 0.3 * np.arange(d)), axis=1)
-    # a fused fit step (N <= 256) would show here: time one lml + gradient call at the flagship notebook size too
+    # where gpax actually runs (every reference notebook fits N = 6 ... 40 points): one lml + gradient evaluation as the
+    # samplers issue it (gpx_fit_batch, B = 1 — ONE kernel launch up to N = 127, csrc/fit_small.hip), host to host
     eng = _lib.get_engine()
     small = {}
-    for n_small in (32, 128, 512):
+    for n_small in (25, 100, 512):
         Xs, ys_, _, p = bench_inputs.synthetic_problem(n_small, d, 4, seed=1)
         eng.set_train(Xs)
         kind = _lib.kernel_kind("RBF")
-
-        def step():
-            eng.factor(kind, p["k_length"], p["k_scale"], p["noise"], 1e-6, ys_)
-            eng.lml_grad()
-
-        small[f"fit_step_ms_N{n_small}"] = _median_ms(step, reps=20)
+        args = (kind, np.asarray(p["k_length"], dtype=float)[None, :], [p["k_scale"]], [p["noise"]], 1e-6, ys_)
+        small[f"fit_step_ms_N{n_small}"] = _median_ms(lambda: eng.fit_batch(*args), reps=50)  # noqa: B023
+    # ... and the simpleGP notebook's own size through the model API: NUTS 200 + 200 at N = 25
+    Xs, ys_, _, _ = bench_inputs.synthetic_problem(25, 1, 4, seed=1)
+    m25 = ExactGP(1, "RBF")
+    t0 = time.perf_counter()
+    m25.fit(k1, Xs, ys_, num_warmup=200, num_samples=200, progress_bar=False, print_summary=False)
+    small["nuts_200_200_N25_s"] = time.perf_counter() - t0
+    small["nuts_N25_leapfrogs"] = int(sum(int(np.sum(st["n_leapfrog"])) for st in m25.mcmc.get_extra_fields()))
     return {"config": "C1: ExactGP(1, 'RBF') N=512 d=1, NUTS 200 + 200, predict M=100 n=1 (BASELINE.json configs[0])",
             "fit_s": t1 - t0, "predict_s": t2 - t1, "leapfrogs_in_sampling": nl,
             "posterior_means": {k: np.asarray(v).mean(axis=0).ravel().tolist() for k, v in s.items()},

@@ -154,6 +154,22 @@ int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
                                   sizeof(double)));
   GPX_TRY(ensure(ctx, ctx->Linv, (size_t)B * bp.linv_bs * sizeof(double)));
   double* K = ctx->K.d();
+  ctx->small_grad_ready = false;
+  if (ctx->fit_small && !fused && N < TILE && !ctx->has_diag) {
+    // one launch: the factor in K, its inverse in Linv, [quad, sumlog] AND the gradient (a few microseconds more than the
+    // lml alone; gpx_lml_grad / the batch's dev_grad then has nothing left to do), alpha (fit_small.hip)
+    RoctxRange r("gpx:fit_small (gram, potf2, lml, gradient: one launch)");
+    GPX_TRY(ensure(ctx, ctx->alpha, (size_t)B * ctx->Np * sizeof(double)));
+    GPX_TRY(launch_fit_small(ctx, ctx->theta, ctx->noise + ctx->jitter, bp.th, ts_train(ctx), ctx->X.d(), N, bp.yres,
+                             bp.y_bs, bp.y_mod, K, ctx->ldk, bp.k_bs, ctx->Linv.d(), bp.linv_bs, ctx->alpha.d(), ctx->Np,
+                             bp.scal, bp.scal_bs, bp.info_train, 1, B));
+    ctx->small_grad_ready = true;
+    ctx->factored = (B == 1);
+    ctx->have_kinv = false;
+    ctx->fused_vt = false;
+    ctx->have_post = false;
+    return 0;
+  }
   {
     RoctxRange r("gpx:gram");
     GPX_TRY(launch_gram_padded(ctx, ctx->theta, ctx->X.d(), N, N, ctx->X.d(), N, Np,
@@ -187,6 +203,12 @@ int dev_factor(gpx_ctx* ctx, bool fused) { return dev_factor(ctx, fused, make_pl
 // Per sample b the results land in bp.scal + b * bp.scal_bs: [quad, sumlog, grad...].
 int dev_grad(gpx_ctx* ctx, const BatchPlan& bp) {
   const int N = ctx->N, B = bp.B;
+  if (ctx->small_grad_ready) { // fit_small.hip left the gradient and alpha behind the factorisation
+    ctx->small_grad_ready = false;
+    ctx->factored = false; // (as after the general path, whose K^-1 overwrites the factor)
+    ctx->have_kinv = false;
+    return 0;
+  }
   const int nt = (N + TILE - 1) / TILE; // tiles that carry real rows (excludes a pure aug tile)
   const int n128 = nt * TILE;
   const int64_t w_bs = (int64_t)ctx->Np * ctx->ldk, alpha_bs = ctx->Np;
@@ -664,10 +686,12 @@ int gpx_init(int device, gpx_ctx** out) {
     if (const char* e = getenv("GPX_POTF2")) {
       if (gpx_debug_set_potf2(ctx, e) != 0) return -1;
     }
+    if (const char* e = getenv("GPX_FIT_SMALL")) ctx->fit_small = (e[0] != '0');
+    if (const char* e = getenv("GPX_LAT_GEMM")) ctx->lat_gemm = (std::strcmp(e, "r1") == 0) ? 1 : ((std::strcmp(e, "r5") == 0) ? 5 : 0);
     if (const char* e = getenv("GPX_SMALL_BK")) ctx->small_bk = (atoi(e) == 32) ? 32 : (atoi(e) == 16 ? 16 : 0);
     if (const char* e = getenv("GPX_LINVT")) ctx->linvt_tree = (std::strcmp(e, "sweep") == 0) ? 0 : 1;
     if (const char* e = getenv("GPX_SGP_SOLVE"))
-      ctx->sgp_inverse = (std::strcmp(e, "sweep") == 0) ? 0 : ((std::strcmp(e, "inverse") == 0) ? 1 : 2);
+      ctx->sgp_inverse = (std::strcmp(e, "sweep") == 0) ? 0 : ((std::strcmp(e, "ride") == 0) ? 2 : 1);
     ctx->s = ctx->stream;
   }
   GPX_HIP(ctx, hipEventCreate(&ctx->ev0));
@@ -709,6 +733,7 @@ void gpx_destroy(gpx_ctx* ctx) {
     ctx->pin_in.release();
     ctx->pin_out.release();
     ctx->pin_x.release();
+    ctx->pin_fit.release();
     sgp_release(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -903,6 +928,60 @@ int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const doubl
   GPX_HIP(ctx, hipSetDevice(ctx->device));
   const int N = ctx->N;
   constexpr int SB = 32; // doubles per sample in bscal
+  if (ctx->fit_small && N < TILE && !ctx->has_diag && grad != nullptr) {
+    // Small N: ONE kernel launch (fit_small.hip) that reads its hyper-parameters and residuals from, and writes its
+    // results to, page-locked host memory — no copy calls at all around it: at N = 25 the five hipMemcpyAsync of the
+    // general sequence cost more than the arithmetic (profiles/r05/fit_small.json).  X stays resident on the device.
+    const int d = ctx->d, stride = d + (kind == GPX_KERNEL_PERIODIC ? 1 : 0);
+    const size_t th_b = round_up64((int64_t)B * sizeof(ThetaDev), 64), y_b = round_up64((int64_t)yres_rows * N * 8, 64),
+                 sc_b = (size_t)B * SB * 8, in_b = round_up64((int64_t)B * sizeof(int), 64), al_b = (size_t)B * TILE * 8;
+    if (ctx->pin_fit.cap < th_b + y_b + sc_b + in_b + al_b) {
+      GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      GPX_HIP(ctx, ctx->pin_fit.ensure(2 * (th_b + y_b + sc_b + in_b + al_b)));
+    }
+    char* base = static_cast<char*>(ctx->pin_fit.p);
+    ThetaDev* th = reinterpret_cast<ThetaDev*>(base);
+    double* hy = reinterpret_cast<double*>(base + th_b);
+    double* hsc = reinterpret_cast<double*>(base + th_b + y_b);
+    int* hin = reinterpret_cast<int*>(base + th_b + y_b + sc_b);
+    double* hal = reinterpret_cast<double*>(base + th_b + y_b + sc_b + in_b);
+    const KernelParams saved = ctx->theta;
+    for (int b = 0; b < B; ++b) {
+      const int rc = set_theta(ctx, kind, d, ells + (int64_t)b * stride, scales[b]);
+      if (rc < 0) {
+        ctx->theta = saved;
+        return rc;
+      }
+      th[b].kp = ctx->theta;
+      th[b].diag_train = noises[b] + jitter;
+      th[b].diag_pred = th[b].diag_train;
+      th[b].kdiag_pred = 0.0;
+    }
+    ctx->jitter = jitter;
+    std::memcpy(hy, yres, (size_t)yres_rows * N * 8);
+    GPX_TRY(ensure(ctx, ctx->K, (size_t)B * ctx->Np * ctx->ldk * sizeof(double)));
+    GPX_TRY(ensure(ctx, ctx->Linv, (size_t)B * TILE * TILE * sizeof(double)));
+    ctx->s = ctx->stream;
+    GPX_TRY(launch_fit_small(ctx, ctx->theta, 0.0, th, ts_train(ctx), ctx->X.d(), N, hy, yres_rows == 1 ? 0 : N,
+                             (yres_rows == 1 || yres_rows == B) ? 0 : yres_rows, ctx->K.d(), ctx->ldk,
+                             (int64_t)ctx->Np * ctx->ldk, ctx->Linv.d(), (int64_t)TILE * TILE, hal, TILE, hsc, SB, hin, 1, B));
+    GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->factored = false;
+    ctx->have_post = false;
+    ctx->have_kinv = false;
+    ctx->small_grad_ready = false;
+    const int ne = n_ell(ctx->theta);
+    for (int b = 0; b < B; ++b) {
+      int hinfo = hin[b];
+      if (hinfo > N) hinfo = 0; // a failure at the augmentation pivot itself is not a failure of K
+      if (info) info[b] = hinfo;
+      const double* h = hsc + (size_t)b * SB;
+      lml[b] = (hinfo != 0) ? NAN : (-0.5 * h[SC_QUAD] - h[SC_SUMLOG] - 0.5 * N * LOG_2PI);
+      for (int c = 0; c < ne + 2; ++c) grad[(int64_t)b * (ne + 2) + c] = (hinfo != 0) ? NAN : h[SC_GRAD + c];
+      if (alpha) std::memcpy(alpha + (int64_t)b * N, hal + (size_t)b * TILE, (size_t)N * 8);
+    }
+    return 0;
+  }
   SweepIO io;
   io.kind = kind;
   io.S = B;
@@ -1184,6 +1263,61 @@ int gpx_debug_set_potf2(gpx_ctx* ctx, const char* mode) {
   if (v == "slim") ctx->potf2_mode = gpx::GPX_POTF2_SLIM;
   else if (v == "tile") ctx->potf2_mode = gpx::GPX_POTF2_TILE;
   else return bad_arg(ctx, "potf2 kernel: slim | tile");
+  return 0;
+}
+
+int gpx_debug_set_lat_gemm(gpx_ctx* ctx, const char* mode) {
+  if (!ctx || !mode) return -1;
+  const std::string v(mode);
+  if (v == "r5") ctx->lat_gemm = 5;
+  else if (v == "r1") ctx->lat_gemm = 1;
+  else if (v == "auto") ctx->lat_gemm = 0;
+  else return bad_arg(ctx, "latency-shape GEMM: auto | r5 | r1");
+  return 0;
+}
+
+int gpx_debug_gemm_time(gpx_ctx* ctx, int tiles_m, int tiles_n, int K, int mode, int lower, int shape, int reps,
+                        double* ms_per_launch) {
+  if (!ctx || ctx->device < 0) return -1;
+  if (tiles_m < 1 || tiles_n < 1 || K < 16 || K % 16 != 0 || reps < 1 || mode < 0 || mode > 2 || !ms_per_launch)
+    return bad_arg(ctx, "gemm timing arguments");
+  if (mode == 2 && (tiles_n != 1 || K != TILE)) return bad_arg(ctx, "in-place form: tiles_n = 1, K = 128");
+  GPX_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t lda = pick_ld(K), ldc = pick_ld((int64_t)tiles_n * TILE);
+  const size_t ab = (size_t)tiles_m * TILE * lda * sizeof(double), bb = (size_t)tiles_n * TILE * lda * sizeof(double),
+               cb = (size_t)tiles_m * TILE * ldc * sizeof(double);
+  GPX_TRY(ensure(ctx, ctx->tA, ab));
+  GPX_TRY(ensure(ctx, ctx->tB, bb));
+  GPX_TRY(ensure(ctx, ctx->tC, cb));
+  // every byte 0x3f: the double 0x3f3f3f3f3f3f3f3f = 4.8e-4 — finite, non-zero, and small enough that repeated updates stay finite
+  GPX_HIP(ctx, hipMemsetAsync(ctx->tA.p, 0x3f, ab, ctx->stream));
+  GPX_HIP(ctx, hipMemsetAsync(ctx->tB.p, 0x3f, bb, ctx->stream));
+  GPX_HIP(ctx, hipMemsetAsync(ctx->tC.p, 0x3f, cb, ctx->stream));
+  GemmArgs g{};
+  g.A = ctx->tA.d();
+  g.lda = lda;
+  g.B = ctx->tB.d();
+  g.ldb = lda;
+  g.C = mode == 2 ? ctx->tA.d() : ctx->tC.d();
+  g.ldc = mode == 2 ? lda : ldc;
+  g.K = K;
+  g.alpha = mode == 1 ? -1.0 : (mode == 2 ? 1e-3 : 1.0); // (in place: the result feeds the next repetition — keep it small)
+  g.beta = mode == 1 ? 1.0 : 0.0;
+  g.lower = lower;
+  g.latency_shape = shape == 1;
+  g.big_shape = shape == 2;
+  ctx->s = ctx->stream;
+  ctx->small_bk_now = ctx->small_bk != 0 ? ctx->small_bk : 16;
+  const double work = 2.0 * tiles_m * TILE * (double)tiles_n * TILE * K * (lower ? 0.5 : 1.0);
+  for (int r = 0; r < 3; ++r) GPX_TRY(launch_gemm_nt(ctx, g, tiles_m, tiles_n, 0, GPX_PROF_GEMM_OTHER, work)); // warm-up
+  GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  GPX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  for (int r = 0; r < reps; ++r) GPX_TRY(launch_gemm_nt(ctx, g, tiles_m, tiles_n, 0, GPX_PROF_GEMM_OTHER, work));
+  GPX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  GPX_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  GPX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *ms_per_launch = (double)ms / reps;
   return 0;
 }
 

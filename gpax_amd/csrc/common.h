@@ -33,6 +33,21 @@ constexpr int SMALL_BK_ROWS = 40;
 constexpr int FAR_AFTER_U1 = 40;
 enum { GPX_POTF2_SLIM = 0, GPX_POTF2_TILE = 2 }; // gpx_ctx::potf2_mode
 
+// k(r2) of the three kernels (gpax/kernels/kernels.py:44-117) — shared by the Gram build (gram.hip) and the fused small-N
+// fit step (fit_small.hip), so that both produce the same matrix bit for bit
+template <int KIND>
+__device__ __forceinline__ double kernel_value(double r2, double scale) {
+  if (KIND == GPX_KERNEL_RBF) {
+    return scale * exp(-0.5 * r2);
+  } else if (KIND == GPX_KERNEL_PERIODIC) { // r2 carries sum_k (sin(pi (x_k - z_k) / p) / l_k)^2
+    return scale * exp(-2.0 * r2);
+  } else {
+    const double r = sqrt(r2 + MATERN_EPS);
+    const double s5r = SQRT5 * r;
+    return scale * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);
+  }
+}
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -167,6 +182,16 @@ struct gpx_ctx {
   // sweeps lose 3 - 6 % of their occupancy-bound throughput).  Never changes a bit.
   int small_bk = 0;
   int small_bk_now = 16;
+  // latency-shape GEMM: 5 = round 5 (gemm_tile.h lat_tile: LDS-direct staging, ring of 64-B k-slices, one barrier per
+  // slice) | 1 = round 1 (register staging, padded LDS, two barriers per k-step of 16 / 32) | 0 = by driver (default):
+  // round 5 wherever the chain has the chip to itself (one-outer-block factorisations, the L^-T trees, the sparse path's
+  // M x M chains and products: C2 fit step -1.6 %, C5 sparse step -1.5 %, tree levels at K >= 512 1.2 - 1.4 x), round 1
+  // inside the BLOCKED two-stream sweeps, whose chain launches share every SIMD with two MFMA-saturating waves of the
+  // trailing update — there a barrier costs what the slowest of four contended waves costs, and 16 of them per K = 128
+  // lose to 8 (C3: gemm_other 18.4 -> 20.3 ms per predict, potrf 29.4 -> 29.7; profiles/r05/lat_gemm_ab.md).  Same bits.
+  // GPX_LAT_GEMM=r5|r1 / gpx_debug_set_lat_gemm force one everywhere.
+  int lat_gemm = 0;
+  int lat_now = 5; // the kernel the launches of the current driver call take (set by the drivers from lat_gemm)
   hipEvent_t evD = nullptr;
   // > 0 while a driver whose own panel chain holds no potf2 (the right-looking TRSM sweeps, the K^-1 = W W^T product)
   // is queueing launches: its big-tile GEMMs run persistently (GPX_PERSIST_SCOPE=0 disables)
@@ -196,10 +221,11 @@ struct gpx_ctx {
   gpx::DevBuf K;     // Np x ldk : Gram -> L (lower) -> K^-1 (lower)
   gpx::DevBuf W;     // Np x ldk : L^-T (upper), allocated on first gradient
   gpx::DevBuf Wscr;  // Np x ldk : scratch of the L^-T tree (linalg.hip: T and the transposed C blocks of one level)
-  // GPX_SGP_SOLVE = ride (2, default, round 5: W = Kfu Luu^-T as a blocked solve that follows the Cholesky chain of Kuu
-  // group by group, the L^-T trees on the side stream) | inverse (1, round 3 / 4: factor, tree, then ONE GEMM against
-  // Luu^-1) | sweep (0, round 2: right-looking sweeps)  (sparse.hip)
-  int sgp_inverse = 2;
+  // GPX_SGP_SOLVE = inverse (1, default: factor Kuu, L^-T tree, then W = Kfu Luu^-T as ONE GEMM against Luu^-1) | ride (2,
+  // round 5: W as a blocked solve that follows the Cholesky chain of Kuu group by group, the trees on the side stream —
+  // measured equal: the chain runs 2.7 x slower beside the tall GEMMs, profiles/r05/sparse_ride.md) | sweep (0, round 2:
+  // right-looking sweeps)  (sparse.hip)
+  int sgp_inverse = 1;
   int linvt_tree = 1; // GPX_LINVT=tree|sweep: L^-T by the block-recursive inverse (default) or the right-looking sweep
   gpx::DevBuf Linv;  // (Np/128) x 128 x 128 inverses of the diagonal blocks of L
   gpx::DevBuf yres;  // N
@@ -210,6 +236,12 @@ struct gpx_ctx {
   gpx::DevBuf alpha; // N
   gpx::KernelParams theta{};
   double noise = 0, jitter = 0;
+  // N <= 127: the whole fit step (Gram, factorisation, lml terms, alpha, K^-1, gradient contraction) as ONE launch
+  // (fit_small.hip; GPX_FIT_SMALL=0: the general launch sequence).  small_grad_ready: the gradient of the factorisation in
+  // K already sits in the plan's scal / ctx->alpha — dev_grad has nothing left to launch
+  bool fit_small = true;
+  bool small_grad_ready = false;
+  unsigned fit_small_attr = 0; // fit_small_kernel variants whose dynamic-LDS limit this context has raised on its device
   bool factored = false;
   bool have_kinv = false; // K holds K^-1 and alpha is resident (after the gradient pass)
   bool fused_vt = false; // rows Np.. of K hold k_pX L^-T from a fused factorisation
@@ -235,6 +267,7 @@ struct gpx_ctx {
   // ---- batched sweep state (gpx_predict_sweep / gpx_sweep_resident) -----------------------
   gpx::DevBuf st_eps, st_yres, st_means, st_samples, st_infos, st_vars, st_pred; // sweep I/O staging (grow-only)
   gpx::PinBuf pin_in, pin_out, pin_x;                                            // page-locked host side of it
+  gpx::PinBuf pin_fit; // small-N fit batches: [theta table | residuals | results] read and written by the kernel itself
   gpx::DevBuf thtab;   // S x ThetaDev
   gpx::DevBuf binfo;   // 2 x B ints (train / cov pivots of the batch in flight)
   gpx::DevBuf bscal;   // B x 32 doubles: lml pieces + gradient of every entry of a fit batch
@@ -366,6 +399,12 @@ int mfma_peak(gpx_ctx* ctx, double* tflops);
 // potf2.hip
 int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo,
                      int info_base, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0);
+
+// fit_small.hip: lml + gradient of `batch` hyper-parameter vectors at N <= 127 in one launch
+int launch_fit_small(gpx_ctx* ctx, const KernelParams& kp, double diag_train, const ThetaDev* th, TaskStride ts,
+                     const double* dX, int N, const double* dy, int64_t y_bs, int y_mod, double* dK, int64_t ldk,
+                     int64_t k_bs, double* dLinv, int64_t linv_bs, double* dalpha, int64_t alpha_bs, double* dscal,
+                     int64_t scal_bs, int* dinfo, int want_grad, int batch);
 
 // linalg.hip
 int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, double* dLinv,

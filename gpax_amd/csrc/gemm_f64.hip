@@ -44,6 +44,15 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)
   gemm_nt_tile<MT, NT, BK, DBUF>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// round-5 latency shapes (gemm_tile.h lat_tile): <2,2> 64 x 64 (ring of 3 k-slices, 24 KB), <1,4> 32 x 128 strips for the
+// in-place panel TRSM (ring of 2, 20 KB); <= 80 VGPRs: six waves per SIMD alone, one beside two trailing-update workgroups
+template <int MT, int NT, int NST, int EPI>
+__global__ __launch_bounds__(256, 6) void gemm_lat_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __builtin_amdgcn_s_setprio(2); // chain launches sit on the critical path of the look-ahead
+  lat_tile<MT, NT, NST, EPI>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 template <int TAG, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -167,6 +176,25 @@ static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int til
   return 0;
 }
 
+template <int MT, int NT, int NST, int EPI>
+static int launch_lat_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n) {
+  constexpr size_t lds = (size_t)NST * (32 * MT + 32 * NT) * 8 * sizeof(double); // < 48 KB: no attribute needed
+  dim3 grid(tiles_n * (4 / NT), tiles_m * (4 / MT), g.nsplit * g.batch);
+  gemm_lat_kernel<MT, NT, NST, EPI><<<grid, 256, lds, ctx->s>>>(g);
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+template <int MT, int NT, int NST>
+static int launch_lat(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int tiles_n, int splits) {
+  GemmArgs g = g0;
+  g.nsplit = splits > 0 ? splits : 1;
+  if (g.batch < 1) g.batch = 1;
+  if (g.beta == 0.0) return launch_lat_epi<MT, NT, NST, 0>(ctx, g, tiles_m, tiles_n);
+  if (g.alpha == -1.0 && g.beta == 1.0) return launch_lat_epi<MT, NT, NST, 1>(ctx, g, tiles_m, tiles_n);
+  return launch_lat_epi<MT, NT, NST, 2>(ctx, g, tiles_m, tiles_n);
+}
+
 template <int TAG, int EPI>
 static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n) {
   constexpr size_t lds = (size_t)2 * 256 * 16 * sizeof(double); // 2 buffers x (128 A rows + 128 B rows) x 128 B
@@ -248,7 +276,13 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   constexpr double small_max = 400.0; // launches with fewer 128x128 tiles take the latency shapes (profiles/r02/chain_experiments.md)
   if (g.big_shape && g.C != g.A && !on_panel) return launch_big<0>(ctx, g, tiles_m, tiles_n, splits);
   if (tiles < small_max || on_panel || g.latency_shape) {
-    if (g.C == g.A) { // in-place (panel TRSM): one workgroup must own the whole row width
+    if ((ctx->lat_gemm != 0 ? ctx->lat_gemm : ctx->lat_now) == 5) { // round-5 latency shapes; else the register-staged kernels below
+      if (g.C == g.A) {
+        if (tiles_n == 1) return launch_lat<1, 4, 2>(ctx, g, tiles_m, tiles_n, splits);
+      } else {
+        return launch_lat<2, 2, 3>(ctx, g, tiles_m, tiles_n, splits);
+      }
+    } else if (g.C == g.A) { // in-place (panel TRSM): one workgroup must own the whole row width
       // 32x128 strip, single LDS buffer: 22 KB and < 80 VGPRs, i.e. it fits in what two resident trailing-update
       // workgroups leave free on a CU (32 KB, 80 registers per SIMD) and is placed at once; the round-1 64x128 shape
       // (52 KB, 125 VGPRs) had to wait for a trailing workgroup to retire — half a tile time (~50 us) per panel step

@@ -203,9 +203,201 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g, double* smem, co
   }
 }
 
-// ---- throughput shape -------------------------------------------------------------------------------
 typedef void __attribute__((address_space(3)))* lds_ptr_t;
 typedef const volatile double __attribute__((address_space(3)))* lds_cvd_t;
+
+// ---- latency shapes, round 5 ---------------------------------------------------------------------------
+// The same (32 MT) x (32 NT) tiles as gemm_nt_tile above (64 x 64, and 32 x 128 strips for the in-place panel TRSM) on the
+// staging of the throughput shape: LDS-direct loads (`buffer_load_dwordx4 ... lds`: no staging VGPRs, no ds_write),
+// unpadded swizzled rows, ONE barrier per k-slice, the epilogue form a template parameter (the generic-beta epilogue no
+// longer rides in every instantiation: the strip kernel spilled 22 - 26 VGPRs for code its launches never run).
+// A k-slice is BK = 8 doubles = 64-B rows in LDS, a ring of NST slices: the loads of slice t + NST - 1 are issued at the
+// top of slice t (NST = 3: two slices = 2 x 8 KB in flight per workgroup while the third is multiplied), so a K = 128
+// update is 16 slices behind ONE exposed load latency instead of 8 (BK = 16) exposed global -> VGPR -> LDS round trips
+// with two barriers each.  (32 MT + 32 NT) x 64 B x NST: 24 KB for 64 x 64 with three slices, 20 KB for the strips with two —
+// both fit in what two resident trailing-update workgroups leave free on a CU (32 KB, 80 VGPRs per SIMD; tests/test_abi.py).
+// One wave-instruction = 64 lanes x 16 B = 16 LDS rows of 64 B; lane -> row (lane >> 2), LDS chunk (lane & 3), which holds
+// SOURCE chunk (lane & 3) ^ ((row >> 2) & 3): a fragment read (16 rows x one chunk per half-wave) then touches all 16
+// chunk positions of the 256-B bank row once — conflict-free ds_read_b64, as in nt128_tile.
+// Arithmetic: every C element accumulates its k range in ascending k from the same start value with the same epilogue as
+// in every other shape — bit-identical to gemm_nt_tile and nt128_tile.
+template <int MT, int NT, int NST, int EPI>
+__device__ __forceinline__ void lat_tile(const GemmArgs& g, double* smem, const int bx, const int by, const int bzz) {
+  constexpr int BK = 8, BM = 32 * MT, BN = 32 * NT, SD = (BM + BN) * BK; // doubles per slice buffer
+  constexpr int NIA = BM / 16, NIB = BN / 16;                             // wave-instructions per slice: A rows, B rows
+  constexpr int LA = NIA >= 4 ? NIA / 4 : 1, LB = NIB >= 4 ? NIB / 4 : 1; // ... per wave (NIA < 4: waves share them)
+  static_assert(NST == 2 || NST == 3, "ring of 2 or 3 slices");
+  const int bb = (g.batch > 1) ? bzz / g.nsplit : 0;
+  const int bz = bzz - bb * g.nsplit;
+  int64_t off_a, off_b, off_c;
+  batch_offsets(g, bb, off_a, off_b, off_c);
+  const int row0 = g.ti_off * 128 + by * BM, col0 = g.tj_off * 128 + bx * BN;
+  if (g.lower && col0 > row0 + BM - 1) return; // entirely above the diagonal
+
+  int kb = 0, ke = g.K;
+  if (g.ktri) kb = row0 & ~15;
+  if (g.kcol) kb = max(kb, col0 & ~15);
+  if (g.kupper) ke = min(ke, col0 + BN);
+  double* C = g.C + off_c; // may alias A (in-place panel TRSM): the whole k range is read before the first store
+  if (g.kchunk > 0) {
+    kb = max(kb, bz * g.kchunk);
+    ke = min(ke, (bz + 1) * g.kchunk);
+    C += (int64_t)bz * g.c_split_stride;
+  }
+  const int nk = (ke > kb) ? (ke - kb) / BK : 0;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + off_a + (int64_t)by * BM * g.lda), 0, 0x7fffffff, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + off_b + (int64_t)bx * BN * g.ldb), 0, 0x7fffffff, 0x00020000);
+  // staging map: instruction ia covers LDS rows [16 ia, 16 ia + 16) of the A part, ib likewise of the B part
+  int voffA[LA], voffB[LB], ldsA[LA], ldsB[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) {
+    const int ia = (wave * LA + i) % NIA;
+    const int row = ia * 16 + (lane >> 2);
+    voffA[i] = (int)(((int64_t)row * g.lda + (((lane & 3) ^ ((row >> 2) & 3)) * 2)) * 8);
+    ldsA[i] = ia * 16 * BK;
+  }
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    const int ib = (wave * LB + i) % NIB;
+    const int row = ib * 16 + (lane >> 2);
+    voffB[i] = (int)(((int64_t)row * g.ldb + (((lane & 3) ^ ((row >> 2) & 3)) * 2)) * 8);
+    ldsB[i] = (BM + ib * 16) * BK;
+  }
+
+  double* Cw = C + ((int64_t)by * BM + wr * 16 * MT + fk) * g.ldc + (int64_t)bx * BN + wc * 16 * NT + fr;
+  d4_t acc[MT][NT];
+  if (EPI == 1) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n][r] = -Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16];
+  } else {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = d4_t{0.0, 0.0, 0.0, 0.0};
+  }
+
+  // fragment offsets (doubles) in a slice: row * 8 + ((k >> 1) ^ ((row >> 2) & 3)) * 2 + (k & 1), k = 4 kk + fk: block kk = 1 is
+  // `offset ^ 4` (2 kk only touches bit 1 of the chunk index)
+  int aoff[MT], boff[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int ra = wr * 16 * MT + m * 16 + fr;
+    aoff[m] = ra * BK + (((fk >> 1) ^ ((ra >> 2) & 3)) * 2) + (fk & 1);
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int rb = BM + wc * 16 * NT + n * 16 + fr;
+    boff[n] = rb * BK + (((fk >> 1) ^ ((rb >> 2) & 3)) * 2) + (fk & 1);
+  }
+
+#define GPX_LAT_ISSUE(slice, buf)                                                                                       \
+  do {                                                                                                                  \
+    const int soff_ = (kb + (slice) * BK) * 8;                                                                          \
+    _Pragma("unroll") for (int i = 0; i < LA; ++i)                                                                      \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(smem + (buf) * SD + ldsA[i]), 16, voffA[i], soff_, 0, 0); \
+    _Pragma("unroll") for (int i = 0; i < LB; ++i)                                                                      \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(smem + (buf) * SD + ldsB[i]), 16, voffB[i], soff_, 0, 0); \
+  } while (0)
+#define GPX_LAT_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+  // one k-slice out of buffer `cur`: all fragments of both 4-deep blocks first (8 - 10 ds_read_b64), then the MFMAs
+#define GPX_LAT_COMPUTE(cur)                                                                      \
+  do {                                                                                            \
+    const double* cb_ = smem + (cur) * SD;                                                        \
+    double af_[2][MT], bf_[2][NT];                                                                \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                            \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) af_[kk][m] = *((lds_cvd_t)cb_ + (aoff[m] ^ (4 * kk))); \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) bf_[kk][n] = *((lds_cvd_t)cb_ + (boff[n] ^ (4 * kk))); \
+    }                                                                                             \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                              \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m)                                              \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n)                                            \
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af_[kk][m], bf_[kk][n], acc[m][n], 0, 0, 0); \
+  } while (0)
+  // workgroup barrier WITHOUT the fence of __syncthreads (which drains vmcnt: the slice in flight behind the next one
+  // would be waited for at every barrier).  What has to be visible is stated explicitly: this wave's LDS-DMA loads of
+  // the NEXT slice (GPX_LAT_WAIT) — its own ds_reads of the current one were consumed by the MFMAs above.
+#define GPX_LAT_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+  if (nk > 0) {
+    GPX_LAT_ISSUE(0, 0);
+    if (NST == 3 && nk > 1) {
+      GPX_LAT_ISSUE(1, 1);
+      GPX_LAT_WAIT(LA + LB);
+    } else {
+      GPX_LAT_WAIT(0);
+    }
+    GPX_LAT_BARRIER();
+    int cur = 0, t = 0;
+    // steady state: the loads of slice t + NST - 1 go out, slice t is multiplied, slice t + 1 has landed at the barrier
+    for (; t + NST - 1 < nk; ++t) {
+      int nb = cur + NST - 1;
+      if (nb >= NST) nb -= NST;
+      GPX_LAT_ISSUE(t + NST - 1, nb);
+      GPX_LAT_COMPUTE(cur);
+      if (NST == 3) GPX_LAT_WAIT(LA + LB);
+      else GPX_LAT_WAIT(0);
+      GPX_LAT_BARRIER();
+      cur = (cur + 1 == NST) ? 0 : cur + 1;
+    }
+    // the last NST - 1 slices: nothing left to issue
+    for (; t < nk; ++t) {
+      GPX_LAT_COMPUTE(cur);
+      if (t + 1 < nk) {
+        GPX_LAT_WAIT(0);
+        GPX_LAT_BARRIER();
+      }
+      cur = (cur + 1 == NST) ? 0 : cur + 1;
+    }
+  }
+#undef GPX_LAT_COMPUTE
+#undef GPX_LAT_BARRIER
+#undef GPX_LAT_ISSUE
+#undef GPX_LAT_WAIT
+
+  const double alpha = g.alpha, beta = g.beta;
+  if (EPI == 1) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = -acc[m][n][r];
+  } else if (EPI == 2) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      double cv[4][NT];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) cv[r][n] = Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = fma(beta, cv[r][n], alpha * acc[m][n][r]);
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = alpha * acc[m][n][r];
+  }
+}
+
+// ---- throughput shape -------------------------------------------------------------------------------
 
 // EPI: 0 beta == 0 | 1 alpha == -1, beta == 1 (accumulators start from -C) | 2 generic read-modify-write
 // TAG only gives the Cholesky trailing update (TAG = 1) its own symbol, so that rocprofv3 kernel statistics

@@ -17,19 +17,6 @@ namespace gpx {
 constexpr int GT_ROWS = 32;
 constexpr int GT_COLS = 512;
 
-template <int KIND>
-__device__ __forceinline__ double kernel_value(double r2, double scale) {
-  if (KIND == GPX_KERNEL_RBF) {
-    return scale * exp(-0.5 * r2);
-  } else if (KIND == GPX_KERNEL_PERIODIC) { // r2 carries sum_k (sin(pi (x_k - z_k) / p) / l_k)^2
-    return scale * exp(-2.0 * r2);
-  } else {
-    const double r = sqrt(r2 + MATERN_EPS);
-    const double s5r = SQRT5 * r;
-    return scale * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);
-  }
-}
-
 template <int KIND, int D>
 __global__ __launch_bounds__(256) void gram_kernel(KernelParams kpv, const double* __restrict__ X,
                                                    int n, int n_pad,

@@ -159,6 +159,13 @@ int potrf_lower(gpx_ctx* ctx, double* dA, int64_t lda, int np, int extra_tiles, 
   // fewer than `tail_tiles` tile rows behind it): one outer block per update.  Every combination gives the same bits.
   const int tail_tiles = ctx->tail_tiles;
   const int nouter = (nblk + OT - 1) / OT;
+  // latency-shape kernel of this call's chain launches (common.h lat_gemm): round 5 with the chip to itself, round 1 beside
+  // the trailing updates of the blocked schedule; whatever follows this call starts from round 5 again
+  ctx->lat_now = (nouter == 1) ? 5 : 1;
+  struct LatReset {
+    gpx_ctx* c;
+    ~LatReset() { c->lat_now = 5; }
+  } lat_reset{ctx};
   if (nouter == 1) {
     // one outer block (N <= 512, and single-sample factorisations up to ONE_BLOCK_TILES tile rows): nothing to look ahead over — the chain runs on the main stream, without the two
     // cross-stream event waits of the look-ahead (~10 - 18 us each at this size)
@@ -269,6 +276,11 @@ int trsm_right_lt(gpx_ctx* ctx, double* dB, int64_t ldb, int rows_t, const doubl
   const int nouter = (nblk + OT - 1) / OT;
   GPX_TRY(ensure_events(ctx, nouter));
   hipStream_t smain = ctx->stream, span = ctx->pstream;
+  ctx->lat_now = (nouter == 1) ? 5 : 1; // (as in potrf_lower)
+  struct LatReset {
+    gpx_ctx* c;
+    ~LatReset() { c->lat_now = 5; }
+  } lat_reset{ctx};
   GPX_HIP(ctx, hipEventRecord(ctx->evU[nouter], smain));
   GPX_HIP(ctx, hipStreamWaitEvent(span, ctx->evU[nouter], 0));
   // This sweep's panel chain has no diagonal-block factorisation (the blocks of L come inverted): every chain launch

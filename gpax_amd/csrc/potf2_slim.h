@@ -371,8 +371,11 @@ __device__ __forceinline__ void potf2_slim_worker(double* A, int64_t lda, double
 }
 
 // ---- the chain wave (potf2_chain.h's, on this kernel's LDS map, as a loop) --------------------------------------------------
+// n_active: order of the leading part that holds data — the block is the identity from there on (fit_small.hip: N + 1 of 128).
+// A diagonal tile that lies wholly in the identity part factors into itself: its 16 dependent column steps (2.4 us of the
+// chain wave's time per tile) are skipped; everything else — barriers, T / U, the workers — runs as always.
 __device__ __forceinline__ void potf2_slim_chain_wave(double* A, int64_t lda, double* Linv, int* info, int info_base, double* lds,
-                                                      int lane) {
+                                                      int lane, int n_active = PB) {
   double* Dg = lds + PSL_DG * TSZ;
   double* col = lds + PSL_TILES * TSZ;
   GPX_SLIM_TRACE_BEGIN(0);
@@ -391,7 +394,17 @@ __device__ __forceinline__ void potf2_slim_chain_wave(double* A, int64_t lda, do
 #pragma unroll 1
   for (int P = 0; P < 8; ++P) {
     double* Dinv = lds + (PSL_DINV + (P & 1)) * TSZ;
-    diag16(Dg, Dinv, col, lane, bad, P * TS);
+    if (P * TS < n_active) {
+      diag16(Dg, Dinv, col, lane, bad, P * TS);
+    } else { // identity tile: L = L^-1 = I
+      const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = 4 * q + t;
+        Dg[r * TLD + i] = (r == i) ? 1.0 : 0.0;
+        Dinv[i * TLD + r] = (r == i) ? 1.0 : 0.0;
+      }
+    }
     {
       const int r = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -426,10 +439,11 @@ __device__ __forceinline__ void potf2_slim_chain_wave(double* A, int64_t lda, do
 }
 
 // 256 threads: wave 0 = chain, waves 1 - 3 = workers.  Every wave passes the same 16 barriers.
-__device__ __forceinline__ void potf2_slim_body(double* A, int64_t lda, double* Linv, int* info, int info_base, double* lds) {
+__device__ __forceinline__ void potf2_slim_body(double* A, int64_t lda, double* Linv, int* info, int info_base, double* lds,
+                                                int n_active = PB) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (w == 0) potf2_slim_chain_wave(A, lda, Linv, info, info_base, lds, lane);
+  if (w == 0) potf2_slim_chain_wave(A, lda, Linv, info, info_base, lds, lane, n_active);
   else if (w == 1) potf2_slim_worker<1>(A, lda, Linv, lds, lane);
   else if (w == 2) potf2_slim_worker<2>(A, lda, Linv, lds, lane);
   else potf2_slim_worker<3>(A, lda, Linv, lds, lane);

@@ -490,7 +490,8 @@ struct SgpState {
   int npartW = 0; // partial sums of |W|_F^2 left in `part` by the forward pass
   uint64_t h_train_gen = 0;
   int h_kind = -1;
-  double h_par[GPX_MAX_DIM + 3] = {0};
+  double h_par[GPX_MAX_DIM + 4] = {0};
+  double kfu_diag = 0; // added to the diagonal of Kfu (same-shape rule of the reference's kernels; sgp_setup)
   std::vector<double> h_Xu, h_y;
 };
 
@@ -522,16 +523,20 @@ static double kd_value(const KernelParams& kp) {
   return kp.scale * (1.0 + SQRT5 * r) * std::exp(-SQRT5 * r);
 }
 
+// kfu_diag: what the reference's call of the kernel for Kuf adds to its diagonal.  The kernels add (noise + jitter) I iff
+// the two inputs have the SAME SHAPE (kernels.py:63-65), and viSparseGP.model calls `kernel(Xu, X, params)` with the default
+// jitter 1e-6 (sparse_gp.py:96): with as many inducing points as training points Kuf carries 1e-6 on its diagonal in the
+// bound — and nothing in get_mvn_posterior, which passes jitter=0 (sparse_gp.py:196).  Part of the reuse key.
 static int sgp_setup(gpx_ctx* ctx, SgpState* s, int kind, const double* ell, double scale, double noise,
-                     double jitter, const double* Xu, int Mi, const double* yres) {
+                     double jitter, const double* Xu, int Mi, const double* yres, double kfu_diag) {
   if (ctx->N < 1) return bad_arg(ctx, "gpx_set_train must be called first");
   if (kind != GPX_KERNEL_RBF && kind != GPX_KERNEL_MATERN52) return bad_arg(ctx, "kernel kind");
   if (Mi < 1 || !Xu || !ell || !yres) return bad_arg(ctx, "sparse GP arguments");
   const int d = ctx->d;
   {
-    double par[GPX_MAX_DIM + 3] = {0};
+    double par[GPX_MAX_DIM + 4] = {0};
     for (int c = 0; c < d; ++c) par[c] = ell[c];
-    par[GPX_MAX_DIM] = scale; par[GPX_MAX_DIM + 1] = noise; par[GPX_MAX_DIM + 2] = jitter;
+    par[GPX_MAX_DIM] = scale; par[GPX_MAX_DIM + 1] = noise; par[GPX_MAX_DIM + 2] = jitter; par[GPX_MAX_DIM + 3] = kfu_diag;
     const size_t xb = (size_t)Mi * d * 8, yb = (size_t)ctx->N * 8;
     s->reuse = s->fwd_valid && s->h_train_gen == ctx->train_gen && s->h_kind == kind && s->M == Mi &&
                std::memcmp(par, s->h_par, sizeof(par)) == 0 && s->h_Xu.size() * 8 == xb && s->h_y.size() * 8 == yb &&
@@ -561,6 +566,7 @@ static int sgp_setup(gpx_ctx* ctx, SgpState* s, int kind, const double* ell, dou
   s->kp.scale = scale;
   s->noise = noise;
   s->jitter = jitter;
+  s->kfu_diag = kfu_diag;
   GPX_TRY(ens(ctx, s->Xu, (size_t)Mi * d * 8));
   GPX_HIP(ctx, hipMemcpyAsync(s->Xu.d(), Xu, (size_t)Mi * d * 8, hipMemcpyHostToDevice, ctx->stream));
   GPX_HIP(ctx, hipMemcpyAsync(ctx->yres.d(), yres, (size_t)ctx->N * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -627,7 +633,7 @@ static int sgp_factor_ride(gpx_ctx* ctx, SgpState* s, int* dinfo) {
   GPX_HIP(ctx, hipMemsetAsync(Tu, 0, (size_t)Mp * s->ldu * sizeof(double), sside)); // zero below the diagonal: Tu enters full GEMMs
   // R = Kfu on the main stream, beside the first chain steps
   ctx->s = smain;
-  GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), ctx->N, Ntp, s->Xu.d(), s->M, Mp, 0.0, 0, 0, s->Kfu.d(), s->ldw));
+  GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), ctx->N, Ntp, s->Xu.d(), s->M, Mp, s->kfu_diag, s->kfu_diag != 0.0, 0, s->Kfu.d(), s->ldw));
   int rc = 0;
   for (int g = 0; g < ng && rc >= 0; ++g) {
     const int a = gb[(size_t)g], b = gb[(size_t)g + 1], w = b - a;
@@ -749,21 +755,26 @@ static int sgp_forward_run(gpx_ctx* ctx, SgpState* s) {
   int* dinfo = s->scal.i() + 1024;
   GPX_HIP(ctx, hipMemsetAsync(dinfo, 0, 2 * sizeof(int), ctx->stream));
   if (ctx->sgp_inverse == 2) return sgp_forward_ride(ctx, s);
+  GPX_TRY(sgp_events(ctx, s, SGP_EV_GROUPS));
+  SgpJoin join{ctx, s->evG[SGP_EV_JOIN1], s->evG[SGP_EV_JOIN2]}; // every way out: the main stream waits for the others
   if (ctx->sgp_inverse) {
-    // (round 4, GPX_SGP_SOLVE=inverse) Kfu = k(X, Xu) waits for nothing of the Kuu branch: on the panel stream, beside the latency-bound Cholesky chain
-    // of Kuu (a 16-step chain at M = 2048 that leaves the chip idle), joined again before the solve that reads it
+    // (rounds 4 / 5, GPX_SGP_SOLVE=inverse: the default) Kfu = k(X, Xu) waits for nothing of the Kuu branch: on the SIDE
+    // stream, beside the latency-bound Cholesky chain of Kuu (a 16-step chain at M = 2048 that leaves the chip idle),
+    // joined again before the solve that reads it.  (Round 4 queued it on the panel stream, which a blocked factorisation
+    // of Kuu — more than ONE_BLOCK_TILES tile rows, or GPX_OUTER_TILES set — would also have used for its chain: the
+    // build then delayed the chain instead of hiding beside it.  ADVICE r4.)
     if (!s->evFork) {
       GPX_HIP(ctx, hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming));
       GPX_HIP(ctx, hipEventCreateWithFlags(&s->evJoin, hipEventDisableTiming));
     }
     GPX_TRY(ens(ctx, s->Kfu, (size_t)Ntp * s->ldw * 8));
     GPX_HIP(ctx, hipEventRecord(s->evFork, ctx->stream)); // Xu, X, theta are in place
-    GPX_HIP(ctx, hipStreamWaitEvent(ctx->pstream, s->evFork, 0));
-    ctx->s = ctx->pstream;
-    const int rc_kfu = launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->Kfu.d(), s->ldw);
+    GPX_HIP(ctx, hipStreamWaitEvent(ctx->xstream, s->evFork, 0));
+    ctx->s = ctx->xstream;
+    const int rc_kfu = launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, s->kfu_diag, s->kfu_diag != 0.0, 0, s->Kfu.d(), s->ldw);
     ctx->s = ctx->stream;
     GPX_TRY(rc_kfu);
-    GPX_HIP(ctx, hipEventRecord(s->evJoin, ctx->pstream));
+    GPX_HIP(ctx, hipEventRecord(s->evJoin, ctx->xstream));
   }
   // Kuu = kernel(Xu, Xu, params, **jitter): noise defaults to 0 (sparse_gp.py:92)
   GPX_TRY(launch_gram_padded(ctx, s->kp, s->Xu.d(), M, Mp, s->Xu.d(), M, Mp, s->jitter, 1, 1, s->Kuu.d(), s->ldu));
@@ -778,7 +789,7 @@ static int sgp_forward_run(gpx_ctx* ctx, SgpState* s) {
     GPX_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->evJoin, 0)); // Kfu (built on the panel stream, above)
     GPX_TRY(solve_by_inverse(ctx, s->Kfu.d(), s->ldw, ntl, s->Vu.d(), s->ldu, mt, s->Wn.d(), s->ldw));
   } else {
-    GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, 0.0, 0, 0, s->Wn.d(), s->ldw));
+    GPX_TRY(launch_gram_padded(ctx, s->kp, ctx->X.d(), N, Ntp, s->Xu.d(), M, Mp, s->kfu_diag, s->kfu_diag != 0.0, 0, s->Wn.d(), s->ldw));
     GPX_TRY(trsm_right_lt(ctx, s->Wn.d(), s->ldw, ntl, s->Kuu.d(), s->ldu, s->LinvU.d(), mt, 0));
   }
   { // Wt = W^T, and |W|_F^2 in partial sums on the way (the bound's trace term)
@@ -830,7 +841,7 @@ int gpx_sgp_bound(gpx_ctx* ctx, int kind, const double* ell, double scale, doubl
   if (!ctx || ctx->device < 0) return -1;
   GPX_HIP(ctx, hipSetDevice(ctx->device));
   SgpState* s = sgp_state(ctx);
-  GPX_TRY(sgp_setup(ctx, s, kind, ell, scale, noise, jitter, Xu, Mi, yres));
+  GPX_TRY(sgp_setup(ctx, s, kind, ell, scale, noise, jitter, Xu, Mi, yres, Mi == ctx->N ? 1e-6 : 0.0));
   GPX_TRY(sgp_forward(ctx, s));
   const int N = ctx->N, d = ctx->d, M = s->M, Mp = s->Mp, Ntp = s->Ntp, mt = Mp / TILE;
   const double s2 = noise, kd = kd_value(s->kp);
@@ -1007,7 +1018,7 @@ int gpx_sgp_posterior(gpx_ctx* ctx, int kind, const double* ell, double scale, d
   if (!Xnew || Ms < 1) return bad_arg(ctx, "sparse posterior arguments");
   GPX_HIP(ctx, hipSetDevice(ctx->device));
   SgpState* s = sgp_state(ctx);
-  GPX_TRY(sgp_setup(ctx, s, kind, ell, scale, noise, jitter, Xu, Mi, yres));
+  GPX_TRY(sgp_setup(ctx, s, kind, ell, scale, noise, jitter, Xu, Mi, yres, 0.0));
   GPX_TRY(sgp_forward(ctx, s));
   const int d = ctx->d, M = s->M, Mp = s->Mp, mt = Mp / TILE;
   const int Msp = round_up(Ms, TILE), st = Msp / TILE;

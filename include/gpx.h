@@ -269,6 +269,19 @@ int gpx_profile_read_bytes(gpx_ctx* ctx, int cls, double* total_bytes);
  * tests).  Both produce the same bits; bench.py uses it for the in-process A/B of the potf2 class.
  * The environment variable GPX_POTF2 sets the same thing at gpx_init. */
 int gpx_debug_set_potf2(gpx_ctx* ctx, const char* mode);
+/* Diagnostic: the latency-shape GEMM (64 x 64 tiles and 32 x 128 strips of the panel chains) for the following calls on
+ * this context — "r5" (csrc/gemm_tile.h lat_tile: LDS-direct staging, ring of k-slices), "r1" (round 1: register
+ * staging, the reference of the bit-identity tests) or "auto" (default: r5 wherever a chain has the chip to itself, r1
+ * inside the blocked two-stream sweeps; csrc/common.h).  Same bits from all.  GPX_LAT_GEMM at gpx_init. */
+int gpx_debug_set_lat_gemm(gpx_ctx* ctx, const char* mode);
+/* Diagnostic: device time of ONE GEMM launch of the library on resident scratch operands (constant, non-zero), average
+ * over `reps` back-to-back launches between two HIP events: C (tiles_m x tiles_n 128-tiles) from A (tiles_m*128 x K) and
+ * B (tiles_n*128 x K).  mode 0: C = A B^T; 1: C -= A B^T (the Cholesky / TRSM update form: accumulators start from -C);
+ * 2: the in-place panel TRSM A <- A B^T (tiles_n = 1, K = 128).  lower: lower tiles only.  shape 0: the shape
+ * launch_gemm_nt picks for that tile count; 1: latency shapes; 2: the 128 x 128 throughput shape.  What tools/
+ * lat_gemm_bench.py and bench.py quote for the chain GEMMs (the kernels under gpax/models/gp.py:160-164's Cholesky). */
+int gpx_debug_gemm_time(gpx_ctx* ctx, int tiles_m, int tiles_n, int K, int mode, int lower, int shape, int reps,
+                        double* ms_per_launch);
 
 /* Device-only timed repetitions (inputs resident in HBM; used by bench.py so that `value`
  * excludes PCIe).  Each call runs `reps` passes of the named stage at the theta/Xnew last set

@@ -168,8 +168,12 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
                 dict(GPX_PERSIST_SCOPE="0"),
                 # k-step of the latency shapes, the diagonal-block kernels
                 dict(GPX_SMALL_BK="32"), dict(GPX_SMALL_BK="16", GPX_LAZY_GROUP="3", GPX_OUTER_TILES="4"),
+                # the round-1 register-staged latency-shape GEMM (the default since round 5: lat_tile, LDS-direct staging)
+                dict(GPX_LAT_GEMM="r1"), dict(GPX_LAT_GEMM="r1", GPX_SMALL_BK="32", GPX_OUTER_TILES="2"),
+                dict(GPX_LAT_GEMM="r5"), dict(GPX_LAT_GEMM="r5", GPX_OUTER_TILES="4"),
                 dict(GPX_POTF2="tile", GPX_OUTER_TILES="2")]
-    switches = ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_PERSIST_SCOPE", "GPX_TAIL_TILES", "GPX_SMALL_BK", "GPX_POTF2")
+    switches = ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_PERSIST_SCOPE", "GPX_TAIL_TILES", "GPX_SMALL_BK", "GPX_POTF2",
+                "GPX_LAT_GEMM")
     for env in variants:
         for k in switches:
             monkeypatch.delenv(k, raising=False)

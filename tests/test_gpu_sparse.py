@@ -102,12 +102,14 @@ def test_solves_by_inverse_agree_with_the_sweeps(monkeypatch, N, Mi):
     """sparse.hip round 3: W = Kfu Luu^-T, V1 = Ksu Luu^-T, V2 = V1 LA^-T as ONE GEMM each against L^-1 (from the
     L^-T tree) and the gradient products trimmed to the triangle of Luu^-T / re-associated — against GPX_SGP_SOLVE=sweep
     (the right-looking solves of rounds 1 - 2): bound, every gradient component and the posterior agree to rounding, and
-    both agree with the oracle (sparse_gp.py:62-114, 173-223)."""
+    both agree with the oracle (sparse_gp.py:62-114, 173-223).  Round 5: so does GPX_SGP_SOLVE=ride, where W is the blocked
+    right-looking solve that follows the Cholesky chain of Kuu group by group on three streams (M = 700: groups of 2, 2 and
+    a ragged last one; M = 100: a single group)."""
     from gpax_amd import _lib
     X, y, Xn, p = bench_inputs.synthetic_problem(N, 2, 150, seed=5)
     Xu = X[np.random.default_rng(2).choice(N, Mi, replace=False)] + 1e-3
     outs = {}
-    for mode in ("inverse", "sweep"):
+    for mode in ("inverse", "sweep", "ride"):
         monkeypatch.setenv("GPX_SGP_SOLVE", mode)
         e = _lib.Engine(0)
         e.set_train(X)
@@ -117,18 +119,101 @@ def test_solves_by_inverse_agree_with_the_sweeps(monkeypatch, N, Mi):
         assert info == 0 and info2 == 0
         outs[mode] = (b, g, mean, cov, var)
         e.close()
-    a, s = outs["inverse"], outs["sweep"]
-    assert abs(a[0] - s[0]) <= 1e-10 * abs(s[0])
-    for k in ("k_length", "k_scale", "noise", "Xu", "yres"):
-        u, v = np.asarray(a[1][k], dtype=float), np.asarray(s[1][k], dtype=float)
-        np.testing.assert_allclose(u, v, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(v).max()))
-    np.testing.assert_allclose(a[2], s[2], rtol=0, atol=1e-9 * np.abs(s[2]).max())
-    np.testing.assert_allclose(a[3], s[3], rtol=0, atol=1e-9 * np.abs(s[3]).max())
+    s = outs["sweep"]
+    for a in (outs["inverse"], outs["ride"]):
+        assert abs(a[0] - s[0]) <= 1e-10 * abs(s[0])
+        for k in ("k_length", "k_scale", "noise", "Xu", "yres"):
+            u, v = np.asarray(a[1][k], dtype=float), np.asarray(s[1][k], dtype=float)
+            np.testing.assert_allclose(u, v, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(v).max()))
+        np.testing.assert_allclose(a[2], s[2], rtol=0, atol=1e-9 * np.abs(s[2]).max())
+        np.testing.assert_allclose(a[3], s[3], rtol=0, atol=1e-9 * np.abs(s[3]).max())
+    a = outs["inverse"]
     expect = ref.sparse_bound(X, y, Xu, p, kernel="Matern", jitter=1e-6)
     assert abs(a[0] - expect) <= 1e-8 * abs(expect)
     m_ref, c_ref = ref.sparse_posterior(X, y, Xu, Xn, p, noiseless=True, kernel="Matern", jitter=1e-6)
     np.testing.assert_allclose(a[2], m_ref, rtol=0, atol=1e-7 * np.abs(m_ref).max())
     np.testing.assert_allclose(a[3], c_ref, rtol=0, atol=1e-7 * np.abs(c_ref).max())
+
+
+@pytest.mark.parametrize("kind,name", KINDS)
+def test_clipped_trace_term_value_and_gradient(engine, kind, name):
+    """sparse_gp.py:100-104: trace_term = clip(N kd - |W|_F^2, a_min=0) — zero value AND zero gradient when clipped.  The
+    switch is evaluated on the device (mat_combine_kernel) and again on the host for the scale / noise terms (no
+    test exercised it).  Forced here with inducing points AT well separated training points and a NEGATIVE jitter:
+    Kuu = Kff - 1e-3 I (still positive definite) makes Qff = Kff Kuu^-1 Kff exceed Kff, so N kd - |W|_F^2 < 0.  Bound
+    against the oracle, gradients against central differences of the oracle (whose clip has the same zero slope)."""
+    rng = np.random.default_rng(4)
+    g1 = np.arange(12, dtype=float)
+    X = np.stack(np.meshgrid(g1, g1, indexing="ij"), axis=-1).reshape(-1, 2) + 0.05 * rng.standard_normal((144, 2))
+    X[-1] = X[-2] + 0.01  # the one training point without an inducing point of its own sits next to one
+    y = np.sin(X[:, 0]) + 0.1 * rng.standard_normal(144)
+    Xu = X[:-1].copy()  # (all but one: with M = N the same-shape rule also puts 1e-6 on the diagonal of Kuf — next test)
+    ell, scale, noise, jit = np.array([0.35, 0.4]), 1.2, 0.05, -1e-3
+    p = {"k_length": ell, "k_scale": scale, "noise": noise}
+    engine.set_train(X)
+    bound, info, g = engine.sgp_bound(kind, ell, scale, noise, jit, Xu, y)
+    assert info == 0
+
+    def f(ell_, scale_, noise_, xu=Xu):
+        return ref.sparse_bound(X, y, xu, {"k_length": ell_, "k_scale": scale_, "noise": noise_}, kernel=name, jitter=jit)
+
+    f0 = f(ell, scale, noise)
+    assert abs(bound - f0) <= 1e-9 * abs(f0)
+    # the clip IS active here: the raw trace term of the reference's formula (sparse_gp.py:96-104) is negative
+    kfn = ref.get_kernel(name)
+    import scipy.linalg as sla
+    W = sla.solve_triangular(np.linalg.cholesky(kfn(Xu, Xu, p, jitter=jit)), kfn(Xu, X, p), lower=True).T
+    assert (np.diag(kfn(X, X, p, jitter=0)) - np.square(W).sum(axis=-1)).sum() < -1e-3
+    scale_g = max(np.abs(g["k_length"]).max(), abs(g["k_scale"]), abs(g["noise"]))
+    for m in range(2):
+        h = 1e-6 * ell[m]
+        a, b = ell.copy(), ell.copy()
+        a[m] += h
+        b[m] -= h
+        assert abs((f(a, scale, noise) - f(b, scale, noise)) / (2 * h) - g["k_length"][m]) <= 5e-5 * scale_g
+    h = 1e-6 * scale
+    assert abs((f(ell, scale + h, noise) - f(ell, scale - h, noise)) / (2 * h) - g["k_scale"]) <= 5e-5 * scale_g
+    h = 1e-6 * noise
+    assert abs((f(ell, scale, noise + h) - f(ell, scale, noise - h)) / (2 * h) - g["noise"]) <= 5e-5 * scale_g
+    gx = np.abs(g["Xu"]).max()
+    for a_, m_ in [(0, 0), (77, 1)]:
+        h = 1e-6
+        xp, xm = Xu.copy(), Xu.copy()
+        xp[a_, m_] += h
+        xm[a_, m_] -= h
+        assert abs((f(ell, scale, noise, xp) - f(ell, scale, noise, xm)) / (2 * h) - g["Xu"][a_, m_]) <= 1e-4 * max(gx, 1.0)
+
+
+def test_as_many_inducing_points_as_training_points_follow_the_same_shape_rule(engine):
+    """kernels.py:63-65 adds (noise + jitter) I iff the two inputs have the same SHAPE, and viSparseGP.model builds Kuf with
+    the kernel's default jitter (sparse_gp.py:96): at inducing ratio 1 the bound's Kuf carries 1e-6 on its diagonal,
+    get_mvn_posterior's (jitter=0, sparse_gp.py:196) does not.  Both against the oracle, which restates the calls as they
+    are; and the cached forward pass of the one is not reused for the other."""
+    rng = np.random.default_rng(8)
+    N = 96
+    X = rng.uniform(0, 10, (N, 2))
+    y = np.sin(X[:, 0]) * np.cos(X[:, 1]) + 0.05 * rng.standard_normal(N)
+    Xu = X[rng.permutation(N)] + 0.2 * rng.standard_normal((N, 2))
+    Xn = rng.uniform(0, 10, (40, 2))
+    p = {"k_length": np.array([1.5, 2.0]), "k_scale": 1.1, "noise": 0.02}
+    jit = 1e-2  # large against the 1e-6 under test, so that the comparison resolves it
+    engine.set_train(X)
+    for _ in range(2):  # bound -> posterior -> bound -> posterior: never the other call's forward pass
+        bound, info, _ = engine.sgp_bound(1, p["k_length"], p["k_scale"], p["noise"], jit, Xu, y, want_grad=False)
+        expect = ref.sparse_bound(X, y, Xu, p, kernel="Matern", jitter=jit)
+        assert info == 0 and abs(bound - expect) <= 1e-11 * abs(expect)
+        mean, cov, _, info = engine.sgp_posterior(1, p["k_length"], p["k_scale"], p["noise"], jit, Xu, y, Xn, 0.0,
+                                                  want_cov=True, want_var=False)
+        m_ref, c_ref = ref.sparse_posterior(X, y, Xu, Xn, p, noiseless=True, kernel="Matern", jitter=jit)
+        assert info == 0 and np.abs(mean - m_ref).max() <= 1e-10 * np.abs(m_ref).max()
+        assert np.abs(cov - c_ref).max() <= 1e-10 * np.abs(c_ref).max()
+    # the rule makes a difference the test can see: the bound WITHOUT the diagonal term differs by more than the tolerance
+    kfn = ref.get_kernel("Matern")
+    import scipy.linalg as sla
+    Luu = np.linalg.cholesky(kfn(Xu, Xu, p, jitter=jit))
+    W0 = sla.solve_triangular(Luu, kfn(Xu, X, p, jitter=0), lower=True).T
+    W1 = sla.solve_triangular(Luu, kfn(Xu, X, p), lower=True).T
+    assert np.abs(W0 - W1).max() > 1e-8
 
 
 def test_forward_pass_is_reused_only_for_identical_inputs():
@@ -155,7 +240,12 @@ def test_forward_pass_is_reused_only_for_identical_inputs():
     base = fresh(X, y, p["k_length"], Xn)
     np.testing.assert_array_equal(again[0], base[0])
     np.testing.assert_array_equal(again[2], base[2])
+    # (bound without gradient -> posterior -> bound WITH gradient on the one cached forward pass — the |W|_F^2
+    # partials the gradient's clipped-trace switch reads were left by the forward pass, not by this call)
+    b0, _, _ = e.sgp_bound(*args(y, p["k_length"]), False)
+    e.sgp_posterior(*args(y, p["k_length"]), Xn[:30], 0.0, want_cov=False, want_var=True)
     b1, _, g1 = e.sgp_bound(*args(y, p["k_length"]), True)  # reused by the bound and its gradient as well
+    assert b0 == b1
     e2 = _lib.Engine(0)
     e2.set_train(X)
     b2, _, g2 = e2.sgp_bound(*args(y, p["k_length"]), True)
