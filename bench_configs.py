@@ -72,9 +72,9 @@ def c1():
     # ... and the simpleGP notebook's own size through the model API: NUTS 200 + 200 at N = 25
     Xs, ys_, _, _ = bench_inputs.synthetic_problem(25, 1, 4, seed=1)
     m25 = ExactGP(1, "RBF")
-    t0 = time.perf_counter()
+    t25 = time.perf_counter()
     m25.fit(k1, Xs, ys_, num_warmup=200, num_samples=200, progress_bar=False, print_summary=False)
-    small["nuts_200_200_N25_s"] = time.perf_counter() - t0
+    small["nuts_200_200_N25_s"] = time.perf_counter() - t25
     small["nuts_N25_leapfrogs"] = int(sum(int(np.sum(st["n_leapfrog"])) for st in m25.mcmc.get_extra_fields()))
     return {"config": "C1: ExactGP(1, 'RBF') N=512 d=1, NUTS 200 + 200, predict M=100 n=1 (BASELINE.json configs[0])",
             "fit_s": t1 - t0, "predict_s": t2 - t1, "leapfrogs_in_sampling": nl,

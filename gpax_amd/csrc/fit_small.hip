@@ -198,6 +198,11 @@ __global__ __launch_bounds__(256) void fit_small_kernel(FitSmallArgs a) {
   int* info = a.info + b;
 
   // ---- A: the augmented Gram block -----------------------------------------------------------------------------------------
+  // thread -> two adjacent columns (2 jj, 2 jj + 1) of every fourth row: one 16-byte store per matrix and row, a wave writes
+  // 1 KiB of a row.  y may live in page-locked HOST memory (gpx_fit_batch): its load is issued first, beside that of the
+  // hyper-parameters, so that the kernel pays ONE trip over the host link, not two in a row.
+  const int jj = tid & 63, h = tid >> 6, j0 = 2 * jj;
+  const double y0 = (j0 < N) ? y[j0] : 0.0, y1 = (j0 + 1 < N) ? y[j0 + 1] : 0.0;
   for (int idx = tid; idx < PB * d; idx += 256) {
     const int r = idx / d, c = idx - r * d;
     sx[r * DM + c] = (r < N) ? X[(int64_t)r * d + c] * (PER ? 1.0 : inv_ell[c]) : 0.0;
@@ -205,34 +210,45 @@ __global__ __launch_bounds__(256) void fit_small_kernel(FitSmallArgs a) {
   if (tid == 0) *info = 0;
   __syncthreads();
   {
-    const int j = tid & (PB - 1), h = tid >> 7;
-    double zj[DM];
+    double z0[DM], z1[DM];
 #pragma unroll
-    for (int c = 0; c < DM; ++c) zj[c] = (c < d) ? sx[j * DM + c] : 0.0;
-    const double yj = (j < N) ? y[j] : 0.0;
-    for (int i = h; i < PB; i += 2) {
-      double v;
-      if (i < N && j < N) {
-        double r2 = 0.0;
+    for (int c = 0; c < DM; ++c) {
+      z0[c] = (c < d) ? sx[j0 * DM + c] : 0.0;
+      z1[c] = (c < d) ? sx[(j0 + 1) * DM + c] : 0.0;
+    }
+    for (int i = h; i < PB; i += 4) {
+      double v0, v1;
+      if (i < N) {
+        double r20 = 0.0, r21 = 0.0;
 #pragma unroll
         for (int c = 0; c < DM; ++c) {
           if (c < d) { // uniform
-            double u = sx[i * DM + c] - zj[c];
-            if (PER) u = sin(u * pi_over_p) * inv_ell[c];
-            r2 = fma(u, u, r2);
+            const double x = sx[i * DM + c];
+            double u0 = x - z0[c], u1 = x - z1[c];
+            if (PER) {
+              u0 = sin(u0 * pi_over_p) * inv_ell[c];
+              u1 = sin(u1 * pi_over_p) * inv_ell[c];
+            }
+            r20 = fma(u0, u0, r20);
+            r21 = fma(u1, u1, r21);
           }
         }
-        v = kernel_value<KIND>(r2, k_scale);
-        if (i == j) v += diag_add;
+        v0 = kernel_value<KIND>(r20, k_scale);
+        v1 = kernel_value<KIND>(r21, k_scale);
+        if (i == j0) v0 += diag_add;
+        if (i == j0 + 1) v1 += diag_add;
+        if (j0 >= N) v0 = 0.0;
+        if (j0 + 1 >= N) v1 = 0.0;
       } else if (i == N) {
-        v = (j < N) ? yj : (j == N ? AUG_BIG : 0.0);
-      } else if (i > N) {
-        v = (i == j) ? 1.0 : 0.0;
+        v0 = (j0 < N) ? y0 : (j0 == N ? AUG_BIG : 0.0);
+        v1 = (j0 + 1 < N) ? y1 : (j0 + 1 == N ? AUG_BIG : 0.0);
       } else {
-        v = 0.0;
+        v0 = (i == j0) ? 1.0 : 0.0;
+        v1 = (i == j0 + 1) ? 1.0 : 0.0;
       }
-      A[(int64_t)i * lda + j] = v;
-      Linv[i * PB + j] = (i == j) ? 1.0 : 0.0; // what the factorisation does not visit stays the identity
+      *reinterpret_cast<double2*>(A + (int64_t)i * lda + j0) = make_double2(v0, v1);
+      // what the factorisation does not visit of L^-1 stays the identity
+      *reinterpret_cast<double2*>(Linv + i * PB + j0) = make_double2(i == j0 ? 1.0 : 0.0, i == j0 + 1 ? 1.0 : 0.0);
     }
   }
   __syncthreads(); // (workgroup-scope release / acquire: the block is visible to every wave of this workgroup)
