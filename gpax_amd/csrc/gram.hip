@@ -31,8 +31,22 @@ __global__ __launch_bounds__(256) void gram_kernel(KernelParams kpv, const doubl
     X += task * ts.x_bs;
     Z += task * ts.z_bs;
   }
-  const int j0 = blockIdx.x * GT_COLS;
-  const int i0 = blockIdx.y * GT_ROWS;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (lower_only == 2) {
+    // Only the tiles a lower-triangular build writes are launched (round 5; rounds 1 - 4 launched the full grid and half of
+    // it returned at once): linear id -> column tile c (512 wide) and row tile r (32 high); column c holds the row tiles
+    // 16 c .. R - 1 (the tiles with j0 <= i0 + 31), consecutive ids walk down a column.
+    const int R = (n_pad + GT_ROWS - 1) / GT_ROWS;
+    int id = blockIdx.x, c = 0;
+    while (id >= R - 16 * c) {
+      id -= R - 16 * c;
+      ++c;
+    }
+    bx = c;
+    by = 16 * c + id;
+  }
+  const int j0 = bx * GT_COLS;
+  const int i0 = by * GT_ROWS;
   if (lower_only && j0 > i0 + GT_ROWS - 1) return;
   // batched launch: sample blockIdx.z reads its hyper-parameters from the device table
   const ThetaDev* t = (th != nullptr) ? th + blockIdx.z : nullptr;
@@ -149,6 +163,16 @@ int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, i
   if (n_pad <= 0 || m_pad <= 0) return 0;
   if (batch > 1 && th == nullptr) return bad_arg(ctx, "batched Gram needs a device theta table");
   dim3 grid((m_pad + GT_COLS - 1) / GT_COLS, (n_pad + GT_ROWS - 1) / GT_ROWS, batch > 1 ? batch : 1);
+  if (lower_only) { // launch the lower tiles alone: column tile c of the 512-wide grid has R - 16 c row tiles of 32
+    const int R = (int)grid.y;
+    int64_t tiles = 0;
+    for (int c = 0; c < (int)grid.x && R - 16 * c > 0; ++c) tiles += R - 16 * c;
+    if (tiles > 0 && tiles < (int64_t)grid.x * grid.y) {
+      grid.x = (unsigned)tiles;
+      grid.y = 1;
+      lower_only = 2;
+    }
+  }
   // algorithmic bytes: 8*n*m written (+ inputs); SURVEY 8(d): a symmetric build may claim the
   // full 8 n m.
   ProfScope ps(ctx, GPX_PROF_GRAM, 8.0 * (double)n * (double)m * (batch > 1 ? batch : 1));
