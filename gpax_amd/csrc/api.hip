@@ -483,7 +483,12 @@ int pick_batch(gpx_ctx* ctx, int S, int n_pad, bool want_cov) {
   if (const char* e = getenv("GPX_SWEEP_BATCH")) forced = atoi(e);
   // auto: nominal_batch() — measured in tools/small_n_sweep.py / multi_ctx.py / c4_sweep.py
   int B = forced > 0 ? forced : nominal_batch(ctx);
-  if (B > 256) B = 256;
+  // nominal_batch() stops at 256 (the split-K slab counts of a sweep are sized for it: a function of N only).  Where that
+  // cap binds (N < ~1900) a launch of 256 samples is still partly latency: up to 1024 samples per launch below N = 1152
+  // (+8 ... 13 % posteriors/s at N = 128 ... 512; the memory budget below still applies).  A sample's arithmetic does not
+  // depend on the batch it rides in.
+  if (forced <= 0 && B == 256 && ctx->Np <= 1152) B = 1024;
+  if (B > 1024) B = 1024;
   const BatchPlan p = make_plan(ctx, 1, n_pad, true, true);
   double per = (double)p.k_bs + p.linv_bs + 2.0 * p.mean_bs;
   if (want_cov) per += (double)p.cov_bs + p.splitk_bs + p.covlinv_bs + 2.0 * p.eps_bs;

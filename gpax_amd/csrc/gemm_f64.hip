@@ -264,11 +264,15 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   // not change results: every C element accumulates its k range in the same order in all shapes (the k ranges
   // trimmed by ktri / kupper only drop structural zeros), so batched and single-sample launches stay
   // bit-identical even when they pick different shapes.
-  // Short-K launches (the K = 128 panel steps) keep the small shapes whatever the batch: their cost is the
-  // per-workgroup prologue / epilogue, which the 64x64 shapes hide with 3x the occupancy (N = 512 sweep:
-  // 126 000 vs 50 000 posteriors/s); long-K launches count the batch entries.
+  // Batch entries count towards the tile total whatever K where the chain has the chip to itself (round 5).  Rounds 1 - 4 kept the 64 x 64 shapes for the K = 128
+  // panel steps of a batched sweep (measured in round 1, against that round's register-staged 128 x 128 kernel: 126 000 vs
+  // 50 000 posteriors/s at N = 512); with the LDS-direct kernel the big tile halves the operand traffic per flop of
+  // those updates (a 64 x 64 tile of K = 128 reads 128 KB of panels for 64 KB of C): batched sweep N = 256 349 -> 368 k,
+  // N = 512 145 -> 160 k, N = 1024 / 2048 +2 % posteriors/s (profiles/r05/README.md).
   const int nsplit = splits > 0 ? splits : 1;
-  const int bmul = (g.batch > 1 && g.K >= 512) ? g.batch : 1;
+  // (Inside the blocked two-stream sweeps — lat_now == 1 — the K = 128 chain launches keep the shapes that are placed at
+  // once beside two resident trailing-update workgroups: C4, batches of 4 - 7 at N = 8192, loses 2 - 3 % otherwise.)
+  const int bmul = (g.batch > 1 && (g.K >= 512 || ctx->lat_now == 5)) ? g.batch : 1;
   const double tiles = (double)tiles_m * tiles_n * nsplit * (g.lower ? 0.55 : 1.0) * bmul;
   // persistent scope: the bulk update's workgroups hold their slots until its queue is dry, so a big-shape launch on
   // the panel stream would find no room: everything there takes the shapes that fit next to two resident workgroups
