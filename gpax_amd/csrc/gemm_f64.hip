@@ -37,11 +37,35 @@
 
 namespace gpx {
 
+// Batched launches: which XCD works on which batch entry.  The hardware deals workgroups to the 8 XCDs in linear id order
+// (id % 8), x fastest: with the batch in grid.z the tiles of ONE entry are consecutive ids, i.e. spread over all eight L2s,
+// and every XCD fetches that entry's A / B panels for itself — at N = 512 a K = 128 update of 1024 samples moved ~7.7 GB
+// (C 2.7 GB + the panels up to eight times) at 4.7 TB/s: HBM-bound on re-fetched operands.  Entries are independent and
+// identical, so the order is free: within each group of eight entries, id -> (entry = id % 8, tile = id / 8) puts ALL tiles
+// of an entry on one XCD, back to back (its panels are fetched once into that L2), and keeps the eight XCDs exactly
+// balanced.  A tile's arithmetic does not depend on where it runs.  (Entries beyond the last full group of eight keep the
+// plain order.)
+__device__ __forceinline__ void batch_xcd_order(int& bx, int& by, int& bz) {
+  const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+  if (gz < 8) return;
+  const int per = gx * gy;
+  const int lin = bx + gx * (by + gy * bz);
+  const int grp = lin / (8 * per);
+  if ((grp + 1) * 8 > gz) return; // ragged tail
+  const int loc = lin - grp * 8 * per;
+  const int t = loc >> 3;
+  bz = grp * 8 + (loc & 7);
+  by = t / gx;
+  bx = t - by * gx;
+}
+
 template <int TAG, int MT, int NT, int BK, bool DBUF>
 __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)) void gemm_nt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // panel / small GEMMs sit on the critical path of the look-ahead
-  gemm_nt_tile<MT, NT, BK, DBUF>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
+  gemm_nt_tile<MT, NT, BK, DBUF>(g, smem, bx, by, bz);
 }
 
 // round-5 latency shapes (gemm_tile.h lat_tile): <2,2> 64 x 64 (ring of 3 k-slices, 24 KB), <1,4> 32 x 128 strips for the
@@ -50,14 +74,18 @@ template <int MT, int NT, int NST, int EPI>
 __global__ __launch_bounds__(256, 6) void gemm_lat_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __builtin_amdgcn_s_setprio(2); // chain launches sit on the critical path of the look-ahead
-  lat_tile<MT, NT, NST, EPI>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
+  lat_tile<MT, NT, NST, EPI>(g, smem, bx, by, bz);
 }
 
 template <int TAG, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // non-trailing launches sit on the critical path of the look-ahead
-  nt128_tile<EPI>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
+  nt128_tile<EPI>(g, smem, bx, by, bz);
 }
 
 // Tile enumeration of a persistent launch: only the tiles a launch really has (lower: tj_off + bx <= ti_off + by),
