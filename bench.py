@@ -182,6 +182,35 @@ def gram_bytes_written(N, Np):
     return total
 
 
+def write_only_fill_GBps(nbytes):
+    """What a pure WRITE stream reaches on this device: hipMemsetAsync of `nbytes` (the runtime's fill kernel) between two
+    HIP events, best of 9 — the yardstick for the Gram build, which only writes (the 6.29 TB/s copy figure of
+    MI355X_MICROARCH.md is read + write traffic together).  Returns None when the runtime cannot be bound."""
+    try:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        ptr, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        if hip.hipMalloc(C.byref(ptr), C.c_size_t(nbytes)) != 0:
+            return None
+        hip.hipEventCreate(C.byref(e0))
+        hip.hipEventCreate(C.byref(e1))
+        best = 1e9
+        for _ in range(9):
+            hip.hipEventRecord(e0, None)
+            hip.hipMemsetAsync(ptr, 0, C.c_size_t(nbytes), None)
+            hip.hipEventRecord(e1, None)
+            hip.hipEventSynchronize(e1)
+            ms = C.c_float()
+            hip.hipEventElapsedTime(C.byref(ms), e0, e1)
+            best = min(best, ms.value)
+        hip.hipFree(ptr)
+        hip.hipEventDestroy(e0)
+        hip.hipEventDestroy(e1)
+        return nbytes / (best * 1e-3) / 1e9
+    except Exception:
+        return None
+
+
 def committed_pmc_record(N, d, M):
     """HBM traffic and the serialised launch time of the dominant kernel from the committed rocprofv3 --pmc passes of
     this same command (profiles/<round>/traffic.json; FETCH_SIZE doubled per the gfx950 correction,
@@ -190,7 +219,7 @@ def committed_pmc_record(N, d, M):
     out = {"traffic": None, "traffic_note": None, "serialised_avg_launch_ms": None}
     if (N, d, M) != (16384, 2, 1024):
         return out
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         tj = os.path.join(ROOT, "profiles", rnd, "traffic.json")
         if not os.path.exists(tj):
             continue
@@ -198,7 +227,7 @@ def committed_pmc_record(N, d, M):
         if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
             out["traffic"] = (2.0 * t["FETCH_SIZE"]["avg_per_launch"] + t["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
             out["traffic_note"] = (f"bytes per launch, profiles/{rnd}/{{fetch,write}}.md: (2*FETCH_SIZE + WRITE_SIZE) KB"
-                                   + ("" if rnd in ("r03", "r04") else " (an earlier round's kernel)"))
+                                   + ("" if rnd in ("r03", "r04", "r05") else " (an earlier round's kernel)"))
             us = [v["avg_duration_us"] for v in t.values() if isinstance(v, dict) and "avg_duration_us" in v]
             if us:
                 out["serialised_avg_launch_ms"] = float(np.mean(us)) * 1e-3
@@ -267,6 +296,8 @@ def device_record(eng, a, lml):
     post_flops = N ** 3 / 3 + N * N * M + N * M * M + 2 * N * N + 2 * N * M
     pk = FP64_MFMA_PEAK_TFLOPS * 1e12
     p2 = potf2_record(eng, a)
+    gram_written = gram_bytes_written(N, (N + 1 + 127) // 128 * 128)
+    fill = write_only_fill_GBps(gram_written)
     roof = {
         "bound": "mfma",
         "kernel": "gpx::gemm_nt128_kernel<1,1> (Cholesky trailing SYRK, lower tiles, LDS-direct staging; K = 1024 while the "
@@ -306,9 +337,12 @@ def device_record(eng, a, lml):
         "potrf_tflops": (N ** 3 / 3) / (stages["potrf_ms"] * 1e-3) / 1e12,
         "kernel_classes_ms_per_predict": {"gemm_trailing": ms, "gemm_other": ms_o, "potf2": ms_p, "gram": ms_g},
         "gram_alg_GBps": bytes_g / (ms_g * 1e-3) / 1e9 if ms_g > 0 else None,
-        "gram_written_GBps": (gram_bytes_written(N, (N + 1 + 127) // 128 * 128) / (stages["gram_ms"] * 1e-3) / 1e9),
+        "gram_written_GBps": gram_written / (stages["gram_ms"] * 1e-3) / 1e9,
+        "gram_write_only_fill_GBps": fill,
+        "gram_frac_of_write_only_fill": (gram_written / (stages["gram_ms"] * 1e-3) / 1e9 / fill) if fill else None,
         "gram_note": "alg = 8 N^2 credited to the symmetric build (SURVEY 8d); written = bytes the lower 32x512 "
-                     "tiles actually store, over the stand-alone Gram stage",
+                     "tiles actually store, over the stand-alone Gram stage; write_only_fill = hipMemsetAsync of the same "
+                     "number of bytes, measured in this run (what a kernel that only writes can reach on this device)",
         "mfma_f64_microbench_tflops": eng.mfma_f64_peak(),
         "lml_check": lml,
     }

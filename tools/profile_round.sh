@@ -1,13 +1,13 @@
 #!/bin/bash
 # Regenerate the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_round.sh r04
+#   bash tools/profile_round.sh r05
 #   kernel-trace + stats of the default bench command, separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*), the C4
 #   sweep (S = 1000) with its own kernel trace, and the round's bench line; summarised on the box (the rocpd sqlite
 #   databases stay in /tmp; only .md / .json summaries come back under gpurun_out/prof — copy them to profiles/<round>).
 # NOTE (round 1): a single pass with five TCC_* derived counters on `bench.py --steps 1` did not finish within 10
 # minutes on this pool — keep L2 counters out of this script.  --pmc passes carry --kernel-trace only (gpurun refuses
 # --pmc together with the hip / hsa / memory trace domains).
-RND=${1:-r04}
+RND=${1:-r05}
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/prof
@@ -21,7 +21,7 @@ run() {
   python tools/rocpd_summary.py "$db" $O/$name.md $O/traffic.json > /dev/null 2>> $O/$name.err
   tail -c 300 $O/under_$name.json | head -c 300; echo
 }
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-configs"  # (the configs block — C1, C2, C4, C5 — is part of the final bench line below)
 run trace "$B" --kernel-trace --stats
 # one theta in flight: the dominant kernel's average duration here is the one bench.py's roofline block measures
 # (its profile pass runs on a single context); with 3 contexts in flight (pass above) concurrent kernels stretch
@@ -55,8 +55,9 @@ else:
     for n, c, s, a in rows:
         print(f"| `{n}` | {c} | {s / 1e6:.3f} | {a / 1e3:.1f} |")
 PY
-# C5: viSparseGP / viGP on the 512 x 512 image (flop model in the tool's docstring)
+# C5: viSparseGP / viGP on the 512 x 512 image (flop model in the tool's docstring), and the launch timeline of one sparse step
 python tools/c5_bench.py > $O/c5_sparse.json 2> $O/c5_sparse.err
+bash tools/exp/sgp_trace2.sh $O/sgptrace > /dev/null 2>&1 && cp $O/sgptrace/c5_step_timeline.md $O/c5_step_timeline.md
 # the N > 1 code path of bench.py on this 1-GPU box: one rank over RCCL (the collective sweep incl. the C4 record), and two
 # ranks sharing the GPU over the file transport (control flow only: the two ranks halve the GPU between them)
 python bench.py --force-rank-path --steps 12 --warmup 3 > $O/bench_rank1_rccl.json 2> $O/bench_rank1_rccl.err
@@ -64,7 +65,7 @@ python bench.py --gpus 2 --share-gpu --steps 8 --warmup 2 --c4-S 200 > $O/bench_
 # round 4: the diagonal-block kernel inside the pipeline — per dispatch wait / execution from the kernel trace (default
 # kernel and the round-3 one), the in-kernel phase trace of the default kernel (trace build of the library), the Gram
 # build alone with its HBM counters, the fit step at the sizes gpax is mostly used at, and the RCCL calls one rank issues
-for m in slim chain; do
+for m in slim; do
   rm -rf /tmp/prof_pw_$m
   GPX_POTF2=$m timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_pw_$m -- $B --steps 6 --warmup 1 --inflight 1 > /dev/null 2> $O/pw_$m.err
   echo "## GPX_POTF2=$m: rocprofv3 --kernel-trace -- $B --steps 6 --warmup 1 --inflight 1" >> $O/potf2_wait.md
@@ -76,7 +77,9 @@ fi
 python tools/gram_bench.py > $O/gram.json 2> $O/gram.err
 run gram_write "python tools/gram_bench.py" --kernel-trace --pmc WRITE_SIZE
 run gram_fetch "python tools/gram_bench.py" --kernel-trace --pmc FETCH_SIZE
-for N in 128 512 2048; do
+python tools/fit_small_bench.py > $O/fit_small.json 2> $O/fit_small.log
+python tools/lat_gemm_bench.py > $O/lat_gemm.json 2> $O/lat_gemm.txt
+for N in 25 128 512 2048 4096; do
   rm -rf /tmp/prof_sn$N
   timeout 200 rocprofv3 --kernel-trace -d /tmp/prof_sn$N -- python tools/smalln_timeline.py run $N > $O/smalln_$N.txt 2>&1
   python tools/smalln_timeline.py show "$(find /tmp/prof_sn$N -name '*.db' | head -1)" $O/smalln_timeline_$N.md > /dev/null 2>> $O/smalln_$N.txt

@@ -36,7 +36,8 @@ def show(dbp, out=None):
     db = sqlite3.connect(dbp)
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
     # the last fit step: from the last gram_kernel to the end
-    gi = [i for i, r in enumerate(rows) if "gram_kernel" in r[0]]
+    # (N <= 127: the whole step is ONE launch, fit_small_kernel — csrc/fit_small.hip)
+    gi = [i for i, r in enumerate(rows) if "gram_kernel" in r[0] or "fit_small_kernel" in r[0]]
     seg = rows[gi[-1]:]
     t0 = seg[0][1]
     lines = [f"{len(seg)} launches, span {(seg[-1][2] - t0) / 1e3:.1f} us, kernel time {sum(b - a for _, a, b in seg) / 1e3:.1f} us",
