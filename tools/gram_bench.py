@@ -14,7 +14,7 @@ from bench_inputs import synthetic_problem  # noqa: E402
 from gpax_amd import _lib  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-kind = 1  # Matern: C3
+kind = int(os.environ.get("GRAM_KIND", "1"))  # 1 = Matern: C3 (0 = RBF: one exp per entry, no square root)
 X, y, Xn, p = synthetic_problem(N, 2, 8, seed=0)
 e = _lib.Engine(0)
 e.set_train(X)
