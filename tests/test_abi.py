@@ -63,7 +63,7 @@ def test_chain_kernels_fit_beside_two_resident_trailing_update_workgroups():
     import kernel_resources as kr
 
     csrc = os.path.join(os.path.dirname(__file__), "..", "gpax_amd", "csrc")
-    rows = {r["name"]: r for f in ("potf2.hip", "gemm_f64.hip") for r in kr.resources(os.path.join(csrc, f))}
+    rows = {r["name"]: r for f in ("potf2.hip", "gemm_f64.hip", "fit_small.hip") for r in kr.resources(os.path.join(csrc, f))}
 
     def find(sub):
         hit = [r for n, r in rows.items() if sub in n]
@@ -94,6 +94,7 @@ def test_chain_kernels_fit_beside_two_resident_trailing_update_workgroups():
         assert alloc(r) <= 80 and alloc(r) <= free_vgpr, (r["name"], r["vgpr_count"])
         assert int(r["vgpr_spill_count"]) == 0 and int(r["sgpr_spill_count"]) == 0 and int(r["private_segment_fixed_size"]) == 0
     assert 3 * 128 * 64 <= 28 * 1024 and 2 * 160 * 64 <= 28 * 1024
+    assert len([n for n in rows if "fit_small_kernel" in n]) == 15  # 3 kernels x (d = 1 .. 4, generic d)
     # no VGPR spill and no private segment in any kernel a default run launches
     for n, r in rows.items():
         if "gemm_nt_kernel" in n:  # GPX_LAT_GEMM=r1 only
