@@ -325,9 +325,11 @@ __device__ __forceinline__ void lat_tile(const GemmArgs& g, double* smem, const 
           acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af_[kk][m], bf_[kk][n], acc[m][n], 0, 0, 0); \
   } while (0)
   // workgroup barrier WITHOUT the fence of __syncthreads (which drains vmcnt: the slice in flight behind the next one
-  // would be waited for at every barrier).  What has to be visible is stated explicitly: this wave's LDS-DMA loads of
-  // the NEXT slice (GPX_LAT_WAIT) — its own ds_reads of the current one were consumed by the MFMAs above.
-#define GPX_LAT_BARRIER() asm volatile("s_barrier" ::: "memory")
+  // would be waited for at every barrier).  What has to hold at the barrier is stated explicitly: this wave's LDS-DMA
+  // loads of the NEXT slice have landed (GPX_LAT_WAIT), and its own ds_reads of the CURRENT slice have RETURNED
+  // (lgkmcnt(0)) — the compiler is free to sink the MFMAs that consume them below the barrier, and the buffer they read
+  // is the one the loads issued right after the barrier overwrite.
+#define GPX_LAT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
   if (nk > 0) {
     GPX_LAT_ISSUE(0, 0);
