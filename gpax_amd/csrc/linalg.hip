@@ -60,7 +60,10 @@ static inline void set_batch(GemmArgs& g, int batch, int64_t a_bs, int64_t b_bs,
 // profiles/r02/chain_experiments.md, profiles/r03/panel_kernel.md, tools/exp/panel.hip.  Round 4 ran the inner updates
 // left-looking — column kb brought up to date in ONE update of K = 128 (kb - ob) right before its potf2, a column of
 // the block read and written once instead of (kb - ob) times; bit-identical — potrf 29.1 -> 29.3 ms at C3, the fit
-// step at N = 512 0.565 -> 0.609 ms: the longer update sits on the chain right before the potf2.  Not kept.)
+// step at N = 512 0.565 -> 0.609 ms: the longer update sits on the chain right before the potf2.  Not kept.  Round 5 let
+// the workgroup of the NEXT diagonal block inside update(kb) go on into that block's potf2 — two launches per step and no
+// cross-stream wait; bit-identical, potrf 0.19 -> 0.23 ms at N = 512, 1.99 -> 2.12 ms at N = 4096: one workgroup updates
+// its block at ONE CU's MFMA rate and then factors beside four MFMA-saturating workgroups.  profiles/r05/step_fused.md.)
 static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extra, int ob, int oe,
                        double* dLinv, int* dInfo, const BatchStrides& bs, int kb_end = -1) {
   if (kb_end < 0) kb_end = oe; // (kb_end < oe: the first steps of the block only — potrf_steps)
