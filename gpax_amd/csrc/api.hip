@@ -692,6 +692,7 @@ int gpx_init(int device, gpx_ctx** out) {
       if (gpx_debug_set_potf2(ctx, e) != 0) return -1;
     }
     if (const char* e = getenv("GPX_FIT_SMALL")) ctx->fit_small = (e[0] != '0');
+    if (const char* e = getenv("GPX_LAT_LIN")) ctx->lat_lin = (e[0] != '0');
     if (const char* e = getenv("GPX_LAT_GEMM")) ctx->lat_gemm = (std::strcmp(e, "r1") == 0) ? 1 : ((std::strcmp(e, "r5") == 0) ? 5 : 0);
     if (const char* e = getenv("GPX_SMALL_BK")) ctx->small_bk = (atoi(e) == 32) ? 32 : (atoi(e) == 16 ? 16 : 0);
     if (const char* e = getenv("GPX_LINVT")) ctx->linvt_tree = (std::strcmp(e, "sweep") == 0) ? 0 : 1;

@@ -192,6 +192,7 @@ struct gpx_ctx {
   // GPX_LAT_GEMM=r5|r1 / gpx_debug_set_lat_gemm force one everywhere.
   int lat_gemm = 0;
   int lat_now = 5; // the kernel the launches of the current driver call take (set by the drivers from lat_gemm)
+  bool lat_lin = true; // lower-tile launches of the round-5 latency shape enumerate only the live tiles (GPX_LAT_LIN=0: square grid)
   hipEvent_t evD = nullptr;
   // > 0 while a driver whose own panel chain holds no potf2 (the right-looking TRSM sweeps, the K^-1 = W W^T product)
   // is queueing launches: its big-tile GEMMs run persistently (GPX_PERSIST_SCOPE=0 disables)

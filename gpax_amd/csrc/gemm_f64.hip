@@ -59,35 +59,6 @@ __device__ __forceinline__ void batch_xcd_order(int& bx, int& by, int& bz) {
   bx = t - by * gx;
 }
 
-template <int TAG, int MT, int NT, int BK, bool DBUF>
-__global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)) void gemm_nt_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (TAG == 0) __builtin_amdgcn_s_setprio(2); // panel / small GEMMs sit on the critical path of the look-ahead
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
-  gemm_nt_tile<MT, NT, BK, DBUF>(g, smem, bx, by, bz);
-}
-
-// round-5 latency shapes (gemm_tile.h lat_tile): <2,2> 64 x 64 (ring of 3 k-slices, 24 KB), <1,4> 32 x 128 strips for the
-// in-place panel TRSM (ring of 2, 20 KB); <= 80 VGPRs: six waves per SIMD alone, one beside two trailing-update workgroups
-template <int MT, int NT, int NST, int EPI>
-__global__ __launch_bounds__(256, 6) void gemm_lat_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  __builtin_amdgcn_s_setprio(2); // chain launches sit on the critical path of the look-ahead
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
-  lat_tile<MT, NT, NST, EPI>(g, smem, bx, by, bz);
-}
-
-template <int TAG, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (TAG == 0) __builtin_amdgcn_s_setprio(2); // non-trailing launches sit on the critical path of the look-ahead
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
-  nt128_tile<EPI>(g, smem, bx, by, bz);
-}
-
 // Tile enumeration of a persistent launch: only the tiles a launch really has (lower: tj_off + bx <= ti_off + by),
 // row-major (consecutive ids share their A row panel), one slab per (batch entry, split-K slab).
 struct TileMap {
@@ -121,6 +92,49 @@ __device__ __forceinline__ void decode_tile(const TileMap& tm, int lower, int l,
     by = tm.b + l / tm.tiles_n;
     bx = l - (l / tm.tiles_n) * tm.tiles_n;
   }
+}
+
+// grid.x of a live-tiles launch -> (bx, by), wave-uniform
+__device__ __forceinline__ void live_tile(const TileMap& tm, int& bx, int& by) {
+  int ty, tx;
+  decode_tile(tm, 1, bx, ty, tx);
+  bx = __builtin_amdgcn_readfirstlane(tx);
+  by = __builtin_amdgcn_readfirstlane(ty);
+}
+
+template <int TAG, int MT, int NT, int BK, bool DBUF>
+__global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)) void gemm_nt_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (TAG == 0) __builtin_amdgcn_s_setprio(2); // panel / small GEMMs sit on the critical path of the look-ahead
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
+  gemm_nt_tile<MT, NT, BK, DBUF>(g, smem, bx, by, bz);
+}
+
+// round-5 latency shapes (gemm_tile.h lat_tile): <2,2> 64 x 64 (ring of 3 k-slices, 24 KB), <1,4> 32 x 128 strips for the
+// in-place panel TRSM (ring of 2, 20 KB); <= 80 VGPRs: six waves per SIMD alone, one beside two trailing-update workgroups
+// tm.total > 0: a lower-tile launch WITHOUT the workgroups above the diagonal — a square grid over a triangle is half
+// workgroups that return at once, and at these sizes (a K = 128 update of 16 x 16 tile rows: 1024 workgroups for 35 MB of C)
+// the launch is paced by how fast workgroups are dispatched, not by what they do (tools/exp/update_shape_sweep.py: 23 us
+// where the C traffic is 10): blockIdx.x enumerates the live tiles row by row (TileMap in units of this shape's tiles).
+template <int MT, int NT, int NST, int EPI>
+__global__ __launch_bounds__(256, 6) void gemm_lat_kernel(GemmArgs g, TileMap tm) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __builtin_amdgcn_s_setprio(2); // chain launches sit on the critical path of the look-ahead
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
+  if (tm.total > 0) live_tile(tm, bx, by);
+  lat_tile<MT, NT, NST, EPI>(g, smem, bx, by, bz);
+}
+
+template <int TAG, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g, TileMap tm) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (TAG == 0) __builtin_amdgcn_s_setprio(2); // non-trailing launches sit on the critical path of the look-ahead
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
+  if (tm.total > 0) live_tile(tm, bx, by); // (as in gemm_lat_kernel)
+  nt128_tile<EPI>(g, smem, bx, by, bz);
 }
 
 // PERSISTENT, dynamically scheduled variant: the grid is two workgroups per CU; each takes the next tile from an atomic
@@ -208,7 +222,13 @@ template <int MT, int NT, int NST, int EPI>
 static int launch_lat_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n) {
   constexpr size_t lds = (size_t)NST * (32 * MT + 32 * NT) * 8 * sizeof(double); // < 48 KB: no attribute needed
   dim3 grid(tiles_n * (4 / NT), tiles_m * (4 / MT), g.nsplit * g.batch);
-  gemm_lat_kernel<MT, NT, NST, EPI><<<grid, 256, lds, ctx->s>>>(g);
+  TileMap tm{};
+  if (MT == 2 && NT == 2 && g.lower && ctx->lat_lin && tiles_m * tiles_n >= 16) { // live tiles only (a grid of a few dozen workgroups is placed at once either way)
+    tm = make_tile_map2(1, 2 * (g.ti_off - g.tj_off), 2 * tiles_m, 2 * tiles_n, 1);
+    if (tm.total <= 0) return 0;
+    grid = dim3(tm.total, 1, g.nsplit * g.batch);
+  }
+  gemm_lat_kernel<MT, NT, NST, EPI><<<grid, 256, lds, ctx->s>>>(g, tm);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -265,7 +285,13 @@ static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
     ctx->func_attr_mask |= bit;
   }
   dim3 grid(tiles_n, tiles_m, g.nsplit * g.batch);
-  gemm_nt128_kernel<TAG, EPI><<<grid, 256, lds, ctx->s>>>(g);
+  TileMap tm{};
+  if (g.lower && ctx->lat_lin && tiles_m * tiles_n >= 16) { // live tiles only
+    tm = make_tile_map2(1, g.ti_off - g.tj_off, tiles_m, tiles_n, 1);
+    if (tm.total <= 0) return 0;
+    grid = dim3(tm.total, 1, g.nsplit * g.batch);
+  }
+  gemm_nt128_kernel<TAG, EPI><<<grid, 256, lds, ctx->s>>>(g, tm);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -305,7 +331,13 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   // persistent scope: the bulk update's workgroups hold their slots until its queue is dry, so a big-shape launch on
   // the panel stream would find no room: everything there takes the shapes that fit next to two resident workgroups
   const bool on_panel = ctx->persist_scope > 0 && ctx->s != ctx->stream;
-  constexpr double small_max = 400.0; // launches with fewer 128x128 tiles take the latency shapes (profiles/r02/chain_experiments.md)
+  // launches with fewer 128x128 tiles take the latency shapes (profiles/r02/chain_experiments.md).  The rank-128 lower update
+  // of a chain that has the chip to itself keeps the round-5 64 x 64 shape up to the largest one-block factorisation: that
+  // launch is bound by the read-modify-write of C, and on live tiles only the small shape is ahead at every size
+  // (t x t tile rows, us: t = 28 37 / 44, t = 31 42 / 76, t = 36 57 / 65, t = 40 65 / 84; profiles/r05/update_shape_sweep.json)
+  const bool rank128_alone = ctx->lat_lin && g.lower && g.K <= TILE && g.batch <= 1 && g.C != g.A && nsplit == 1 &&
+                             (ctx->lat_gemm != 0 ? ctx->lat_gemm : ctx->lat_now) == 5;
+  const double small_max = rank128_alone ? 1400.0 : 400.0;
   if (g.big_shape && g.C != g.A && !on_panel) return launch_big<0>(ctx, g, tiles_m, tiles_n, splits);
   if (tiles < small_max || on_panel || g.latency_shape) {
     if ((ctx->lat_gemm != 0 ? ctx->lat_gemm : ctx->lat_now) == 5) { // round-5 latency shapes; else the register-staged kernels below

@@ -171,9 +171,12 @@ def test_lazy_far_updates_do_not_change_a_single_bit(monkeypatch):
                 # the round-1 register-staged latency-shape GEMM (the default since round 5: lat_tile, LDS-direct staging)
                 dict(GPX_LAT_GEMM="r1"), dict(GPX_LAT_GEMM="r1", GPX_SMALL_BK="32", GPX_OUTER_TILES="2"),
                 dict(GPX_LAT_GEMM="r5"), dict(GPX_LAT_GEMM="r5", GPX_OUTER_TILES="4"),
-                dict(GPX_POTF2="tile", GPX_OUTER_TILES="2")]
+                dict(GPX_POTF2="tile", GPX_OUTER_TILES="2"),
+                # lower-tile launches over the full square grid (round 5 default: only the live tiles are launched, and the
+                # rank-128 update of a one-block chain keeps the 64 x 64 shape at every size)
+                dict(GPX_LAT_LIN="0"), dict(GPX_LAT_LIN="0", GPX_PERSIST_SCOPE="0"), dict(GPX_LAT_LIN="0", GPX_LAT_GEMM="r1")]
     switches = ("GPX_LAZY_GROUP", "GPX_OUTER_TILES", "GPX_PERSIST_SCOPE", "GPX_TAIL_TILES", "GPX_SMALL_BK", "GPX_POTF2",
-                "GPX_LAT_GEMM")
+                "GPX_LAT_GEMM", "GPX_LAT_LIN")
     for env in variants:
         for k in switches:
             monkeypatch.delenv(k, raising=False)
@@ -279,3 +282,31 @@ def test_linv_t_tree_and_sweep_give_the_same_gradient(monkeypatch, N):
         np.testing.assert_allclose(np.asarray(a, dtype=float), np.asarray(b, dtype=float), rtol=1e-9, atol=1e-9)
     # entry 0 of the batch is the single-sample fit step, bit for bit
     np.testing.assert_array_equal(np.ravel(outs["tree"][1][2][0]), g_tree)
+
+
+@pytest.mark.gpu
+def test_live_tile_grids_give_the_bits_of_the_square_grids_in_batched_sweeps(monkeypatch):
+    """gemm_f64.hip: a lower-tile launch enumerates only its live tiles (round 5; GPX_LAT_LIN=0: the square grid whose upper
+    half returns at once) — with the batch in grid.z and the entries dealt to the XCDs in groups of eight (batch_xcd_order),
+    with ride-along rows below the square part, with a ragged last group.  A tile's arithmetic does not depend on where in the
+    grid it sits: factor, gradient, posterior and draws of a 19-sample sweep agree bit for bit."""
+    import numpy as np
+    from bench_inputs import synthetic_problem, synthetic_theta_samples
+    from gpax_amd import _lib
+
+    N, d, M, S = 1300, 2, 200, 19
+    X, y, Xn, _ = synthetic_problem(N, d, M, seed=5)
+    th = synthetic_theta_samples(S, d, seed=6)
+    eps = np.random.default_rng(7).standard_normal((S, 2, M))
+    outs = []
+    for lin in ("1", "0"):
+        monkeypatch.setenv("GPX_LAT_LIN", lin)
+        e = _lib.Engine(0)
+        e.set_train(X)
+        sweep = e.predict_sweep(1, th["k_length"], th["k_scale"], th["noise"], y, Xn, False, 1e-6, eps)
+        fb = e.fit_batch(1, th["k_length"], th["k_scale"], th["noise"], 1e-6, y)
+        e.close()
+        outs.append((sweep[0], sweep[1], fb[0], fb[1], fb[2], fb[3]))
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    assert np.all(np.isfinite(outs[0][0])) and np.all(outs[0][3] == 0)
