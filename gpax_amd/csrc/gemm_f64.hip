@@ -337,7 +337,14 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   // (t x t tile rows, us: t = 28 37 / 44, t = 31 42 / 76, t = 36 57 / 65, t = 40 65 / 84; profiles/r05/update_shape_sweep.json)
   const bool rank128_alone = ctx->lat_lin && g.lower && g.K <= TILE && g.batch <= 1 && g.C != g.A && nsplit == 1 &&
                              (ctx->lat_gemm != 0 ? ctx->lat_gemm : ctx->lat_now) == 5;
-  const double small_max = rank128_alone ? 1400.0 : 400.0;
+  // Any other launch of such a chain: the 64 x 64 shape up to 900 tiles (30 x 30 full, 40 x 40 lower).  On live tiles it
+  // is level with or ahead of the throughput shape at every size but the exact fits of 256 / 1024 tiles
+  // (profiles/r05/shape_sweep.json), and it takes K^-1 = L^-T L^-1 of the gradient half off the persistent 128 x 128 launch
+  // that lasts as long as its longest tile: fit step N = 4096 3.30 -> 3.03 ms, N = 5120 4.79 -> 4.69; beyond (N = 8192:
+  // 1024 tiles of K = 4096 at the top of the L^-T tree) the small shape loses (12.9 -> 13.3 ms at 1400) —
+  // profiles/r05/small_max.md.
+  const bool alone = ctx->lat_lin && g.batch <= 1 && (ctx->lat_gemm != 0 ? ctx->lat_gemm : ctx->lat_now) == 5;
+  const double small_max = rank128_alone ? 1400.0 : (alone ? 900.0 : 400.0);
   if (g.big_shape && g.C != g.A && !on_panel) return launch_big<0>(ctx, g, tiles_m, tiles_n, splits);
   if (tiles < small_max || on_panel || g.latency_shape) {
     if ((ctx->lat_gemm != 0 ? ctx->lat_gemm : ctx->lat_now) == 5) { // round-5 latency shapes; else the register-staged kernels below
