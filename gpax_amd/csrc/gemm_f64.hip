@@ -103,11 +103,12 @@ __device__ __forceinline__ void live_tile(const TileMap& tm, int& bx, int& by) {
 }
 
 template <int TAG, int MT, int NT, int BK, bool DBUF>
-__global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)) void gemm_nt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)) void gemm_nt_kernel(GemmArgs g, TileMap tm) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // panel / small GEMMs sit on the critical path of the look-ahead
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
+  if (tm.total > 0) live_tile(tm, bx, by); // (as in gemm_lat_kernel below)
   gemm_nt_tile<MT, NT, BK, DBUF>(g, smem, bx, by, bz);
 }
 
@@ -213,7 +214,13 @@ static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int til
   }
   // tiles_m / tiles_n are given in 128-tiles
   dim3 grid(tiles_n * (4 / NT), tiles_m * (4 / MT), g.nsplit * g.batch);
-  gemm_nt_kernel<TAG, MT, NT, BK, DBUF><<<grid, 256, lds, ctx->s>>>(g);
+  TileMap tm{};
+  if (MT == 2 && NT == 2 && g.lower && ctx->lat_lin && tiles_m * tiles_n * g.nsplit * g.batch >= 16) { // live tiles only
+    tm = make_tile_map2(1, 2 * (g.ti_off - g.tj_off), 2 * tiles_m, 2 * tiles_n, 1);
+    if (tm.total <= 0) return 0;
+    grid = dim3(tm.total, 1, g.nsplit * g.batch);
+  }
+  gemm_nt_kernel<TAG, MT, NT, BK, DBUF><<<grid, 256, lds, ctx->s>>>(g, tm);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -223,7 +230,7 @@ static int launch_lat_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
   constexpr size_t lds = (size_t)NST * (32 * MT + 32 * NT) * 8 * sizeof(double); // < 48 KB: no attribute needed
   dim3 grid(tiles_n * (4 / NT), tiles_m * (4 / MT), g.nsplit * g.batch);
   TileMap tm{};
-  if (MT == 2 && NT == 2 && g.lower && ctx->lat_lin && tiles_m * tiles_n >= 16) { // live tiles only (a grid of a few dozen workgroups is placed at once either way)
+  if (MT == 2 && NT == 2 && g.lower && ctx->lat_lin && tiles_m * tiles_n * g.nsplit * g.batch >= 16) { // live tiles only (a grid of a few dozen workgroups is placed at once either way)
     tm = make_tile_map2(1, 2 * (g.ti_off - g.tj_off), 2 * tiles_m, 2 * tiles_n, 1);
     if (tm.total <= 0) return 0;
     grid = dim3(tm.total, 1, g.nsplit * g.batch);
@@ -286,7 +293,7 @@ static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
   }
   dim3 grid(tiles_n, tiles_m, g.nsplit * g.batch);
   TileMap tm{};
-  if (g.lower && ctx->lat_lin && tiles_m * tiles_n >= 16) { // live tiles only
+  if (g.lower && ctx->lat_lin && tiles_m * tiles_n * g.nsplit * g.batch >= 16) { // live tiles only
     tm = make_tile_map2(1, g.ti_off - g.tj_off, tiles_m, tiles_n, 1);
     if (tm.total <= 0) return 0;
     grid = dim3(tm.total, 1, g.nsplit * g.batch);
