@@ -29,6 +29,20 @@ run trace1 "$B --inflight 1" --kernel-trace --stats
 run fetch "$B --steps 1 --warmup 0" --kernel-trace --pmc FETCH_SIZE
 run write "$B --steps 1 --warmup 0" --kernel-trace --pmc WRITE_SIZE
 run sq "$B --steps 1 --warmup 0" --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
+if [ -n "$PROFILE_CORE_ONLY" ]; then
+  # the passes bench.py's roofline block reads (trace, fetch, write, sq) + the mid-N timelines + the bench line: what has to be
+  # re-measured when only the launch geometry of the GEMM kernels changed
+  for N in 2048 4096; do
+    rm -rf /tmp/prof_sn$N
+    timeout 200 rocprofv3 --kernel-trace -d /tmp/prof_sn$N -- python tools/smalln_timeline.py run $N > $O/smalln_$N.txt 2>&1
+    python tools/smalln_timeline.py show "$(find /tmp/prof_sn$N -name '*.db' | head -1)" $O/smalln_timeline_$N.md > /dev/null 2>> $O/smalln_$N.txt
+  done
+  bash tools/exp/sgp_trace2.sh $O/sgptrace > /dev/null 2>&1 && cp $O/sgptrace/c5_step_timeline.md $O/c5_step_timeline.md
+  python bench.py > $O/bench_$RND.json 2> $O/bench_$RND.err
+  cut -c1-400 $O/bench_$RND.json
+  ls $O
+  exit 0
+fi
 # C4: the 1000-sample sweep at N = 8192, d = 3 through ExactGP.predict, plain and under the kernel trace
 python tools/c4_sweep.py > $O/c4_sweep.json 2> $O/c4_sweep.err
 run c4trace "python tools/c4_sweep.py" --kernel-trace --stats
