@@ -95,9 +95,9 @@ __device__ __forceinline__ void decode_tile(const TileMap& tm, int lower, int l,
 }
 
 // grid.x of a live-tiles launch -> (bx, by), wave-uniform
-__device__ __forceinline__ void live_tile(const TileMap& tm, int& bx, int& by) {
+__device__ __forceinline__ void live_tile(const TileMap& tm, int lower, int& bx, int& by) {
   int ty, tx;
-  decode_tile(tm, 1, bx, ty, tx);
+  decode_tile(tm, lower, bx, ty, tx);
   bx = __builtin_amdgcn_readfirstlane(tx);
   by = __builtin_amdgcn_readfirstlane(ty);
 }
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // panel / small GEMMs sit on the critical path of the look-ahead
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
-  if (tm.total > 0) live_tile(tm, bx, by); // (as in gemm_lat_kernel below)
+  if (tm.total > 0) live_tile(tm, g.lower, bx, by); // (as in gemm_lat_kernel below)
   gemm_nt_tile<MT, NT, BK, DBUF>(g, smem, bx, by, bz);
 }
 
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 6) void gemm_lat_kernel(GemmArgs g, TileMap tm
   __builtin_amdgcn_s_setprio(2); // chain launches sit on the critical path of the look-ahead
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
-  if (tm.total > 0) live_tile(tm, bx, by);
+  if (tm.total > 0) live_tile(tm, g.lower, bx, by);
   lat_tile<MT, NT, NST, EPI>(g, smem, bx, by, bz);
 }
 
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g, TileMap 
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // non-trailing launches sit on the critical path of the look-ahead
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
-  if (tm.total > 0) live_tile(tm, bx, by); // (as in gemm_lat_kernel)
+  if (tm.total > 0) live_tile(tm, g.lower, bx, by); // (as in gemm_lat_kernel)
   nt128_tile<EPI>(g, smem, bx, by, bz);
 }
 
@@ -188,6 +188,25 @@ static TileMap make_tile_map2(int lower, int delta, int tiles_m, int tiles_n, in
   tm.total = tm.per_slab * slabs;
   return tm;
 }
+// The grid of a plain (non-persistent) launch as a list: lower launches list only their live tiles; launches whose k range
+// ends (kupper) or starts (kcol) at the column tile list their tiles column by column from the longest column.  The second
+// is about WHICH tiles share a CU, not about order in time (a chain-size launch is resident all at once): workgroup id ->
+// XCD id % 8, then the XCD's CUs in turn, so in a row-major grid of 32 tile columns the four workgroups of a CU are tiles
+// of the same eight columns — four long k ranges on one CU, four short ones on another (the K = 2048 product of the top
+// L^-T tree level at N = 4096: 249 us against 164 for its row-trimmed twin of the same flop).  Column-major, a CU's tiles
+// are eight columns apart.  unit: rows of the launch's tile per 128 (2 for the 64 x 64 shapes).  total == 0: plain grid.
+static TileMap plain_launch_map(const gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int unit) {
+  TileMap tm{};
+  if (!ctx->lat_lin || (int64_t)tiles_m * tiles_n * g.nsplit * g.batch < 16) return tm;
+  if (g.lower) {
+    tm = make_tile_map2(1, unit * (g.ti_off - g.tj_off), unit * tiles_m, unit * tiles_n, 1);
+  } else if ((g.kupper || g.kcol) && !g.ktri) {
+    tm = make_tile_map2(0, 0, unit * tiles_m, unit * tiles_n, 1);
+    tm.col_desc = g.kupper ? 1 : 2;
+  }
+  return tm;
+}
+
 static TileMap make_tile_map(const GemmArgs& g, int tiles_m, int tiles_n) {
   TileMap tm = make_tile_map2(g.lower, g.ti_off - g.tj_off, tiles_m, tiles_n, g.nsplit * g.batch);
   tm.col_desc = (!g.lower && g.kupper && !g.ktri) ? 1 : ((!g.lower && g.kcol && !g.ktri) ? 2 : 0);
@@ -215,11 +234,9 @@ static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int til
   // tiles_m / tiles_n are given in 128-tiles
   dim3 grid(tiles_n * (4 / NT), tiles_m * (4 / MT), g.nsplit * g.batch);
   TileMap tm{};
-  if (MT == 2 && NT == 2 && g.lower && ctx->lat_lin && tiles_m * tiles_n * g.nsplit * g.batch >= 16) { // live tiles only
-    tm = make_tile_map2(1, 2 * (g.ti_off - g.tj_off), 2 * tiles_m, 2 * tiles_n, 1);
-    if (tm.total <= 0) return 0;
-    grid = dim3(tm.total, 1, g.nsplit * g.batch);
-  }
+  if (MT == 2 && NT == 2) tm = plain_launch_map(ctx, g, tiles_m, tiles_n, 2);
+  if (tm.total > 0) grid = dim3(tm.total, 1, g.nsplit * g.batch);
+  else if (g.lower && tm.per_slab == 0 && tm.tiles_m > 0) return 0; // (a lower launch without a live tile)
   gemm_nt_kernel<TAG, MT, NT, BK, DBUF><<<grid, 256, lds, ctx->s>>>(g, tm);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
@@ -230,11 +247,9 @@ static int launch_lat_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
   constexpr size_t lds = (size_t)NST * (32 * MT + 32 * NT) * 8 * sizeof(double); // < 48 KB: no attribute needed
   dim3 grid(tiles_n * (4 / NT), tiles_m * (4 / MT), g.nsplit * g.batch);
   TileMap tm{};
-  if (MT == 2 && NT == 2 && g.lower && ctx->lat_lin && tiles_m * tiles_n * g.nsplit * g.batch >= 16) { // live tiles only (a grid of a few dozen workgroups is placed at once either way)
-    tm = make_tile_map2(1, 2 * (g.ti_off - g.tj_off), 2 * tiles_m, 2 * tiles_n, 1);
-    if (tm.total <= 0) return 0;
-    grid = dim3(tm.total, 1, g.nsplit * g.batch);
-  }
+  if (MT == 2 && NT == 2) tm = plain_launch_map(ctx, g, tiles_m, tiles_n, 2); // (a grid of a few dozen workgroups is placed at once either way)
+  if (tm.total > 0) grid = dim3(tm.total, 1, g.nsplit * g.batch);
+  else if (g.lower && tm.per_slab == 0 && tm.tiles_m > 0) return 0;
   gemm_lat_kernel<MT, NT, NST, EPI><<<grid, 256, lds, ctx->s>>>(g, tm);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
@@ -292,12 +307,9 @@ static int launch_big_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tile
     ctx->func_attr_mask |= bit;
   }
   dim3 grid(tiles_n, tiles_m, g.nsplit * g.batch);
-  TileMap tm{};
-  if (g.lower && ctx->lat_lin && tiles_m * tiles_n * g.nsplit * g.batch >= 16) { // live tiles only
-    tm = make_tile_map2(1, g.ti_off - g.tj_off, tiles_m, tiles_n, 1);
-    if (tm.total <= 0) return 0;
-    grid = dim3(tm.total, 1, g.nsplit * g.batch);
-  }
+  TileMap tm = plain_launch_map(ctx, g, tiles_m, tiles_n, 1);
+  if (tm.total > 0) grid = dim3(tm.total, 1, g.nsplit * g.batch);
+  else if (g.lower && tm.per_slab == 0 && tm.tiles_m > 0) return 0;
   gemm_nt128_kernel<TAG, EPI><<<grid, 256, lds, ctx->s>>>(g, tm);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
