@@ -114,10 +114,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)
 
 // round-5 latency shapes (gemm_tile.h lat_tile): <2,2> 64 x 64 (ring of 3 k-slices, 24 KB), <1,4> 32 x 128 strips for the
 // in-place panel TRSM (ring of 2, 20 KB); <= 80 VGPRs: six waves per SIMD alone, one beside two trailing-update workgroups
-// tm.total > 0: a lower-tile launch WITHOUT the workgroups above the diagonal — a square grid over a triangle is half
-// workgroups that return at once, and at these sizes (a K = 128 update of 16 x 16 tile rows: 1024 workgroups for 35 MB of C)
-// the launch is paced by how fast workgroups are dispatched, not by what they do (tools/exp/update_shape_sweep.py: 23 us
-// where the C traffic is 10): blockIdx.x enumerates the live tiles row by row (TileMap in units of this shape's tiles).
+// tm.total > 0: blockIdx.x runs over a LIST of the launch's tiles (plain_launch_map below, TileMap in units of this shape's
+// tiles).  Lower launches list only their live tiles: a square grid over a triangle is half workgroups that return at once,
+// and at these sizes (a K = 128 update of 16 x 16 tile rows: 1024 workgroups for 35 MB of C) the launch is paced by how fast
+// workgroups are dispatched, not by what they do (tools/exp/update_shape_sweep.py: 23 us where the C traffic is 10).
 template <int MT, int NT, int NST, int EPI>
 __global__ __launch_bounds__(256, 6) void gemm_lat_kernel(GemmArgs g, TileMap tm) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
