@@ -81,6 +81,7 @@ def load_library() -> C.CDLL:
         "gpx_debug_set_potf2": (C.c_int, [vp, C.c_char_p]),
         "gpx_debug_set_lat_gemm": (C.c_int, [vp, C.c_char_p]),
         "gpx_debug_gemm_time": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
+        "gpx_debug_tile_list": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
         "gpx_time_stage": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
         "gpx_sweep_resident": (C.c_int, [vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp]),
         "gpx_sweep_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
@@ -121,7 +122,7 @@ EXPORTED_SYMBOLS = (
     "gpx_init gpx_device_count gpx_device_pci gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
     "gpx_factor gpx_lml_grad gpx_lml_grad_diag gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
-    "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_set_potf2 gpx_debug_set_lat_gemm gpx_debug_gemm_time gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
+    "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_set_potf2 gpx_debug_set_lat_gemm gpx_debug_gemm_time gpx_debug_tile_list gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_predict_sweep_multi "
     "gpx_rank_unique_id gpx_rank_init gpx_rank_destroy gpx_rank_last_error gpx_rank_info gpx_rank_device_pci gpx_rank_collective_calls gpx_rank_barrier "
     "gpx_rank_allreduce_max gpx_rank_bcast gpx_rank_predict_sweep gpx_shard_range"
@@ -586,6 +587,19 @@ def shard_range(S: int, part: int, parts: int) -> Tuple[int, int]:
     if load_library().gpx_shard_range(int(S), int(part), int(parts), C.byref(lo), C.byref(hi)) != 0:
         raise ValueError(f"shard_range({S}, {part}, {parts})")
     return lo.value, hi.value
+
+
+def tile_list(lower: bool, delta: int, tiles_m: int, tiles_n: int, order: int = 0) -> np.ndarray:
+    """(by, bx) of every entry of the grid of a plain GEMM launch, in grid order (gpx_debug_tile_list; host only, needs
+    no GPU): the live tiles of a lower-triangular launch, or the full grid row- / column-major."""
+    n = load_library().gpx_debug_tile_list(int(bool(lower)), int(delta), int(tiles_m), int(tiles_n), int(order), 0, None)
+    if n < 0:
+        raise ValueError(f"tile_list({lower}, {delta}, {tiles_m}, {tiles_n}, {order})")
+    out = np.zeros((n, 2), dtype=np.int32)
+    if n:
+        load_library().gpx_debug_tile_list(int(bool(lower)), int(delta), int(tiles_m), int(tiles_n), int(order), n,
+                                           out.ctypes.data_as(_ip))
+    return out
 
 
 def rccl_unique_id() -> bytes:

@@ -70,7 +70,7 @@ struct TileMap {
 };
 
 // slab-local tile id -> (by, bx)
-__device__ __forceinline__ void decode_tile(const TileMap& tm, int lower, int l, int& by, int& bx) {
+__host__ __device__ __forceinline__ void decode_tile(const TileMap& tm, int lower, int l, int& by, int& bx) {
   if (!lower) {
     if (tm.col_desc) {
       const int c = l / tm.tiles_m;
@@ -387,6 +387,20 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
   }
   return launch_big<0>(ctx, g, tiles_m, tiles_n, splits);
 }
+
+} // namespace gpx
+
+// The tile list of a plain launch, on the host: entry i of the grid -> (by, bx) as the kernels decode it (include/gpx.h).
+extern "C" int gpx_debug_tile_list(int lower, int delta, int tiles_m, int tiles_n, int order, int cap, int* by_bx) {
+  using namespace gpx;
+  if (tiles_m < 0 || tiles_n < 0 || order < 0 || order > 2 || cap < 0 || (cap > 0 && !by_bx)) return -1;
+  TileMap tm = make_tile_map2(lower ? 1 : 0, delta, tiles_m, tiles_n, 1);
+  tm.col_desc = lower ? 0 : order;
+  for (int l = 0; l < tm.total && l < cap; ++l) decode_tile(tm, lower ? 1 : 0, l, by_bx[2 * l], by_bx[2 * l + 1]);
+  return tm.total;
+}
+
+namespace gpx {
 
 // ---- raw MFMA issue-rate microbenchmark ----------------------------------------------------
 // out[0] = shader cycles (s_memtime) spent by wave 0 of block 0 in the loop,

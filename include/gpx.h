@@ -283,6 +283,15 @@ int gpx_debug_set_lat_gemm(gpx_ctx* ctx, const char* mode);
 int gpx_debug_gemm_time(gpx_ctx* ctx, int tiles_m, int tiles_n, int K, int mode, int lower, int shape, int reps,
                         double* ms_per_launch);
 
+/* Diagnostic, host only (no GPU, no context): the tile list a plain GEMM launch of the library runs over since round 5 —
+ * entry i of grid.x -> (by, bx) written to by_bx[2 i], by_bx[2 i + 1], at most `cap` entries; returns the length of the
+ * list (< 0: bad arguments).  lower != 0: the live tiles of a lower-triangular launch, row by row (bx <= by + delta,
+ * delta = first tile row - first tile column of the launch, in tiles of the launch's shape).  lower == 0: the full
+ * tiles_m x tiles_n grid, order 0 row-major, 1 column-major from the LAST column (k range ends at the column tile), 2
+ * column-major from the first column (k range starts there).  What tests/test_tile_list.py checks against a brute-force
+ * enumeration; the trailing update of the Cholesky under gpax/models/gp.py:160-164 is such a launch. */
+int gpx_debug_tile_list(int lower, int delta, int tiles_m, int tiles_n, int order, int cap, int* by_bx);
+
 /* Device-only timed repetitions (inputs resident in HBM; used by bench.py so that `value`
  * excludes PCIe).  Each call runs `reps` passes of the named stage at the theta/Xnew last set
  * by gpx_factor/gpx_posterior and returns the elapsed milliseconds between HIP events. */
