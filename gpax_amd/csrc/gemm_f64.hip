@@ -115,9 +115,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)
 // round-5 latency shapes (gemm_tile.h lat_tile): <2,2> 64 x 64 (ring of 3 k-slices, 24 KB), <1,4> 32 x 128 strips for the
 // in-place panel TRSM (ring of 2, 20 KB); <= 80 VGPRs: six waves per SIMD alone, one beside two trailing-update workgroups
 // tm.total > 0: blockIdx.x runs over a LIST of the launch's tiles (plain_launch_map below, TileMap in units of this shape's
-// tiles).  Lower launches list only their live tiles: a square grid over a triangle is half workgroups that return at once,
-// and at these sizes (a K = 128 update of 16 x 16 tile rows: 1024 workgroups for 35 MB of C) the launch is paced by how fast
-// workgroups are dispatched, not by what they do (tools/exp/update_shape_sweep.py: 23 us where the C traffic is 10).
+// tiles).  Lower launches list only their live tiles.  Not because the workgroups above the diagonal cost time — they return
+// at once, and the chip hands out > 2000 empty workgroups per us (tools/exp/dispatch_probe.hip) — but because they take part
+// in the deal: workgroup id -> XCD id % 8, so in a square grid of even width the live tiles of column bx all land on XCD
+// bx % 8, and a triangle has more tiles in its low columns: XCD 0 holds 21 % more live tiles than the average at 16 x 16
+// tile rows (41 % at 8 x 8), 17 % more work in K^-1 = L^-T L^-1 at 32 x 32 — and a launch lasts as long as its fullest
+// XCD.  A list deals the live tiles themselves round.
 template <int MT, int NT, int NST, int EPI>
 __global__ __launch_bounds__(256, 6) void gemm_lat_kernel(GemmArgs g, TileMap tm) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -188,7 +191,8 @@ static TileMap make_tile_map2(int lower, int delta, int tiles_m, int tiles_n, in
   tm.total = tm.per_slab * slabs;
   return tm;
 }
-// The grid of a plain (non-persistent) launch as a list: lower launches list only their live tiles; launches whose k range
+// The grid of a plain (non-persistent) launch as a list: lower launches list only their live tiles (gemm_lat_kernel above:
+// the deal to the XCDs then is even); launches whose k range
 // ends (kupper) or starts (kcol) at the column tile list their tiles column by column from the longest column.  The second
 // is about WHICH tiles share a CU, not about order in time (a chain-size launch is resident all at once): workgroup id ->
 // XCD id % 8, then the XCD's CUs in turn, so in a row-major grid of 32 tile columns the four workgroups of a CU are tiles
