@@ -102,14 +102,14 @@ __device__ __forceinline__ void live_tile(const TileMap& tm, int lower, int& bx,
   by = __builtin_amdgcn_readfirstlane(ty);
 }
 
-template <int TAG, int MT, int NT, int BK, bool DBUF>
-__global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : 6)) void gemm_nt_kernel(GemmArgs g, TileMap tm) {
+template <int TAG, int MT, int NT, int BK, bool DBUF, int EPI>
+__global__ __launch_bounds__(256, (MT * NT >= 16) ? 2 : ((MT * NT >= 8) ? 3 : (BK == 32 ? 4 : 5))) void gemm_nt_kernel(GemmArgs g, TileMap tm) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (TAG == 0) __builtin_amdgcn_s_setprio(2); // panel / small GEMMs sit on the critical path of the look-ahead
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (g.nsplit == 1) batch_xcd_order(bx, by, bz);
   if (tm.total > 0) live_tile(tm, g.lower, bx, by); // (as in gemm_lat_kernel below)
-  gemm_nt_tile<MT, NT, BK, DBUF>(g, smem, bx, by, bz);
+  gemm_nt_tile<MT, NT, BK, DBUF, EPI>(g, smem, bx, by, bz);
 }
 
 // round-5 latency shapes (gemm_tile.h lat_tile): <2,2> 64 x 64 (ring of 3 k-slices, 24 KB), <1,4> 32 x 128 strips for the
@@ -220,18 +220,15 @@ static TileMap make_tile_map(const GemmArgs& g, int tiles_m, int tiles_n) {
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a function: every context sets it once
 // for each variant it launches (a process may hold contexts on several GPUs; contexts are also driven from
 // different host threads, so the "done" bits live in the context, not in a function-local static).
-enum : unsigned { ATTR_SMALL_22 = 0, ATTR_SMALL_24 = 1, ATTR_BIG_BASE = 2 /* + 3 * TAG + EPI */, ATTR_PERSIST_BASE = 8,
-                  ATTR_SMALL_22_BK32 = 20, ATTR_SMALL_24_BK32 = 21 };
+enum : unsigned { ATTR_BIG_BASE = 2 /* + 3 * TAG + EPI */, ATTR_PERSIST_BASE = 8 /* + 3 * TAG + EPI */,
+                  ATTR_SMALL_22 = 14 /* + EPI */, ATTR_SMALL_24 = 17, ATTR_SMALL_22_BK32 = 22, ATTR_SMALL_24_BK32 = 25 };
 
-template <int TAG, int MT, int NT, int BK, bool DBUF>
-static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int tiles_n, int splits) {
-  GemmArgs g = g0;
-  g.nsplit = splits > 0 ? splits : 1;
-  if (g.batch < 1) g.batch = 1;
+template <int TAG, int MT, int NT, int BK, bool DBUF, int EPI>
+static int launch_variant_epi(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n) {
   constexpr size_t lds = gemm_lds_bytes<MT, NT, BK, DBUF>();
-  constexpr unsigned bit = 1u << (BK == 32 ? ((NT == 2) ? ATTR_SMALL_22_BK32 : ATTR_SMALL_24_BK32) : ((NT == 2) ? ATTR_SMALL_22 : ATTR_SMALL_24));
+  constexpr unsigned bit = 1u << (EPI + (BK == 32 ? ((NT == 2) ? ATTR_SMALL_22_BK32 : ATTR_SMALL_24_BK32) : ((NT == 2) ? ATTR_SMALL_22 : ATTR_SMALL_24)));
   if (!(ctx->func_attr_mask & bit)) {
-    GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<TAG, MT, NT, BK, DBUF>),
+    GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<TAG, MT, NT, BK, DBUF, EPI>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ctx->func_attr_mask |= bit;
   }
@@ -241,9 +238,20 @@ static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int til
   if (MT == 2 && NT == 2) tm = plain_launch_map(ctx, g, tiles_m, tiles_n, 2);
   if (tm.total > 0) grid = dim3(tm.total, 1, g.nsplit * g.batch);
   else if (g.lower && tm.per_slab == 0 && tm.tiles_m > 0) return 0; // (a lower launch without a live tile)
-  gemm_nt_kernel<TAG, MT, NT, BK, DBUF><<<grid, 256, lds, ctx->s>>>(g, tm);
+  gemm_nt_kernel<TAG, MT, NT, BK, DBUF, EPI><<<grid, 256, lds, ctx->s>>>(g, tm);
   GPX_HIP(ctx, hipGetLastError());
   return 0;
+}
+
+// the epilogue form is a template parameter of the kernel (gemm_tile.h gemm_nt_tile): chosen here, per launch
+template <int TAG, int MT, int NT, int BK, bool DBUF>
+static int launch_variant(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int tiles_n, int splits) {
+  GemmArgs g = g0;
+  g.nsplit = splits > 0 ? splits : 1;
+  if (g.batch < 1) g.batch = 1;
+  if (g.beta == 0.0) return launch_variant_epi<TAG, MT, NT, BK, DBUF, 0>(ctx, g, tiles_m, tiles_n);
+  if (g.alpha == -1.0 && g.beta == 1.0) return launch_variant_epi<TAG, MT, NT, BK, DBUF, 1>(ctx, g, tiles_m, tiles_n);
+  return launch_variant_epi<TAG, MT, NT, BK, DBUF, 2>(ctx, g, tiles_m, tiles_n);
 }
 
 template <int MT, int NT, int NST, int EPI>

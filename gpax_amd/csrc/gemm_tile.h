@@ -44,7 +44,11 @@ __device__ __forceinline__ void batch_offsets(const GemmArgs& g, const int bb, i
 // in the LDS two resident trailing-update workgroups leave free, so a chain launch is placed at once.
 // One (32 MT) x (32 NT) tile of the latency shapes: the body of gemm_nt_kernel as a device function, so that the
 // cooperative panel kernel (panel.hip) runs the very same arithmetic on its strips.
-template <int MT, int NT, int BK, bool DBUF>
+// EPI: the epilogue form, uniform over a launch and chosen by the host (as in lat_tile / nt128_tile below): 0 beta == 0 |
+// 1 alpha == -1, beta == 1 | 2 generic.  (Rounds 1 - 5 chose it at run time inside the kernel: the 32 x 128 strip instantiation
+// then carried the generic read-modify-write epilogue — 22 - 26 spilled VGPRs, a 92-byte private segment — for code its
+// launches never run.)  Staging, k order and arithmetic are untouched: the same bits.
+template <int MT, int NT, int BK, bool DBUF, int EPI>
 __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g, double* smem, const int bx, const int by, const int bzz) {
   constexpr int BM = 32 * MT, BN = 32 * NT, LDT = BK + 1;
   constexpr int TA = BM * LDT, TB = BN * LDT;
@@ -90,7 +94,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g, double* smem, co
 
   // epilogue form (uniform over the launch) — the same three forms as gemm_nt128_kernel, see the file header
   const double alpha = g.alpha, beta = g.beta;
-  const bool cacc = (alpha == -1.0 && beta == 1.0);
+  constexpr bool cacc = (EPI == 1);
   double* Cw = C + ((int64_t)by * BM + wr * 16 * MT + fk) * g.ldc + (int64_t)bx * BN + wc * 16 * NT + fr;
   d4_t acc[MT][NT];
   if (cacc) {
@@ -178,7 +182,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g, double* smem, co
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int n = 0; n < NT; ++n) Cw[(int64_t)(m * 16 + 4 * r) * g.ldc + n * 16] = -acc[m][n][r];
-  } else if (beta != 0.0) {
+  } else if (EPI == 2) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       double cv[4][NT];

@@ -242,10 +242,10 @@ __global__ __launch_bounds__(256) void sgp_contract_kernel(KernelParams kp, cons
   const int bj = blockIdx.x, bi = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = bj * 64 + lane; // column = inducing point index
-  double acc[DM + 2];
+  double acc[DM], acc_scale = 0.0; // (the scale partial in a scalar of its own: acc[d] with a run-time d put the array in scratch)
   double gx[DM];
 #pragma unroll
-  for (int c = 0; c < DM + 2; ++c) acc[c] = 0.0;
+  for (int c = 0; c < DM; ++c) acc[c] = 0.0;
 #pragma unroll
   for (int c = 0; c < DM; ++c) gx[c] = 0.0;
   if (j < M) {
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void sgp_contract_kernel(KernelParams kp, cons
         acc[c] += g * dk * (-2.0 * diff[c] * diff[c] * kp.inv_ell[c]);
         gx[c] += g * dk * (2.0 * diff[c] * kp.inv_ell[c]); // d k / d xu_c
       }
-      acc[d] += g * kv / kp.scale;
+      acc_scale += g * kv / kp.scale;
     }
   }
 #pragma unroll
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void sgp_contract_kernel(KernelParams kp, cons
 #pragma unroll
   for (int c = 0; c < DM + 2; ++c) {
     if (c >= d + 2) break;
-    const double s = bsum(acc[c], red);
+    const double s = bsum(c < d ? acc[c < DM ? c : 0] : (c == d ? acc_scale : 0.0), red);
     if (threadIdx.x == 0) part[bid * SC_NV + c] = s;
   }
 }

@@ -11,6 +11,7 @@ from typing import Callable, Dict, Optional, Tuple
 
 import numpy as np
 
+from .. import _lib
 from ..infer import dist
 from ..infer.svi import fit_delta, fit_normal
 from ..utils.utils import initialize_inducing_points, rng_from_key, split_in_batches
@@ -33,6 +34,42 @@ class viSparseGP(viGP):
         if self.kernel_name == "Periodic":
             raise NotImplementedError("viSparseGP on the MI355X path supports 'RBF' and 'Matern'")
         self.Xu = None
+
+    def model(self, X, y=None, Xu=None, params: Optional[Dict[str, np.ndarray]] = None, **kwargs: float) -> float:
+        """The reference's NumPyro program (sparse_gp.py:62-114) registers the prior sites, the factor
+        `-trace_term / 2` and a LowRankMultivariateNormal likelihood with a tracer.  As ExactGP.model does for the exact
+        program, this evaluates what that program defines — the log joint of the VFE objective
+            log N(y | m, W W^T + noise I) - clip(tr(Kff - Qff) / noise, 0) / 2 + sum_sites log p(theta_site)
+        at `params` (constrained values; default: the prior medians) and the inducing points `Xu` (default: the fitted
+        self.Xu), the bound on the device (gpx_sgp_bound, no gradient).  y = None: the log prior alone.  NaN when Kuu or
+        the capacitance matrix is not positive definite."""
+        X = self._set_data(X)
+        sites = self._sites()
+        theta = {s.name: (np.full(s.shape, float(s.dist.median())) if s.shape else float(s.dist.median()))
+                 for s in sites}
+        if params is not None:
+            theta.update({k: v for k, v in params.items() if k in theta})
+        theta = self._with_deterministic(theta)
+        val = 0.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for s_ in sites:
+                val += float(np.sum(s_.dist.log_prob(np.asarray(theta[s_.name], dtype=np.float64).reshape(-1))))
+        if y is None:
+            return val
+        if Xu is None:
+            Xu = self.Xu
+        if Xu is None:
+            raise ValueError("viSparseGP.model needs inducing points: pass Xu or fit the model first")
+        Xu = np.asarray(Xu, dtype=np.float64)
+        if Xu.ndim == 1:
+            Xu = Xu[:, None]
+        y = np.asarray(y, dtype=np.float64).squeeze()
+        eng = _lib.get_engine(self._device)
+        eng.set_train(X)
+        bound, info, _ = eng.sgp_bound(self._kind, self._ell(theta), self._scalar(theta["k_scale"]),
+                                       self._scalar(theta["noise"]), float(kwargs.get("jitter", 1e-6)), Xu,
+                                       y - self._mean(X, theta), want_grad=False)
+        return val + bound if info == 0 and np.isfinite(bound) else float("nan")
 
     # -- objective: bound + log prior (+ log |J|), gradient w.r.t. (u, Xu) -----------------------------
     def _sparse_log_joint(self, sites, x, Mi: int, jitter: float, jacobian: bool):

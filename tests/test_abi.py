@@ -63,7 +63,9 @@ def test_chain_kernels_fit_beside_two_resident_trailing_update_workgroups():
     import kernel_resources as kr
 
     csrc = os.path.join(os.path.dirname(__file__), "..", "gpax_amd", "csrc")
-    rows = {r["name"]: r for f in ("potf2.hip", "gemm_f64.hip", "fit_small.hip") for r in kr.resources(os.path.join(csrc, f))}
+    files = sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))
+    assert {"potf2.hip", "gemm_f64.hip", "fit_small.hip", "linalg.hip", "sparse.hip", "gram.hip", "api.hip"} <= set(files)
+    rows = {r["name"]: r for f in files for r in kr.resources(os.path.join(csrc, f))}
 
     def find(sub):
         hit = [r for n, r in rows.items() if sub in n]
@@ -82,10 +84,15 @@ def test_chain_kernels_fit_beside_two_resident_trailing_update_workgroups():
     assert int(slim["vgpr_spill_count"]) == 0 and int(slim["private_segment_fixed_size"]) == 0
     assert (13 * 16 * 17 + 64) * 8 <= free_lds  # POTF2_SLIM_LDS (dynamic LDS: csrc/potf2_slim.h)
     assert not [n for n in rows if "potf2_chain_kernel" in n]  # round 3's 344-VGPR kernel left the product (tools/exp/)
-    for shape in ("gemm_nt_kernelILi0ELi2ELi2ELi16E", "gemm_nt_kernelILi0ELi1ELi4ELi16E"):  # round 1: 64x64, 32x128 strips
-        assert alloc(find(shape)) <= free_vgpr
-    # round 5 latency shapes (gemm_tile.h lat_tile), every epilogue form: <= 80 VGPRs, no scratch at all (the round-1 strip
-    # kernel carries a private segment for a generic-beta epilogue its launches never run: VERDICT r4 weak #2), and their
+    # round-1 register-staged latency shapes (64x64, 32x128 strips): the chain launches of every BLOCKED factorisation
+    # (csrc/linalg.hip lat_now = 1: C3, C4, every N > 5120) — BK = 16 fits beside two trailing-update workgroups in every
+    # epilogue form (EPI 0 / 1 / 2 are kernels of their own since round 6)
+    r1 = [r for n, r in rows.items() if "gemm_nt_kernel" in n]
+    assert len(r1) == 12  # 2 shapes x BK 16 / 32 x 3 epilogue forms
+    for r in r1:
+        if "Li16ELb0E" in r["name"]:
+            assert alloc(r) <= free_vgpr, (r["name"], r["vgpr_count"])
+    # round 5 latency shapes (gemm_tile.h lat_tile), every epilogue form: <= 80 VGPRs, no scratch at all, and their
     # LDS rings — 3 x (64 + 64) x 64 B and 2 x (32 + 128) x 64 B — fit in the 28 KB the diagonal-block kernel is known to
     # be placed with
     lat = [r for n, r in rows.items() if "gemm_lat_kernel" in n]
@@ -95,8 +102,7 @@ def test_chain_kernels_fit_beside_two_resident_trailing_update_workgroups():
         assert int(r["vgpr_spill_count"]) == 0 and int(r["sgpr_spill_count"]) == 0 and int(r["private_segment_fixed_size"]) == 0
     assert 3 * 128 * 64 <= 28 * 1024 and 2 * 160 * 64 <= 28 * 1024
     assert len([n for n in rows if "fit_small_kernel" in n]) == 15  # 3 kernels x (d = 1 .. 4, generic d)
-    # no VGPR spill and no private segment in any kernel a default run launches
+    # no VGPR spill and no private segment in ANY kernel of the library (every .hip under csrc/)
+    assert len(rows) > 100
     for n, r in rows.items():
-        if "gemm_nt_kernel" in n:  # GPX_LAT_GEMM=r1 only
-            continue
         assert int(r["vgpr_spill_count"]) == 0 and int(r["private_segment_fixed_size"]) == 0, n

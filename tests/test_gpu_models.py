@@ -181,6 +181,31 @@ def test_model_log_joint_on_gpu():
     assert abs((full - prior) - expect) <= 1e-10 * abs(expect)
 
 
+@pytest.mark.parametrize("kernel", ["RBF", "Matern"])
+def test_sparse_model_log_joint_on_gpu(kernel):
+    """viSparseGP.model(X, y, Xu) (sparse_gp.py:62-114): priors + LowRankMVN likelihood - trace_term / 2 = the VFE bound
+    (gpx_sgp_bound) + the site log-densities; a lower bound of the exact log joint at the same theta; y = None: priors."""
+    from gpax_amd.models import viSparseGP
+    X, y, _, p = bench_inputs.synthetic_problem(700, 2, 4, seed=4)
+    Xu = X[np.random.default_rng(5).choice(700, 90, replace=False)] + 0.01
+    params = {"k_length": p["k_length"], "k_scale": p["k_scale"], "noise": p["noise"]}
+    m = viSparseGP(2, kernel, noise_prior_dist=dist.HalfNormal(0.5))
+    lp = dist.LogNormal(0, 1).log_prob(np.asarray(p["k_length"], dtype=float)).sum() \
+        + dist.LogNormal(0, 1).log_prob(np.array([p["k_scale"]]))[0] + dist.HalfNormal(0.5).log_prob(np.array([p["noise"]]))[0]
+    assert abs(m.model(X, None, params=params) - lp) < 1e-12
+    full = m.model(X, y, Xu, params=params)
+    expect = ref.sparse_bound(X, y, Xu, p, kernel=kernel, jitter=1e-6)
+    assert abs((full - lp) - expect) <= 1e-9 * abs(expect)
+    exact = ExactGP(2, kernel, noise_prior_dist=dist.HalfNormal(0.5)).model(X, y, params=params)
+    assert full <= exact
+    m.Xu = Xu  # what fit() stores: the default of the Xu argument
+    assert m.model(X, y, params=params) == full
+    assert np.isfinite(m.model(X, y, Xu))  # default params: the prior medians
+    assert np.isnan(m.model(X, y, Xu, params={**params, "k_scale": -1.0}))
+    with pytest.raises(ValueError):
+        viSparseGP(2, kernel).model(X, y)
+
+
 def test_custom_kernel_prior_fit_on_gpu():  # gpax/tests/test_gp.py:129-134
     import gpax_amd
 
