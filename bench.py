@@ -212,28 +212,48 @@ def write_only_fill_GBps(nbytes):
 
 
 def committed_pmc_record(N, d, M):
-    """HBM traffic and the serialised launch time of the dominant kernel from the committed rocprofv3 --pmc passes of
-    this same command (profiles/<round>/traffic.json; FETCH_SIZE doubled per the gfx950 correction,
-    MI355X_MICROARCH.md §HBM).  Under a PMC pass every dispatch runs alone, so the average duration there is the
-    kernel's rate WITHOUT the panel chain sharing the CUs."""
-    out = {"traffic": None, "traffic_note": None, "serialised_avg_launch_ms": None}
+    """HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/<round>/traffic.json; FETCH_SIZE doubled per the gfx950 correction, MI355X_MICROARCH.md §HBM) — the one
+    field of the roofline block that is NOT measured in this run (counters need rocprofv3 around the process)."""
+    out = {"traffic": None, "traffic_note": None, "pmc_serialised_avg_launch_ms": None}
     if (N, d, M) != (16384, 2, 1024):
         return out
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         tj = os.path.join(ROOT, "profiles", rnd, "traffic.json")
         if not os.path.exists(tj):
             continue
         t = json.load(open(tj))
         if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
             out["traffic"] = (2.0 * t["FETCH_SIZE"]["avg_per_launch"] + t["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
-            out["traffic_note"] = (f"bytes per launch, profiles/{rnd}/{{fetch,write}}.md: (2*FETCH_SIZE + WRITE_SIZE) KB"
-                                   + ("" if rnd in ("r03", "r04", "r05") else " (an earlier round's kernel)"))
+            out["traffic_note"] = (f"bytes per launch, profiles/{rnd}/traffic.json (from {{fetch,write}}.md): (2*FETCH_SIZE + WRITE_SIZE) KB"
+                                   + ("" if rnd in ("r03", "r04", "r05", "r06") else " (an earlier round's kernel)"))
             us = [v["avg_duration_us"] for v in t.values() if isinstance(v, dict) and "avg_duration_us" in v]
-            if us:
-                out["serialised_avg_launch_ms"] = float(np.mean(us)) * 1e-3
-                out["serialised_note"] = f"average duration of the same kernel under the --pmc passes of profiles/{rnd} (every dispatch alone on the chip)"
+            if us:  # every dispatch runs alone under a PMC pass: what the live serialised figure is checked against
+                out["pmc_serialised_avg_launch_ms"] = float(np.mean(us)) * 1e-3
             break
     return out
+
+
+def serialised_trailing_record(eng):
+    """The dominant kernel ALONE on the chip, measured in this run: one more predict pass with every Cholesky trailing
+    update serialised against the panel stream of the look-ahead (gpx_debug_set_serialise_trailing) — the same 24 launches
+    on the same operands, HIP events around each on its stream, nothing else resident while they run."""
+    from gpax_amd import _lib
+    eng.set_serialise_trailing(True)
+    try:
+        eng.time_stage(_lib.STAGE_PREDICT, 1)  # warm-up in this mode
+        eng.profile_enable(True)
+        per = []
+        for _ in range(3):
+            eng.profile_reset()
+            eng.time_stage(_lib.STAGE_PREDICT, 1)
+            n, ms, flops = eng.profile_read(_lib.PROF_GEMM_TRAILING)
+            per.append((ms / n if n else None, n, flops))
+        eng.profile_enable(False)
+    finally:
+        eng.set_serialise_trailing(False)
+    per.sort(key=lambda r: r[0])
+    return {"avg_launch_ms": per[1][0], "launches": per[1][1], "flops": per[1][2], "passes": 3}
 
 
 def potf2_record(eng, a):
@@ -293,6 +313,7 @@ def device_record(eng, a, lml):
         eng.time_stage(st, 1)  # warm-up
         stages[name + "_ms"] = float(np.median([eng.time_stage(st, 1) for _ in range(5)]))
     pmc = committed_pmc_record(N, d, M)
+    ser = serialised_trailing_record(eng)
     post_flops = N ** 3 / 3 + N * N * M + N * M * M + 2 * N * N + 2 * N * M
     pk = FP64_MFMA_PEAK_TFLOPS * 1e12
     p2 = potf2_record(eng, a)
@@ -313,15 +334,20 @@ def device_record(eng, a, lml):
         "launches": n_l,
         "avg_launch_ms": ms / n_l if n_l else None,
         "alg_flops_per_launch_avg": flops / n_l if n_l else None,
-        "serialised_avg_launch_ms": pmc["serialised_avg_launch_ms"],
-        "serialised_frac": ((flops / n_l) / (pmc["serialised_avg_launch_ms"] * 1e-3) / pk)
-        if (pmc["serialised_avg_launch_ms"] and n_l) else None,
-        "serialised_note": pmc.get("serialised_note"),
-        "committed_constants": ["traffic", "traffic_over_alg_bytes (its numerator)", "serialised_avg_launch_ms", "serialised_frac "
-                                "(its denominator)"],
-        "committed_constants_note": "read from the committed rocprofv3 --pmc summaries under profiles/ (separate passes of this "
-                                    "same command, MI355X_MICROARCH.md HBM section); every other field of this block is "
-                                    "measured live in this run with HIP events on the launching stream",
+        "serialised_avg_launch_ms": ser["avg_launch_ms"],
+        "serialised_frac": ((ser["flops"] / ser["launches"]) / (ser["avg_launch_ms"] * 1e-3) / pk)
+        if (ser["avg_launch_ms"] and ser["launches"]) else None,
+        "serialised_note": "measured live in this run: the same launches with every trailing update ALONE on the chip "
+                           "(gpx_debug_set_serialise_trailing: main stream waits for the panel stream and vice versa), HIP "
+                           "events around each launch, median of 3 predict passes",
+        "serialised_launches": ser["launches"],
+        "pmc_serialised_avg_launch_ms": pmc["pmc_serialised_avg_launch_ms"],
+        "committed_constants": ["traffic", "traffic_over_alg_bytes (its numerator)", "pmc_serialised_avg_launch_ms"],
+        "committed_constants_note": "traffic is read from the committed rocprofv3 --pmc summary named in traffic_note "
+                                    "(separate passes of this same command, MI355X_MICROARCH.md HBM section); "
+                                    "pmc_serialised_avg_launch_ms is the kernel's average duration under those passes, "
+                                    "kept only as the cross-check of serialised_avg_launch_ms; every other field of this "
+                                    "block is measured live in this run with HIP events on the launching stream",
     }
     return {
         "roofline": roof,

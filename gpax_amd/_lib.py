@@ -80,6 +80,7 @@ def load_library() -> C.CDLL:
         "gpx_profile_read_bytes": (C.c_int, [vp, C.c_int, _dp]),
         "gpx_debug_set_potf2": (C.c_int, [vp, C.c_char_p]),
         "gpx_debug_set_lat_gemm": (C.c_int, [vp, C.c_char_p]),
+        "gpx_debug_set_serialise_trailing": (C.c_int, [vp, C.c_int]),
         "gpx_debug_gemm_time": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
         "gpx_debug_tile_list": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
         "gpx_time_stage": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
@@ -122,7 +123,7 @@ EXPORTED_SYMBOLS = (
     "gpx_init gpx_device_count gpx_device_pci gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
     "gpx_factor gpx_lml_grad gpx_lml_grad_diag gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
-    "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_set_potf2 gpx_debug_set_lat_gemm gpx_debug_gemm_time gpx_debug_tile_list gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
+    "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_set_potf2 gpx_debug_set_lat_gemm gpx_debug_set_serialise_trailing gpx_debug_gemm_time gpx_debug_tile_list gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_predict_sweep_multi "
     "gpx_rank_unique_id gpx_rank_init gpx_rank_destroy gpx_rank_last_error gpx_rank_info gpx_rank_device_pci gpx_rank_collective_calls gpx_rank_barrier "
     "gpx_rank_allreduce_max gpx_rank_bcast gpx_rank_predict_sweep gpx_shard_range"
@@ -440,6 +441,10 @@ class Engine:
     def set_lat_gemm(self, mode: str) -> None:
         """Latency-shape GEMM of the panel chains for the following calls: 'auto' (default), 'r5' or 'r1' — same bits."""
         self._check(self._lib.gpx_debug_set_lat_gemm(self._ctx, mode.encode()), "gpx_debug_set_lat_gemm")
+
+    def set_serialise_trailing(self, on: bool) -> None:
+        """Measurement mode: the Cholesky trailing updates of the following calls run alone on the chip (gpx.h)."""
+        self._check(self._lib.gpx_debug_set_serialise_trailing(self._ctx, int(bool(on))), "gpx_debug_set_serialise_trailing")
 
     def gemm_time(self, tiles_m: int, tiles_n: int, K: int, mode: int = 1, lower: bool = False, shape: int = 0,
                   reps: int = 20) -> float:

@@ -1272,6 +1272,12 @@ int gpx_debug_set_potf2(gpx_ctx* ctx, const char* mode) {
   return 0;
 }
 
+int gpx_debug_set_serialise_trailing(gpx_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  ctx->serialise_trailing = on != 0;
+  return 0;
+}
+
 int gpx_debug_set_lat_gemm(gpx_ctx* ctx, const char* mode) {
   if (!ctx || !mode) return -1;
   const std::string v(mode);

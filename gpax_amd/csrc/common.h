@@ -194,6 +194,7 @@ struct gpx_ctx {
   int lat_now = 5; // the kernel the launches of the current driver call take (set by the drivers from lat_gemm)
   bool lat_lin = true; // lower-tile launches of the round-5 latency shape enumerate only the live tiles (GPX_LAT_LIN=0: square grid)
   hipEvent_t evD = nullptr;
+  bool serialise_trailing = false; // measurement mode: every Cholesky trailing update runs alone on the chip (linalg.hip)
   // > 0 while a driver whose own panel chain holds no potf2 (the right-looking TRSM sweeps, the K^-1 = W W^T product)
   // is queueing launches: its big-tile GEMMs run persistently (GPX_PERSIST_SCOPE=0 disables)
   int persist_scope = 0;

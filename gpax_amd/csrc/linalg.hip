@@ -117,7 +117,21 @@ static int trailing_update(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int 
     if (full > 0) entries += (double)full * TILE * TILE;
     if (R >= c0 && R < c1) entries += 0.5 * TILE * (TILE + 1.0);
   }
-  return launch_gemm_nt(ctx, g, rows, cols, 0, prof_cls, 2.0 * K * entries);
+  // measurement mode (gpx_debug_set_serialise_trailing): the bulk update runs ALONE on the chip — it starts when the
+  // other stream of the look-ahead has drained and that stream resumes when it is done — so that the HIP events around it
+  // (ProfScope) give the kernel's rate on its real operands and shapes without the panel chain sharing the SIMDs
+  const bool alone = ctx->serialise_trailing && prof_cls == GPX_PROF_GEMM_TRAILING;
+  hipStream_t other = (ctx->s == ctx->stream) ? ctx->pstream : ctx->stream;
+  if (alone) {
+    GPX_HIP(ctx, hipEventRecord(ctx->evD, other));
+    GPX_HIP(ctx, hipStreamWaitEvent(ctx->s, ctx->evD, 0));
+  }
+  const int rc = launch_gemm_nt(ctx, g, rows, cols, 0, prof_cls, 2.0 * K * entries);
+  if (alone && rc >= 0) {
+    GPX_HIP(ctx, hipEventRecord(ctx->evD, ctx->s));
+    GPX_HIP(ctx, hipStreamWaitEvent(other, ctx->evD, 0));
+  }
+  return rc;
 }
 
 static int ensure_events(gpx_ctx* ctx, int nouter) {

@@ -274,6 +274,12 @@ int gpx_debug_set_potf2(gpx_ctx* ctx, const char* mode);
  * staging, the reference of the bit-identity tests) or "auto" (default: r5 wherever a chain has the chip to itself, r1
  * inside the blocked two-stream sweeps; csrc/common.h).  Same bits from all.  GPX_LAT_GEMM at gpx_init. */
 int gpx_debug_set_lat_gemm(gpx_ctx* ctx, const char* mode);
+/* Measurement mode (bench.py's roofline block): on != 0 — every trailing update of the blocked Cholesky (the SYRK under
+ * gpax/models/gp.py:160-164, profile class GPX_PROF_GEMM_TRAILING) of the following calls on this context runs ALONE on the
+ * chip: it starts when the panel stream of the look-ahead has drained, and that stream resumes when it is done.  The HIP
+ * events gpx_profile_* puts around each launch then time the kernel on its real operands and shapes without the panel
+ * chain sharing the SIMDs ("serialised" launch time).  Results are the same bits; only the overlap is given up. */
+int gpx_debug_set_serialise_trailing(gpx_ctx* ctx, int on);
 /* Diagnostic: device time of ONE GEMM launch of the library on resident scratch operands (constant, non-zero), average
  * over `reps` back-to-back launches between two HIP events: C (tiles_m x tiles_n 128-tiles) from A (tiles_m*128 x K) and
  * B (tiles_n*128 x K).  mode 0: C = A B^T; 1: C -= A B^T (the Cholesky / TRSM update form: accumulators start from -C);

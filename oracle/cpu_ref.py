@@ -25,7 +25,12 @@ is pinned the same way through the seven posterior tables examples/gpax_GPBO.ipy
 loop — each step's data contain the argmax of UCB over predict() of the step before: tests/test_reference_gpbo_loop.py runs that loop
 exactly with this file's kernel functions and reproduces the tables (steps 4 - 7 within the path envelope the reference's own Monte-Carlo
 error leaves).  Covariances off the diagonal, MVN sampling given eps, the sparse (VFE) bound / posterior and everything bit-level remain
-UNPINNED by reference-generated numbers.  Beyond that, this restatement follows the
+UNPINNED by reference-generated numbers.  The sparse leg is tied to the pinned exact leg ANALYTICALLY only
+(tests/test_oracle.py::test_sparse_bound_tends_to_the_exact_log_likelihood_when_inducing_equals_train and
+::test_sparse_posterior_tends_to_exact_when_inducing_equals_train): at Xu = X the reference's own calls make sparse_bound equal
+exactgp_log_likelihood (the pinned function) to 1e-7, and nested inducing sets approach it from below.  That pins the
+LowRankMVN log-density, the Woodbury algebra and the SIGN and clip of the trace term at that limit; it does NOT pin the
+trace term's magnitude away from the limit (it vanishes there), nor any number the reference generated for a sparse model.  Beyond that, this restatement follows the
 reference line by line (file:line cited per function, paths relative to the reference checkout) and is cross-checked
 independently (tests/test_oracle.py): direct-formula Gram in mpmath at 50 digits, scipy.stats.multivariate_normal for
 the log-density, explicit-inverse vs Cholesky route for the posterior, central finite differences for the gradient,

@@ -242,3 +242,35 @@ def test_sliced_sweep_equals_slice_by_slice_sweeps(engine, kind, name, M, ms):
     m_ref, c_ref = ref.get_mvn_posterior(X, yres[s], Xn[sl], q, False, kernel=name, jitter=1e-6, route="inv")
     assert relerr(means[s, sl], m_ref) < 1e-8
     assert relerr(draws[s][:, sl], ref.mvn_sample(m_ref, c_ref, eps[s][:, sl])) < 1e-6
+
+
+def test_serialised_trailing_updates_give_the_same_bits(engine):
+    """gpx_debug_set_serialise_trailing (bench.py's live `serialised_frac`): the trailing updates of the blocked Cholesky
+    (gp.py:160-164) run alone on the chip instead of beside the panel chain — a change of overlap only, so the
+    factorisation, its lml and the posterior are the same bits, and the same launches are counted."""
+    from gpax_amd import _lib
+    N, d = 6400, 2  # 50 tile rows: blocked (two streams, trailing class launches), not a multiple of the outer block
+    X, y, Xn, p = bench_inputs.synthetic_problem(N, d, 64, seed=3)
+    engine.set_train(X)
+
+    def run():
+        engine.profile_enable(True)
+        engine.profile_reset()
+        lml, info = engine.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+        n, ms, flops = engine.profile_read(_lib.PROF_GEMM_TRAILING)
+        engine.profile_enable(False)
+        mean, cov, _ = engine.posterior(Xn, p["noise"], 1e-6, want_cov=True, want_var=False)
+        return lml, info, n, flops, mean, cov
+
+    a = run()
+    engine.set_serialise_trailing(True)
+    try:
+        b = run()
+    finally:
+        engine.set_serialise_trailing(False)
+    c = run()
+    assert a[1] == 0 and a[2] > 0
+    for other in (b, c):
+        assert other[0] == a[0] and other[1] == 0 and other[2] == a[2] and other[3] == a[3]
+        np.testing.assert_array_equal(other[4], a[4])
+        np.testing.assert_array_equal(other[5], a[5])

@@ -128,6 +128,33 @@ def test_sparse_posterior_tends_to_exact_when_inducing_equals_train():
     np.testing.assert_allclose(c_s, c_e, rtol=1e-3, atol=1e-4)
 
 
+def test_sparse_bound_tends_to_the_exact_log_likelihood_when_inducing_equals_train():
+    """The analytic tie that carries the exact leg's pin to the sparse leg (sparse_gp.py:92-114): with
+    Xu = X, Qff = Kfu Kuu^-1 Kuf -> Kff, so the trace term -> 0 and LowRankMVN(W W^T + noise I) -> MVN(Kff + noise I): the
+    VFE bound becomes the exact log marginal likelihood — and THAT function (exactgp_log_likelihood) is pinned to
+    reference-printed output (tests/test_reference_notebook_pins.py).  The bound is a lower bound for every inducing set
+    and grows towards the exact value as the set grows towards X."""
+    X, y, _, p = bench_inputs.synthetic_problem(60, 1, 3, seed=1)
+    order = np.random.default_rng(0).permutation(60)
+    for name in ("RBF", "Matern"):
+        # Xu = X: the reference's calls as they stand (sparse_gp.py:94-100) give Kuu = Kuf = Kff + jitter I (Kuf is built with
+        # the kernel's DEFAULT jitter and X.shape == Xu.shape puts it on the diagonal, kernels.py:63), so Qff = Kff + jitter I
+        # exactly, the trace term is -N jitter / noise -> clipped to 0, and the low-rank covariance is Kff + (noise + jitter) I:
+        # ExactGP.model's covariance at the same jitter (gp.py:160-164)
+        exact = ref.exactgp_log_likelihood(X, y, p, kernel=name, jitter=1e-6)
+        full = ref.sparse_bound(X, y, X.copy(), p, kernel=name, jitter=1e-6)
+        assert abs(full - exact) <= 1e-7 * abs(exact), (name, full, exact)
+        # nested inducing sets: a lower bound of the exact value (no jitter on Kff there: sparse_gp.py:100) that grows with
+        # the set (Titsias 2009); jitter 1e-6 on Kuu loosens both statements by O(m jitter / noise)
+        exact0 = ref.exactgp_log_likelihood(X, y, p, kernel=name, jitter=0.0)
+        prev = -np.inf
+        for m in (6, 12, 24, 48):
+            b = ref.sparse_bound(X, y, X[order[:m]], p, kernel=name, jitter=1e-6)
+            assert prev - 1e-3 <= b <= exact0 + 1e-3, (name, m, b, prev, exact0)
+            prev = b
+        assert prev > exact0 - 0.05 * abs(exact0)
+
+
 def test_golden_fixtures_match_oracle():
     g = load("gram")
     for c in range(int(g["ncases"])):
