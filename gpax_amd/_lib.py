@@ -93,6 +93,7 @@ def load_library() -> C.CDLL:
         "gpx_node_destroy": (None, [vp]),
         "gpx_node_last_error": (C.c_char_p, [vp]),
         "gpx_node_info": (C.c_int, [vp, _ip, _ip, _ip, _ip]),
+        "gpx_node_last_shares": (C.c_int, [vp, _ip, C.c_int]),
         "gpx_predict_sweep_multi": (C.c_int, [vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
                                               _dp, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, _dp, _ip, _dp,
                                               C.c_int]),
@@ -104,6 +105,8 @@ def load_library() -> C.CDLL:
         "gpx_rank_device_pci": (C.c_int, [vp, _ip, _ip, _ip]),
         "gpx_rank_collective_calls": (C.c_int64, [vp]),
         "gpx_rank_barrier": (C.c_int, [vp]),
+        "gpx_rank_calibrate": (C.c_int, [vp, _dp]),
+        "gpx_shard_ranges_weighted": (C.c_int, [C.c_int, _dp, C.c_int, _ip, _ip]),
         "gpx_rank_allreduce_max": (C.c_int, [vp, _dp, C.c_int]),
         "gpx_rank_bcast": (C.c_int, [vp, _dp, C.c_int64]),
         "gpx_rank_predict_sweep": (C.c_int, [vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
@@ -124,8 +127,8 @@ EXPORTED_SYMBOLS = (
     "gpx_factor gpx_lml_grad gpx_lml_grad_diag gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
     "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_set_potf2 gpx_debug_set_lat_gemm gpx_debug_set_serialise_trailing gpx_debug_gemm_time gpx_debug_tile_list gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
-    "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_predict_sweep_multi "
-    "gpx_rank_unique_id gpx_rank_init gpx_rank_destroy gpx_rank_last_error gpx_rank_info gpx_rank_device_pci gpx_rank_collective_calls gpx_rank_barrier "
+    "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_node_last_shares gpx_predict_sweep_multi "
+    "gpx_rank_unique_id gpx_rank_init gpx_rank_destroy gpx_rank_last_error gpx_rank_info gpx_rank_device_pci gpx_rank_collective_calls gpx_rank_barrier gpx_rank_calibrate gpx_shard_ranges_weighted "
     "gpx_rank_allreduce_max gpx_rank_bcast gpx_rank_predict_sweep gpx_shard_range"
 ).split()
 
@@ -550,6 +553,12 @@ class Node:
         return {"ngpu": g.value, "inflight": f.value, "transport": "rccl" if t.value else "memcpy",
                 "rccl_version": v.value}
 
+    def last_shares(self) -> list:
+        """Samples every GPU worked off in the last predict_sweep (the deal is dynamic: gpx_node_last_shares)."""
+        arr = (C.c_int * len(self.devices))()
+        g = self._lib.gpx_node_last_shares(self._node, arr, len(self.devices))
+        return [int(arr[i]) for i in range(max(g, 0))]
+
     def predict_sweep(self, X, kind: int, ells, scales, noises, yres, Xnew, noiseless: bool, jitter: float,
                       eps: Optional[np.ndarray], want_var: bool = False, m_slice: int = 0):
         X = _f64(X)
@@ -583,6 +592,17 @@ class Node:
 
 
 UNIQUE_ID_BYTES = 128
+
+
+def shard_ranges_weighted(S: int, weights) -> list:
+    """All blocks [(lo, hi), ...] over S samples with sizes in proportion to `weights` (gpx_shard_ranges_weighted; host
+    only, needs no GPU) — the blocks the ranks of a calibrated sweep work off."""
+    w = _f64(weights).reshape(-1)
+    parts = int(w.size)
+    lo, hi = (C.c_int * parts)(), (C.c_int * parts)()
+    if load_library().gpx_shard_ranges_weighted(int(S), _ptr(w), parts, lo, hi) != 0:
+        raise ValueError(f"shard_ranges_weighted({S}, {weights})")
+    return [(int(lo[r]), int(hi[r])) for r in range(parts)]
 
 
 def shard_range(S: int, part: int, parts: int) -> Tuple[int, int]:
@@ -676,6 +696,13 @@ class Rank:
 
     def barrier(self):
         self._check(self._lib.gpx_rank_barrier(self._rk), "gpx_rank_barrier")
+
+    def calibrate(self) -> np.ndarray:
+        """Collective: every rank probes its GPU, the rates are exchanged, and the blocks of the following sweeps are sized
+        in proportion (gpx_rank_calibrate).  Returns the relative speeds (mean 1, clamped to [0.85, 1.15])."""
+        v = np.ones(self.nranks)
+        self._check(self._lib.gpx_rank_calibrate(self._rk, _ptr(v)), "gpx_rank_calibrate")
+        return v
 
     def allreduce_max(self, values) -> np.ndarray:
         v = _f64(values).reshape(-1).copy()

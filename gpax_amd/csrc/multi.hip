@@ -7,9 +7,9 @@
 //
 //   root GPU   : one H2D upload of [X | X_new | y_res | eps] (page-locked staging)
 //   RCCL / xGMI: ncclBroadcast of that payload to every GPU of the node            (KBs .. a few MB)
-//   every GPU  : its contiguous block of the S samples through the batched device pipeline (sweep_core, api.hip),
-//                split again over the contexts in flight on that GPU; one host thread per context
-//   RCCL / xGMI: ncclSend / ncclRecv (one group) of every GPU's [means | draws | vars | pivots] block to the root
+//   every GPU  : chunks of the S samples, taken from ONE cursor all contexts of all GPUs share (dealt as they go, in whole
+//                launch batches), through the batched device pipeline (sweep_core, api.hip); one host thread per context
+//   RCCL / xGMI: ncclSend / ncclRecv (one group) of every GPU's means | draws | vars | pivots to the root
 //   root GPU   : one D2H download
 // No collective sits inside the sweep.  The theta tables stay on the host: every context builds the device table of
 // its own samples from them (they are host data of this very process).
@@ -32,7 +32,8 @@ struct NodeDev {
   std::vector<gpx_ctx*> ctxs; // contexts in flight on this GPU
   hipStream_t cs = nullptr;   // communication / staging stream
   DevBuf payload;             // [X | X_new | y_res | eps] as broadcast
-  DevBuf out;                 // this GPU's result block (the root's holds every block: the gather target)
+  DevBuf out;                 // this GPU's result block, laid out for all S samples (it holds those it took, in taking order)
+  DevBuf gather;              // root only: every GPU's block, compacted — the gather target
 };
 
 } // namespace
@@ -46,6 +47,8 @@ struct gpx_node {
   std::string err;
   PinBuf pin_in, pin_out;
   int64_t sweeps = 0;
+  std::vector<int> shares;        // samples every GPU worked off in the last sweep (gpx_node_last_shares)
+  int slow_gpu = -1, slow_us = 0; // tests: GPX_NODE_SLOW="<gpu index>:<microseconds>" — that GPU's contexts sleep after every chunk
 };
 
 namespace {
@@ -87,6 +90,13 @@ int gpx_node_init(int ngpu, const int* devices, int inflight, gpx_node** out) {
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return node_fail(nd, "no HIP device available");
   const char* tr = getenv("GPX_NODE_TRANSPORT");
   nd->use_rccl = !(tr && std::string(tr) == "memcpy");
+  if (const char* sl = getenv("GPX_NODE_SLOW")) {
+    int gi = -1, us = 0;
+    if (sscanf(sl, "%d:%d", &gi, &us) == 2 && gi >= 0 && us > 0) {
+      nd->slow_gpu = gi;
+      nd->slow_us = us;
+    }
+  }
   nd->devs.resize((size_t)ngpu);
   std::vector<int> devlist((size_t)ngpu);
   for (int r = 0; r < ngpu; ++r) {
@@ -143,6 +153,7 @@ void gpx_node_destroy(gpx_node* nd) {
     for (gpx_ctx* c : D.ctxs) gpx_destroy(c);
     D.payload.release();
     D.out.release();
+    D.gather.release();
     if (D.cs) (void)hipStreamDestroy(D.cs);
   }
   nd->pin_in.release();
@@ -159,6 +170,12 @@ int gpx_node_info(const gpx_node* nd, int* ngpu, int* inflight, int* transport_r
   if (transport_rccl) *transport_rccl = nd->use_rccl ? 1 : 0;
   if (rccl_version) *rccl_version = nd->rccl_version;
   return 0;
+}
+
+int gpx_node_last_shares(const gpx_node* nd, int* counts, int cap) {
+  if (!nd || cap < 0 || (cap > 0 && !counts)) return -1;
+  for (size_t r = 0; r < nd->shares.size() && (int)r < cap; ++r) counts[r] = nd->shares[r];
+  return (int)nd->shares.size();
 }
 
 int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int d, int S, const double* ells,
@@ -218,18 +235,18 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
   NODE_HIP(nd, hipSetDevice(root.device));
   NODE_HIP(nd, hipStreamSynchronize(root.cs));
 
-  // ---- 2. every GPU sweeps its block of samples; contexts in flight split it again -------------------------------
-  std::vector<int> lo((size_t)G), hi((size_t)G);
-  std::vector<int64_t> boff((size_t)G + 1, 0); // block offsets (doubles) inside the root's gather buffer
-  for (int r = 0; r < G; ++r) {
-    shard_range(S, r, G, &lo[(size_t)r], &hi[(size_t)r]);
-    boff[(size_t)r + 1] = boff[(size_t)r] + BlockLayout(hi[(size_t)r] - lo[(size_t)r], n, M).total;
-  }
+  // ---- 2. the samples are DEALT to the GPUs as they go: one cursor over all S (rccl_bind.h ShardCursor: guided
+  // self-scheduling in whole launch batches) that every context of every GPU takes its chunks from — this process owns
+  // them all, so a shared cursor costs one mutex.  (Static contiguous blocks per GPU, rounds 1 - 5: GPUs of one node differ
+  // by a few per cent in sustained clocks — the builder's boxes spread +-4 % — and the slowest one set the time of the
+  // sweep.)  A sample's values do not depend on the batch it rides in, so the deal never changes a result bit.  Every
+  // GPU fills its result block in the order its contexts take chunks (ChunkLog) — laid out for S samples, the most one
+  // GPU can end up with.
+  const BlockLayout capL(S, n, M);
   for (int r = 0; r < G; ++r) {
     NodeDev& D = nd->devs[(size_t)r];
     NODE_HIP(nd, hipSetDevice(D.device));
-    const int64_t need = (r == 0) ? boff[(size_t)G] : BlockLayout(hi[(size_t)r] - lo[(size_t)r], n, M).total;
-    NODE_HIP(nd, D.out.ensure((size_t)(need > 0 ? need : 1) * sizeof(double)));
+    NODE_HIP(nd, D.out.ensure((size_t)capL.total * sizeof(double)));
   }
   // below N ~ 3000 one context's batched sweep already fills a GPU: one context per GPU there
   const int per_gpu = (N < 3000) ? 1 : (int)root.ctxs.size();
@@ -237,31 +254,69 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
   std::vector<std::thread> threads;
   std::vector<int> rcs((size_t)G * per_gpu, 0);
   std::vector<int> cblock((size_t)G * per_gpu, M);
+  std::vector<ChunkLog> logs((size_t)G);
+  auto cur = std::make_shared<ShardCursor>();
+  cur->total = S;
+  cur->parts = G * per_gpu;
   for (int r = 0; r < G; ++r) {
     NodeDev& D = nd->devs[(size_t)r];
-    // block r starts at offset 0 of its own buffer (the root's block is block 0 of the gather buffer)
-    spawn_shard_sweep(threads, D.ctxs, per_gpu, lo[(size_t)r], hi[(size_t)r] - lo[(size_t)r], jb, pl, D.payload.d(),
-                      D.out.d(), &rcs[(size_t)r * per_gpu], &cblock[(size_t)r * per_gpu]);
+    spawn_shard_sweep(threads, D.ctxs, per_gpu, 0, S, jb, pl, D.payload.d(), D.out.d(), &rcs[(size_t)r * per_gpu],
+                      &cblock[(size_t)r * per_gpu], cur, &logs[(size_t)r], S, r == nd->slow_gpu ? nd->slow_us : 0);
   }
   for (std::thread& t : threads) t.join();
+  int cM = M; // covariance block of the sweep (the same on every context that did work; idle ones still say M)
   for (int r = 0; r < G; ++r)
-    for (int c = 0; c < per_gpu; ++c)
+    for (int c = 0; c < per_gpu; ++c) {
       if (rcs[(size_t)r * per_gpu + c] != 0) {
         nd->err = std::string("sweep failed on device ") + std::to_string(nd->devs[(size_t)r].device) + ": " +
                   gpx_last_error(nd->devs[(size_t)r].ctxs[(size_t)c]);
         return rcs[(size_t)r * per_gpu + c];
       }
+      if (cblock[(size_t)r * per_gpu + c] < cM) cM = cblock[(size_t)r * per_gpu + c];
+    }
+  nd->shares.assign((size_t)G, 0);
+  std::vector<int64_t> boff((size_t)G + 1, 0); // block offsets (doubles) inside the root's gather buffer
+  for (int r = 0; r < G; ++r) {
+    nd->shares[(size_t)r] = logs[(size_t)r].placed;
+    boff[(size_t)r + 1] = boff[(size_t)r] + BlockLayout(logs[(size_t)r].placed, n, M).total;
+  }
 
-  // ---- 3. gather every block on the root GPU (one RCCL group), one download ---------------------------------------
+  // ---- 3. gather on the root GPU: every GPU's block, compacted to the samples it holds (one RCCL group, up to four
+  // segments per GPU: means | draws | vars | pivots), one download --------------------------------------------------
+  NODE_HIP(nd, hipSetDevice(root.device));
+  NODE_HIP(nd, root.gather.ensure((size_t)(boff[(size_t)G] > 0 ? boff[(size_t)G] : 1) * sizeof(double)));
+  struct Seg {
+    int64_t src, dst, cnt;
+  };
+  auto segments = [&](int r, Seg* sg) -> int {
+    const int c = logs[(size_t)r].placed;
+    if (c <= 0) return 0;
+    const BlockLayout bl(c, n, M);
+    int k = 0;
+    sg[k++] = Seg{capL.means, boff[(size_t)r] + bl.means, (int64_t)c * M};
+    if (n > 0) sg[k++] = Seg{capL.draws, boff[(size_t)r] + bl.draws, (int64_t)c * n * M};
+    if (vars) sg[k++] = Seg{capL.vars, boff[(size_t)r] + bl.vars, (int64_t)c * M};
+    sg[k++] = Seg{capL.infos, boff[(size_t)r] + bl.infos, (int64_t)c};
+    return k;
+  };
+  Seg sg[4];
+  { // the root's own block: device-to-device on its staging stream
+    const int k = segments(0, sg);
+    for (int i = 0; i < k; ++i)
+      NODE_HIP(nd, hipMemcpyAsync(root.gather.d() + sg[i].dst, root.out.d() + sg[i].src, (size_t)sg[i].cnt * sizeof(double),
+                                  hipMemcpyDeviceToDevice, root.cs));
+  }
   if (nd->use_rccl) {
     ncclResult_t first = ncclSuccess;
     NODE_NCCL(nd, nd->rccl.GroupStart());
     for (int r = 1; r < G && first == ncclSuccess; ++r) {
-      const int64_t cnt = boff[(size_t)r + 1] - boff[(size_t)r];
-      if (cnt <= 0) continue;
       NodeDev& D = nd->devs[(size_t)r];
-      first = nd->rccl.Recv(root.out.d() + boff[(size_t)r], (size_t)cnt, ncclDouble, r, nd->comms[0], root.cs);
-      if (first == ncclSuccess) first = nd->rccl.Send(D.out.p, (size_t)cnt, ncclDouble, 0, nd->comms[(size_t)r], D.cs);
+      const int k = segments(r, sg);
+      for (int i = 0; i < k && first == ncclSuccess; ++i) {
+        first = nd->rccl.Recv(root.gather.d() + sg[i].dst, (size_t)sg[i].cnt, ncclDouble, r, nd->comms[0], root.cs);
+        if (first == ncclSuccess)
+          first = nd->rccl.Send(D.out.d() + sg[i].src, (size_t)sg[i].cnt, ncclDouble, 0, nd->comms[(size_t)r], D.cs);
+      }
     }
     const ncclResult_t ge = nd->rccl.GroupEnd();
     if (first == ncclSuccess) first = ge;
@@ -272,23 +327,22 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
     }
   } else {
     for (int r = 1; r < G; ++r) {
-      const int64_t cnt = boff[(size_t)r + 1] - boff[(size_t)r];
-      if (cnt <= 0) continue;
       NodeDev& D = nd->devs[(size_t)r];
-      NODE_HIP(nd, hipMemcpyPeerAsync(root.out.d() + boff[(size_t)r], root.device, D.out.p, D.device,
-                                      (size_t)cnt * sizeof(double), root.cs));
+      const int k = segments(r, sg);
+      for (int i = 0; i < k; ++i)
+        NODE_HIP(nd, hipMemcpyPeerAsync(root.gather.d() + sg[i].dst, root.device, D.out.d() + sg[i].src, D.device,
+                                        (size_t)sg[i].cnt * sizeof(double), root.cs));
     }
   }
   NODE_HIP(nd, hipSetDevice(root.device));
   const size_t o_bytes = (size_t)boff[(size_t)G] * sizeof(double);
   NODE_HIP(nd, nd->pin_out.ensure(o_bytes));
-  NODE_HIP(nd, hipMemcpyAsync(nd->pin_out.p, root.out.p, o_bytes, hipMemcpyDeviceToHost, root.cs));
+  NODE_HIP(nd, hipMemcpyAsync(nd->pin_out.p, root.gather.p, o_bytes, hipMemcpyDeviceToHost, root.cs));
   NODE_HIP(nd, hipStreamSynchronize(root.cs));
   const double* ho = nd->pin_out.d();
   for (int r = 0; r < G; ++r)
-    if (hi[(size_t)r] > lo[(size_t)r])
-      scatter_block(ho + boff[(size_t)r], hi[(size_t)r] - lo[(size_t)r], lo[(size_t)r], N, M, n, cblock[0], means, samples,
-                    infos, vars);
+    for (const std::array<int, 3>& ch : logs[(size_t)r].chunks) // (first global sample, count, position in the block)
+      scatter_chunk(ho + boff[(size_t)r], logs[(size_t)r].placed, ch[2], ch[1], ch[0], N, M, n, cM, means, samples, infos, vars);
   nd->sweeps += 1;
   return 0;
 }

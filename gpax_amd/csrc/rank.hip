@@ -10,8 +10,9 @@
 //
 //   rank 0     : one H2D upload of [X | X_new | y_res | eps | theta table]            (page-locked staging)
 //   RCCL / xGMI: ncclBroadcast of that payload                                         (KBs .. a few MB)
-//   every rank : its contiguous block of the S samples through the batched device pipeline (sweep_core, api.hip),
-//                split again over the contexts in flight on its GPU, one host thread per context
+//   every rank : its contiguous block of the S samples — sized by its GPU's measured speed once the ranks have calibrated
+//                (gpx_rank_calibrate) — through the batched device pipeline (sweep_core, api.hip), dealt to the
+//                contexts in flight on its GPU as they go, one host thread per context
 //   RCCL / xGMI: ncclSend of the [means | draws | vars | pivots] block to rank 0, ncclRecv there (one group)
 //   rank 0     : one D2H download
 // No collective sits inside the sweep.  gpx_rank_barrier / gpx_rank_allreduce_max (ncclAllReduce of a few doubles)
@@ -54,6 +55,8 @@ struct gpx_rank {
   // use and group nesting are all exercised (NCCL_DEBUG=INFO log: profiles/r04/rank1_rccl_nccl_debug.log).
   bool force_coll = false;
   int64_t coll_calls = 0; // RCCL collective / p2p calls issued so far
+  // relative speed of every rank's GPU (gpx_rank_calibrate; empty: equal blocks) — what sizes the ranks' blocks of a sweep
+  std::vector<double> speeds;
 };
 
 namespace {
@@ -300,6 +303,61 @@ int gpx_rank_allreduce_max(gpx_rank* rk, double* v, int n) {
   return allreduce_max(rk, v, n);
 }
 
+int gpx_shard_ranges_weighted(int S, const double* weights, int parts, int* lo, int* hi) {
+  if (S < 0 || parts < 1 || !lo || !hi) return -1;
+  shard_ranges_weighted(S, weights, parts, lo, hi);
+  return 0;
+}
+
+// Collective.  The ranks of a sweep work off STATIC contiguous blocks (processes share no cursor), so a block's size should
+// follow its GPU's speed: GPUs of one node differ by a few per cent in sustained clocks (+-4 % over the builder's boxes),
+// and with equal blocks the slowest of eight sets the time of the sweep.  Every rank times a probe on its own GPU — the
+// Cholesky trailing-update form of the fp64 MFMA GEMM (C -= A B^T, 32 x 32 tiles of 128, K = 2048: 69 GFLOP, about a
+// millisecond) on resident scratch operands, best of three averages over ten launches — and the rates are exchanged with one
+// all-reduce (a vector with the own slot set, zeros elsewhere, maximum over ranks).  Rates are taken relative to their mean
+// and clamped to [0.85, 1.15]: a probe that caught a GPU mid clock ramp must not starve it.
+int gpx_rank_calibrate(gpx_rank* rk, double* speeds) {
+  if (!rk || rk->device < 0) return -1;
+  if (rk->nranks > 64) return rank_bad_arg(rk, "gpx_rank_calibrate: at most 64 ranks");
+  double best = 1e300;
+  for (int t = 0; t < 3; ++t) {
+    double ms = 0.0;
+    const int rc = gpx_debug_gemm_time(rk->ctxs[0], 32, 32, 2048, 1, 0, 2, 10, &ms);
+    if (rc != 0) {
+      best = -1.0; // this rank cannot say: every rank falls back to equal blocks (the exchange below still runs)
+      break;
+    }
+    if (ms < best) best = ms;
+  }
+  double mine = best > 0.0 ? 1.0 / best : 0.0;
+  if (const char* e = getenv("GPX_RANK_SPEED_SCALE")) { // tests: an artificially slow / fast rank
+    const double f = atof(e);
+    if (f > 0.0) mine *= f;
+  }
+  double v[64];
+  for (int r = 0; r < rk->nranks; ++r) v[r] = (r == rk->rank) ? mine : 0.0;
+  RANK_TRY(allreduce_max(rk, v, rk->nranks));
+  double sum = 0.0;
+  bool ok = true;
+  for (int r = 0; r < rk->nranks; ++r) {
+    if (!(v[r] > 0.0)) ok = false;
+    sum += v[r];
+  }
+  rk->speeds.clear();
+  if (ok) {
+    const double mean = sum / rk->nranks;
+    for (int r = 0; r < rk->nranks; ++r) {
+      double s = v[r] / mean;
+      if (s < 0.85) s = 0.85;
+      if (s > 1.15) s = 1.15;
+      rk->speeds.push_back(s);
+    }
+  }
+  if (speeds)
+    for (int r = 0; r < rk->nranks; ++r) speeds[r] = ok ? rk->speeds[(size_t)r] : 1.0;
+  return 0;
+}
+
 int gpx_rank_barrier(gpx_rank* rk) {
   if (!rk) return -1;
   // everything this rank has queued on its own contexts is done before it reports in
@@ -387,10 +445,10 @@ int gpx_rank_predict_sweep(gpx_rank* rk, int kind, const double* X, int N, int d
   // ---- 2. this rank's block of samples; contexts in flight split it again ------------------------------------------
   std::vector<int> lo((size_t)G), hi((size_t)G);
   std::vector<int64_t> boff((size_t)G + 1, 0); // block offsets (doubles) inside rank 0's gather buffer
-  for (int r = 0; r < G; ++r) {
-    shard_range(S, r, G, &lo[(size_t)r], &hi[(size_t)r]);
-    boff[(size_t)r + 1] = boff[(size_t)r] + BlockLayout(hi[(size_t)r] - lo[(size_t)r], n, M).total;
-  }
+  // blocks in proportion to the GPUs' measured speeds when the ranks have calibrated (gpx_rank_calibrate: every rank holds
+  // the same vector), equal blocks otherwise
+  shard_ranges_weighted(S, (int)rk->speeds.size() == G ? rk->speeds.data() : nullptr, G, lo.data(), hi.data());
+  for (int r = 0; r < G; ++r) boff[(size_t)r + 1] = boff[(size_t)r] + BlockLayout(hi[(size_t)r] - lo[(size_t)r], n, M).total;
   const int c_me = hi[(size_t)rk->rank] - lo[(size_t)rk->rank];
   const int64_t my_total = BlockLayout(c_me, n, M).total;
   // (forced collectives with one rank: room for a copy of the block behind it — the receive side of the self send)

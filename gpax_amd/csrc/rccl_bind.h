@@ -12,6 +12,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -101,6 +102,43 @@ inline void shard_range(int S, int r, int parts, int* lo, int* hi) {
   *hi = *lo + base + (r < rem ? 1 : 0);
 }
 
+// contiguous blocks [lo[r], hi[r]) over S items with sizes in proportion to the weights w[r] > 0 (largest-remainder rounding,
+// ties to the lower part): the same on every process that holds the same weights.  w == nullptr: shard_range.
+inline void shard_ranges_weighted(int S, const double* w, int parts, int* lo, int* hi) {
+  std::vector<int> cnt((size_t)parts, 0);
+  double sum = 0.0;
+  bool ok = w != nullptr;
+  for (int r = 0; ok && r < parts; ++r) {
+    if (!(w[r] > 0.0) || !(w[r] < 1e300)) ok = false;
+    else sum += w[r];
+  }
+  if (!ok) {
+    for (int r = 0; r < parts; ++r) shard_range(S, r, parts, lo + r, hi + r);
+    return;
+  }
+  std::vector<double> frac((size_t)parts);
+  int given = 0;
+  for (int r = 0; r < parts; ++r) {
+    const double share = (double)S * (w[r] / sum);
+    cnt[(size_t)r] = (int)share;
+    frac[(size_t)r] = share - cnt[(size_t)r];
+    given += cnt[(size_t)r];
+  }
+  for (; given < S; ++given) {
+    int best = 0;
+    for (int r = 1; r < parts; ++r)
+      if (frac[(size_t)r] > frac[(size_t)best]) best = r;
+    cnt[(size_t)best] += 1;
+    frac[(size_t)best] = -1.0;
+  }
+  int at = 0;
+  for (int r = 0; r < parts; ++r) {
+    lo[r] = at;
+    at += cnt[(size_t)r];
+    hi[r] = at;
+  }
+}
+
 // result block of c samples, in doubles: [means c*M | draws c*n*M | vars c*M | pivots: 2c ints in c doubles]
 struct BlockLayout {
   int64_t means, draws, vars, infos, total;
@@ -129,17 +167,18 @@ struct PayloadLayout {
   }
 };
 
-// Copy one gathered block (host image `blk` of c_r samples whose first global index is g0) into the caller's arrays,
-// decoding the pivots exactly as gpx_predict_sweep does: train-factor failure -> means / vars / draws NaN, covariance
-// failure -> draws NaN, infos = pivot (train) or -pivot (cov).
-inline void scatter_block(const double* blk, int c_r, int g0, int N, int M, int n, int cM, double* means, double* samples,
-                          int* infos, double* vars) {
-  const BlockLayout bl(c_r, n, M);
-  std::memcpy(means + (int64_t)g0 * M, blk + bl.means, (size_t)c_r * M * sizeof(double));
-  if (n > 0) std::memcpy(samples + (int64_t)g0 * n * M, blk + bl.draws, (size_t)c_r * n * M * sizeof(double));
-  if (vars) std::memcpy(vars + (int64_t)g0 * M, blk + bl.vars, (size_t)c_r * M * sizeof(double));
-  const int* hin = reinterpret_cast<const int*>(blk + bl.infos);
-  for (int s = 0; s < c_r; ++s) {
+// Copy `cnt` samples of a gathered block (host image `blk`, laid out for `cap` samples) from position `pos` of the block
+// to global samples g0 .. g0 + cnt - 1 of the caller's arrays, decoding the pivots exactly as gpx_predict_sweep does:
+// train-factor failure -> means / vars / draws NaN, covariance failure -> draws NaN, infos = pivot (train) or -pivot (cov).
+inline void scatter_chunk(const double* blk, int cap, int pos, int cnt, int g0, int N, int M, int n, int cM, double* means,
+                          double* samples, int* infos, double* vars) {
+  const BlockLayout bl(cap, n, M);
+  std::memcpy(means + (int64_t)g0 * M, blk + bl.means + (int64_t)pos * M, (size_t)cnt * M * sizeof(double));
+  if (n > 0)
+    std::memcpy(samples + (int64_t)g0 * n * M, blk + bl.draws + (int64_t)pos * n * M, (size_t)cnt * n * M * sizeof(double));
+  if (vars) std::memcpy(vars + (int64_t)g0 * M, blk + bl.vars + (int64_t)pos * M, (size_t)cnt * M * sizeof(double));
+  const int* hin = reinterpret_cast<const int*>(blk + bl.infos) + 2 * (int64_t)pos;
+  for (int s = 0; s < cnt; ++s) {
     int it = hin[2 * s], ic = hin[2 * s + 1];
     if (it > N) it = 0;
     if (ic > cM) ic = 0;
@@ -156,8 +195,16 @@ inline void scatter_block(const double* blk, int c_r, int g0, int N, int M, int 
   }
 }
 
+// a whole block of c_r consecutive samples starting at global sample g0
+inline void scatter_block(const double* blk, int c_r, int g0, int N, int M, int n, int cM, double* means, double* samples,
+                          int* infos, double* vars) {
+  scatter_chunk(blk, c_r, 0, c_r, g0, N, M, n, cM, means, samples, infos, vars);
+}
+
 } // namespace gpx
 
+#include <array>
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -207,15 +254,32 @@ struct ShardCursor {
   }
 };
 
+// Where ONE GPU put the chunks it took from a cursor it shares with other GPUs (the node model, multi.hip): a GPU's result
+// block is filled in the order its contexts take chunks, and the root scatters by this list.
+struct ChunkLog {
+  std::mutex mu;
+  int placed = 0;                         // samples placed so far = next free position in this GPU's block
+  std::vector<std::array<int, 3>> chunks; // (first global sample, count, position in the block)
+};
+
+// cur == nullptr: the block [g_lo, g_lo + c_r) belongs to this GPU alone (the rank model: static blocks per rank); a
+// cursor of its own deals it to the contexts and sample g_lo + i sits at position i of `blk` (laid out for c_r samples).
+// cur != nullptr (the node model): the cursor runs over c_r samples starting at g_lo that SEVERAL GPUs work off; `blk` is
+// laid out for `cap` samples, this GPU's chunks are placed one behind the other and recorded in `log`.
+// slow_us > 0 (tests: GPX_NODE_SLOW): every context of this GPU sleeps that long after each chunk — an artificially slow GPU.
 inline void spawn_shard_sweep(std::vector<std::thread>& threads, const std::vector<gpx_ctx*>& ctxs, int per_gpu, int g_lo,
                               int c_r, const ShardJob& jb, const PayloadLayout& pl, const double* payload, double* blk,
-                              int* rc_slots, int* cb_slots) {
+                              int* rc_slots, int* cb_slots, std::shared_ptr<ShardCursor> cur = nullptr,
+                              ChunkLog* log = nullptr, int cap = 0, int slow_us = 0) {
   if (c_r <= 0) return;
-  const BlockLayout bl(c_r, jb.n, jb.M);
-  const int parts = per_gpu < c_r ? per_gpu : c_r;
-  auto cur = std::make_shared<ShardCursor>();
-  cur->total = c_r;
-  cur->parts = parts;
+  const bool shared = cur != nullptr;
+  const BlockLayout bl(shared ? cap : c_r, jb.n, jb.M);
+  const int parts = shared ? per_gpu : (per_gpu < c_r ? per_gpu : c_r);
+  if (!shared) {
+    cur = std::make_shared<ShardCursor>();
+    cur->total = c_r;
+    cur->parts = parts;
+  }
   for (int c = 0; c < parts; ++c) {
     gpx_ctx* ctx = ctxs[(size_t)c];
     int* rc_slot = rc_slots + c;
@@ -229,17 +293,25 @@ inline void spawn_shard_sweep(std::vector<std::thread>& threads, const std::vect
       while (rc == 0 && cur->take(&slo, &shi)) {
         const int g0 = g_lo + slo; // first global sample of this chunk
         const int cnt = shi - slo;
+        int pos = slo;
+        if (log) {
+          std::lock_guard<std::mutex> g(log->mu);
+          pos = log->placed;
+          log->placed += cnt;
+          log->chunks.push_back({g0, cnt, pos});
+        }
         rc = sweep_device_io(
             ctx, j.kind, cnt, j.ells + (int64_t)g0 * j.ne, j.scales + g0, j.noises + g0, payload + p.X, j.N, j.d,
             payload + p.y + (j.yres_rows == 1 ? 0 : (int64_t)g0 * j.N), j.yres_rows == 1 ? 1 : cnt, payload + p.Xn, j.M,
             j.noiseless, j.jitter, j.n > 0 ? payload + p.eps + (int64_t)g0 * j.n * j.M : nullptr, j.n,
-            blk + bl.means + (int64_t)slo * j.M, j.n > 0 ? blk + bl.draws + (int64_t)slo * j.n * j.M : nullptr,
-            reinterpret_cast<int*>(blk + bl.infos) + 2 * slo, j.want_vars ? blk + bl.vars + (int64_t)slo * j.M : nullptr,
+            blk + bl.means + (int64_t)pos * j.M, j.n > 0 ? blk + bl.draws + (int64_t)pos * j.n * j.M : nullptr,
+            reinterpret_cast<int*>(blk + bl.infos) + 2 * pos, j.want_vars ? blk + bl.vars + (int64_t)pos * j.M : nullptr,
             j.m_slice);
         if (rc == 0) rc = gpx_synchronize(ctx);
         int last = 0;
         if (rc == 0 && gpx_sweep_stats(ctx, nullptr, nullptr, &last) == 0) cur->saw_batch(last);
         *cb_slot = ctx_cov_block(ctx);
+        if (slow_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(slow_us));
       }
       *rc_slot = rc;
     });

@@ -229,6 +229,10 @@ def init_rank(env: RankEnv, device: Optional[int] = None, inflight: Optional[int
             rk = make_rank(device, env.rank, env.world, None, xfer_dir, inflight)
             store.set(f"finit.{env.rank}", b"ok")
             store.gather("finit", env.world, timeout)
+        # the ranks of a sweep work off static blocks: size them by the GPUs' measured speeds (collective probe + one
+        # all-reduce, gpx_rank_calibrate; GPX_RANK_WEIGHTED=0: equal blocks)
+        if env.world > 1 and os.environ.get("GPX_RANK_WEIGHTED", "1") != "0" and hasattr(rk, "calibrate"):
+            rk.speeds = rk.calibrate()
         return rk
     finally:
         done.set()

@@ -190,10 +190,10 @@ int gpx_sgp_posterior(gpx_ctx* ctx, int kind, const double* ell, double scale, d
  * GPUs of ONE node from ONE process.  A gpx_node owns `inflight` contexts on each of `ngpu`
  * devices (devices == NULL: ordinals 0 .. ngpu-1) and one RCCL communicator per device (ncclCommInitAll; RCCL is
  * bound at run time with dlopen, libgpx does not link it).  gpx_predict_sweep_multi = gpx_predict_sweep (T = 1,
- * no pred_diag) with the S samples split in contiguous blocks over the GPUs:
+ * no pred_diag) with the S samples dealt to the GPUs as they go:
  *   root GPU <- one H2D of [X | X_new | y_res | eps];  ncclBroadcast of that payload over xGMI;
- *   every GPU sweeps its block (contexts in flight split it again, one host thread each);
- *   ncclSend / ncclRecv (one group) of the [means | draws | vars | pivots] blocks to the root;  one D2H.
+ *   every context of every GPU takes chunks (whole launch batches) from one shared cursor, one host thread each;
+ *   ncclSend / ncclRecv (one group) of every GPU's means | draws | vars | pivots to the root;  one D2H.
  * Results equal gpx_predict_sweep's sample by sample (same kernels, same per-sample arithmetic).
  * Environment: GPX_NODE_TRANSPORT=memcpy replaces the two RCCL steps by hipMemcpyPeerAsync (testing on a box
  * with one GPU listed twice, which RCCL refuses); never selected implicitly. */
@@ -203,6 +203,11 @@ void gpx_node_destroy(gpx_node* node);
 const char* gpx_node_last_error(const gpx_node* node);
 /* transport_rccl: 1 = RCCL, 0 = memcpy test transport; rccl_version as ncclGetVersion reports it (0 without RCCL) */
 int gpx_node_info(const gpx_node* node, int* ngpu, int* inflight, int* transport_rccl, int* rccl_version);
+/* Samples every GPU of the node worked off in the last gpx_predict_sweep_multi (counts[0 .. min(cap, ngpu))); returns ngpu
+ * (0 before the first sweep).  The samples are dealt to the GPUs as they go (one cursor shared by all contexts of all
+ * GPUs), so a slower GPU ends up with fewer.  Test hook: GPX_NODE_SLOW="<gpu index>:<microseconds>" at gpx_node_init makes
+ * the contexts of that GPU sleep after every chunk. */
+int gpx_node_last_shares(const gpx_node* node, int* counts, int cap);
 int gpx_predict_sweep_multi(gpx_node* node, int kind, const double* X, int N, int d, int S, const double* ells,
                             const double* scales, const double* noises, const double* yres, int yres_rows,
                             const double* Xnew, int M, int noiseless, double jitter, const double* eps, int n,
@@ -239,6 +244,12 @@ int gpx_rank_device_pci(const gpx_rank* rk, int* domain, int* bus, int* dev);
  * GPX_RANK_FORCE_COLLECTIVES=1 a communicator of ONE rank issues them too (diagnostic: the 1-GPU rehearsal of the path). */
 int64_t gpx_rank_collective_calls(const gpx_rank* rk);
 int gpx_rank_barrier(gpx_rank* rk);
+/* Collective.  Every rank times a probe on its own GPU (the trailing-update form of the fp64 MFMA GEMM on resident scratch
+ * operands) and the ranks exchange the rates (one all-reduce); from then on gpx_rank_predict_sweep sizes the ranks'
+ * contiguous blocks in proportion to them (gpx_shard_ranges_weighted; rates relative to their mean, clamped to
+ * [0.85, 1.15]).  speeds (nranks doubles, or NULL) receives them.  Without this call the blocks are equal (gpx_shard_range).
+ * Test hook: GPX_RANK_SPEED_SCALE=<factor> multiplies this rank's measured rate. */
+int gpx_rank_calibrate(gpx_rank* rk, double* speeds);
 int gpx_rank_allreduce_max(gpx_rank* rk, double* v, int n);
 int gpx_rank_bcast(gpx_rank* rk, double* buf, int64_t count);
 int gpx_rank_predict_sweep(gpx_rank* rk, int kind, const double* X, int N, int d, int S, const double* ells,
@@ -248,6 +259,9 @@ int gpx_rank_predict_sweep(gpx_rank* rk, int kind, const double* X, int N, int d
 /* Host only (no device call): the contiguous block [lo, hi) of part `part` out of `parts` over S samples that both
  * sharded sweeps use (sizes differ by at most one). */
 int gpx_shard_range(int S, int part, int parts, int* lo, int* hi);
+/* Host only: all `parts` blocks at once, sizes in proportion to weights[part] > 0 (largest-remainder rounding, ties to the
+ * lower part); weights == NULL or not all positive: the blocks of gpx_shard_range.  lo / hi: `parts` ints each. */
+int gpx_shard_ranges_weighted(int S, const double* weights, int parts, int* lo, int* hi);
 
 /* Sweep statistics since gpx_init: batches launched, samples processed, and the batch size B
  * chosen by the most recent sweep. */

@@ -276,3 +276,26 @@ def test_a_hung_initialisation_hands_control_to_the_callers_on_hang(tmp_path):
     assert launch.spawn_ranks(str(script), [str(tmp_path)], 2, timeout=120) == 0
     for r in range(2):
         assert "hung for 1 s" in (tmp_path / f"hang{r}").read_text()
+
+
+def test_weighted_shard_ranges_follow_the_weights_and_partition_exactly():
+    from gpax_amd import _lib
+    """gpx_shard_ranges_weighted (host only): the ranks' blocks of a calibrated sweep (gpx_rank_calibrate) — contiguous, every
+    sample once, sizes within one of S w / sum(w), equal weights = gpx_shard_range, bad weights fall back to it."""
+    rng = np.random.default_rng(0)
+    for S in (0, 1, 7, 40, 1000, 1001):
+        for parts in (1, 2, 3, 8):
+            eq = _lib.shard_ranges_weighted(S, np.ones(parts))
+            assert eq == [_lib.shard_range(S, r, parts) for r in range(parts)]
+            w = rng.uniform(0.85, 1.15, parts)
+            blocks = _lib.shard_ranges_weighted(S, w)
+            assert blocks[0][0] == 0 and blocks[-1][1] == S
+            assert all(blocks[r][1] == blocks[r + 1][0] for r in range(parts - 1))
+            for r, (lo, hi) in enumerate(blocks):
+                assert abs((hi - lo) - S * w[r] / w.sum()) < 1.0
+            bad = w.copy()
+            bad[0] = 0.0
+            assert _lib.shard_ranges_weighted(S, bad) == eq
+    # a GPU 8 % slower than seven equal ones gets the smaller block of C4's 1000 samples
+    sizes = [hi - lo for lo, hi in _lib.shard_ranges_weighted(1000, [1.0] * 7 + [0.92])]
+    assert sizes[-1] == min(sizes) and sizes[-1] in (116, 117) and sum(sizes) == 1000
