@@ -691,6 +691,7 @@ int gpx_init(int device, gpx_ctx** out) {
     if (const char* e = getenv("GPX_POTF2")) {
       if (gpx_debug_set_potf2(ctx, e) != 0) return -1;
     }
+    if (const char* e = getenv("GPX_POTF2_TRSM")) ctx->potf2_trsm = (e[0] != '0');
     if (const char* e = getenv("GPX_FIT_SMALL")) ctx->fit_small = (e[0] != '0');
     if (const char* e = getenv("GPX_LAT_LIN")) ctx->lat_lin = (e[0] != '0');
     if (const char* e = getenv("GPX_LAT_GEMM")) ctx->lat_gemm = (std::strcmp(e, "r1") == 0) ? 1 : ((std::strcmp(e, "r5") == 0) ? 5 : 0);
@@ -734,7 +735,7 @@ void gpx_destroy(gpx_ctx* ctx) {
                       &ctx->part, &ctx->alpha, &ctx->Xnew,  &ctx->Vt,     &ctx->Cov,  &ctx->CovLinv,
                       &ctx->SplitK, &ctx->mean, &ctx->var,  &ctx->eps,    &ctx->draws, &ctx->tA,
                       &ctx->tB,   &ctx->tC,  &ctx->thtab,   &ctx->binfo, &ctx->bscal, &ctx->byres, &ctx->diagv, &ctx->st_eps, &ctx->st_yres,
-                      &ctx->st_means, &ctx->st_samples, &ctx->st_infos, &ctx->st_vars, &ctx->st_pred, &ctx->tile_counters};
+                      &ctx->st_means, &ctx->st_samples, &ctx->st_infos, &ctx->st_vars, &ctx->st_pred, &ctx->tile_counters, &ctx->chain_flag};
     for (DevBuf* b : bufs) b->release();
     ctx->pin_in.release();
     ctx->pin_out.release();
@@ -1268,7 +1269,9 @@ int gpx_debug_set_potf2(gpx_ctx* ctx, const char* mode) {
   const std::string v(mode);
   if (v == "slim") ctx->potf2_mode = gpx::GPX_POTF2_SLIM;
   else if (v == "tile") ctx->potf2_mode = gpx::GPX_POTF2_TILE;
-  else return bad_arg(ctx, "potf2 kernel: slim | tile");
+  else if (v == "fuse") ctx->potf2_trsm = true;    // the panel TRSM rides in the potf2 launch (one-outer-block chains)
+  else if (v == "nofuse") ctx->potf2_trsm = false; // ... or is a launch of its own
+  else return bad_arg(ctx, "potf2 kernel: slim | tile | fuse | nofuse");
   return 0;
 }
 

@@ -194,6 +194,12 @@ struct gpx_ctx {
   int lat_now = 5; // the kernel the launches of the current driver call take (set by the drivers from lat_gemm)
   bool lat_lin = true; // lower-tile launches of the round-5 latency shape enumerate only the live tiles (GPX_LAT_LIN=0: square grid)
   hipEvent_t evD = nullptr;
+  // one-outer-block chains (a single sample with the chip to itself): the panel TRSM rides in the potf2 launch (potf2.hip
+  // potf2_trsm_kernel; GPX_POTF2_TRSM=0 / gpx_debug_set_potf2 "nofuse": the three-launch step)
+  bool potf2_trsm = true;
+  gpx::DevBuf chain_flag; // the flag workgroup 0 of potf2_trsm_kernel publishes L^-1 through
+  bool chain_flag_zeroed = false, chain_attr_set = false;
+  unsigned chain_epoch = 0;
   bool serialise_trailing = false; // measurement mode: every Cholesky trailing update runs alone on the chip (linalg.hip)
   // > 0 while a driver whose own panel chain holds no potf2 (the right-looking TRSM sweeps, the K^-1 = W W^T product)
   // is queueing launches: its big-tile GEMMs run persistently (GPX_PERSIST_SCOPE=0 disables)
@@ -399,6 +405,9 @@ int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, in
 int mfma_peak(gpx_ctx* ctx, double* tflops);
 
 // potf2.hip
+struct GemmArgs;
+int launch_potf2_trsm(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo, int info_base, const GemmArgs& g,
+                      int below);
 int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo,
                      int info_base, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0);
 

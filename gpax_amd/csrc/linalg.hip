@@ -70,11 +70,20 @@ static int panel_block(gpx_ctx* ctx, double* dA, int64_t lda, int nblk, int extr
   for (int kb = ob; kb < kb_end; ++kb) {
     double* Akk = dA + (int64_t)kb * TILE * lda + (int64_t)kb * TILE;
     double* Li = dLinv + (int64_t)kb * TILE * TILE;
-    GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs));
     const int below = nblk - kb - 1 + extra;
-    if (below <= 0) continue;
     double* Apan = dA + (int64_t)(kb + 1) * TILE * lda + (int64_t)kb * TILE;
-    { // panel TRSM, in place: A[kb+1.., kb] <- A[kb+1.., kb] * Linv^T
+    // a single sample with the chip to itself (round-5 latency shapes in force): the panel TRSM rides in the potf2 launch
+    // (potf2.hip potf2_trsm_kernel: the same strip body, the same bits) — two launches per step instead of three
+    const bool fused = ctx->potf2_trsm && below > 0 && bs.batch == 1 && ctx->potf2_mode == GPX_POTF2_SLIM &&
+                       (ctx->lat_gemm != 0 ? ctx->lat_gemm : ctx->lat_now) == 5;
+    if (fused) {
+      GemmArgs g = gemm_args(Apan, lda, Li, TILE, Apan, lda, TILE, 1.0, 0.0);
+      GPX_TRY(launch_potf2_trsm(ctx, Akk, lda, Li, dInfo, kb * TILE, g, below));
+    } else {
+      GPX_TRY(launch_potf2_inv(ctx, Akk, lda, Li, dInfo, kb * TILE, bs.batch, bs.a_bs, bs.linv_bs));
+    }
+    if (below <= 0) continue;
+    if (!fused) { // panel TRSM, in place: A[kb+1.., kb] <- A[kb+1.., kb] * Linv^T
       GemmArgs g = gemm_args(Apan, lda, Li, TILE, Apan, lda, TILE, 1.0, 0.0);
       set_batch(g, bs.batch, bs.a_bs, bs.linv_bs, bs.a_bs);
       GPX_TRY(launch_gemm_nt(ctx, g, below, 1, 0, GPX_PROF_GEMM_OTHER,

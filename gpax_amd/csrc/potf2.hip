@@ -14,6 +14,7 @@
 // (Round 1's column-by-column kernel and round 2's blocked 16 x 16 diagonal factor were measured slower and removed:
 // profiles/r02/chain_experiments.md.)
 #include "common.h"
+#include "gemm_tile.h"
 #include "potf2_tile.h"
 #include "potf2_slim.h"
 
@@ -57,9 +58,173 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112))) void pot
   potf2_slim_body(A, lda, Linv, info, info_base, lds);
 }
 
+// Diagonal block AND panel TRSM of one step of the chain in ONE launch (round 6; a step of the one-outer-block
+// factorisation is then potf2+trsm -> update: two launches instead of three).  Workgroup 0 is potf2_slim_kernel; the others
+// own one 16-row strip of the panel below the diagonal block each, are dispatched with it, and wait — one lane polling a
+// flag in device memory — until workgroup 0 has published L^-1 of the block: agent-scope release behind its last store,
+// agent-scope acquire in every strip workgroup before its first load of L^-1 (the strips run on other XCDs, whose L2 is
+// not the one workgroup 0 wrote through).  Workgroup 0 is dispatched first (workgroup ids are handed out in order), so the
+// strips never wait for a workgroup that is not resident.  `epoch`: the value this launch publishes — the flag is reused
+// by every step of a context, launches of one stream are ordered, and each publishes a value no earlier launch has.
+//
+// What the strips do while they wait is what makes this worth a kernel (the same strips as a plain rider — lat_tile behind
+// the flag — measured level with the three-launch step: profiles/r06/potf2_trsm.md): the strip's own operand, 16 rows x 128
+// of the panel, is read BEFORE the flag, straight into registers in MFMA fragment order (lane l: row l & 15, k = 4 kk +
+// (l >> 4), 32 doubles); after the flag only L^-1 is missing, and it comes in ONE piece — 128 rows x 1 KB by LDS-direct
+// loads, all issued at once, one exposed latency (the stand-alone strip kernel walks 16 k-slices through a ring of two:
+// 16 exposed latencies, 10 us of the step).  LDS rows are unpadded 1-KB lines with the 16-B chunk index XOR-ed with
+// (row & 15), applied to the SOURCE address (LDS-DMA writes lane-linearly) and to the fragment reads: the 16 rows a
+// fragment read touches sit at 16 different chunk positions of the 256-B bank row — conflict-free ds_read_b64.
+// Arithmetic: every element accumulates k = 0 .. 127 ascending from 0 in v_mfma_f64_16x16x4_f64 steps and is stored as
+// alpha * acc — what lat_tile<1, 4, 2, 0> and every other shape do: the same bits.
+#ifndef GPX_CHAIN_ACQUIRE
+#define GPX_CHAIN_ACQUIRE 0
+#endif
+constexpr size_t POTF2_TRSM_LDS = (size_t)PB * PB * sizeof(double); // L^-1 whole (128 KB) >= POTF2_SLIM_LDS
+
+#ifdef GPX_POTF2_TRACE
+// trace build (make trace; tools/potf2_trsm_trace.py): 100 MHz wall-clock stamps per launch, slot epoch % ring:
+// [0] workgroup 0 starts  [1] its factorisation is done  [2] flag published  [3] / [4] first / last strip sees the flag
+// [5] last strip has L^-1 in LDS  [6] last strip has stored  [7] strips
+constexpr int CHAIN_TRACE_RING = 1024;
+__device__ long long gpx_chain_trace[CHAIN_TRACE_RING * 8];
+#define GPX_CHAIN_STAMP(k) do { if (threadIdx.x == 0) trc_[(k)] = (long long)wall_clock64(); } while (0)
+#define GPX_CHAIN_MIN(k) do { if (threadIdx.x == 0) atomicMin((unsigned long long*)&trc_[(k)], (unsigned long long)wall_clock64()); } while (0)
+#define GPX_CHAIN_MAX(k) do { if (threadIdx.x == 0) atomicMax((unsigned long long*)&trc_[(k)], (unsigned long long)wall_clock64()); } while (0)
+#else
+#define GPX_CHAIN_STAMP(k) do { } while (0)
+#define GPX_CHAIN_MIN(k) do { } while (0)
+#define GPX_CHAIN_MAX(k) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128))) void potf2_trsm_kernel(double* A, int64_t lda, double* Linv,
+                                                                                           int* info, int info_base,
+                                                                                           GemmArgs g, unsigned* flag,
+                                                                                           unsigned epoch) {
+  __builtin_amdgcn_s_setprio(3);
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+#ifdef GPX_POTF2_TRACE
+  long long* trc_ = gpx_chain_trace + (size_t)(epoch % CHAIN_TRACE_RING) * 8;
+#endif
+  if (blockIdx.x == 0) {
+    GPX_CHAIN_STAMP(0);
+    potf2_slim_body(A, lda, Linv, info, info_base, lds);
+    __syncthreads(); // every wave's stores of L and L^-1 are issued and counted (the barrier's workgroup-scope fence)
+    GPX_CHAIN_STAMP(1);
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    GPX_CHAIN_STAMP(2);
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fk = lane >> 4;
+  // in place (C == A): this workgroup's 16 rows, all of k, before the flag
+  double* P = g.C + ((int64_t)(blockIdx.x - 1) * 16) * g.ldc;
+  double af[32];
+  {
+    const double* Ap = P + (int64_t)fr * g.ldc + fk;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) af[kk] = Ap[4 * kk];
+  }
+  // every wave holds the strip's rows in registers before any wave may store into them (the only barrier of a strip
+  // workgroup, and it is passed while workgroup 0 still factors)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // every wave polls for itself and goes on alone: no barrier behind the flag
+  if (lane == 0)
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+  GPX_CHAIN_MIN(3);
+  GPX_CHAIN_MAX(4);
+#if GPX_CHAIN_ACQUIRE
+  // the textbook form: every wave acquires at agent scope in front of its loads of L^-1.  On this chip that is a
+  // `buffer_inv sc1` per wave, i.e. each of up to ~1000 waves wipes the L2 of its XCD, and every strip workgroup then
+  // fetches its 128 KB of L^-1 from memory — the same 1024 lines for all of them: 12 us for 248 strips, level with the
+  // three-launch step (profiles/r06/potf2_trsm.md).
+  (void)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  // No cache invalidate here, and none is needed: the L2 of this XCD cannot hold a line of THIS block's L^-1.  Every L2 is
+  // invalidated when a kernel starts (what makes the panel written by one launch visible to the next on another XCD),
+  // nothing in this launch reads L^-1 before the flag, and workgroup 0's release has written its lines back to memory —
+  // the first strip of an XCD misses and fetches them, the others hit.  (The poll itself is an agent-scope atomic load: it
+  // bypasses the L2.)  The loads below are issued behind the poll that saw the flag (a GPU does not speculate past the
+  // branch), so nothing is left to order but the compiler:
+  asm volatile("" ::: "memory");
+#endif
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
+  // wave w computes columns [32 w, 32 w + 32) and needs rows 32 w .. 32 w + 31 of L^-1, nothing else: it brings them in
+  // itself (one wave-instruction = 64 lanes x 16 B = one row) and waits for nobody — its first 16 x 16 accumulator starts
+  // when the first 16 rows have landed, behind them the other 16 are still in flight
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    const int row = 32 * wave + r;
+    const int voff = (row * PB + ((lane ^ (row & 15)) * 2)) * 8;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(lds + row * PB), 16, voff, 0, 0, 0);
+  }
+  d4_t acc[2] = {d4_t{0.0, 0.0, 0.0, 0.0}, d4_t{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    if (n == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (n == 1) GPX_CHAIN_MAX(5);
+    const int j = wave * 32 + n * 16 + fr;
+    const int jb = j * PB + (fk & 1), jx = j & 15;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      const double bf = *((lds_cvd_t)lds + (jb + ((2 * kk + (fk >> 1)) ^ jx) * 2));
+      acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf, acc[n], 0, 0, 0);
+    }
+  }
+  const double alpha = g.alpha;
+  double* Cw = P + (int64_t)fk * g.ldc + wave * 32 + fr;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) Cw[(int64_t)(4 * r) * g.ldc + n * 16] = alpha * acc[n][r];
+#ifdef GPX_POTF2_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  GPX_CHAIN_MAX(6);
+}
+
 } // namespace gpx
 
 namespace gpx {
+// potf2 of the diagonal block + the in-place panel TRSM of the `below` 128-row tiles under it (g: the TRSM as
+// launch_gemm_nt would get it — A = C = the panel, B = L^-1 of the block, K = 128, alpha = 1, beta = 0), one launch
+int launch_potf2_trsm(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo, int info_base, const GemmArgs& g0,
+                      int below) {
+  if (!ctx->chain_flag_zeroed) { // once per context
+    if (ctx->chain_flag.ensure(64) != hipSuccess) return bad_arg(ctx, "chain flag");
+    GPX_HIP(ctx, hipMemset(ctx->chain_flag.p, 0, 64));
+    ctx->chain_flag_zeroed = true;
+  }
+  if (!ctx->chain_attr_set) { // 128 KB of dynamic LDS: above the default limit, per device (this context's)
+    GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_trsm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)POTF2_TRSM_LDS));
+    ctx->chain_attr_set = true;
+  }
+  GemmArgs g = g0;
+  g.nsplit = 1;
+  g.batch = 1;
+  ctx->chain_epoch += 1;
+  if (ctx->chain_epoch == 0) ctx->chain_epoch = 1; // (0 is the cleared flag)
+  const unsigned epoch = ctx->chain_epoch;
+#ifdef GPX_POTF2_TRACE
+  {
+    long long init[8] = {0, 0, 0, 0x7fffffffffffffffLL, 0, 0, 0, 8LL * below};
+    GPX_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(gpx_chain_trace), init, sizeof init,
+                                        (size_t)(epoch % CHAIN_TRACE_RING) * 8 * sizeof(long long), hipMemcpyHostToDevice, ctx->s));
+  }
+#endif
+  {
+    ProfScope ps(ctx, GPX_PROF_POTF2, 2.0 * PB * (double)PB * PB / 3.0 + 2.0 * below * TILE * (double)TILE * TILE);
+    potf2_trsm_kernel<<<1 + 8 * below, 256, POTF2_TRSM_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, g,
+                                                                     reinterpret_cast<unsigned*>(ctx->chain_flag.p), epoch);
+  }
+  GPX_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
 int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo, int info_base,
                      int batch, int64_t a_bs, int64_t linv_bs) {
   const int nb = batch > 1 ? batch : 1;
@@ -77,6 +242,13 @@ int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* 
 } // namespace gpx
 
 #ifdef GPX_POTF2_TRACE
+// debug build only (make trace): the stamps of the last `cap_records` potf2_trsm launches (8 long long each, slot = epoch % ring)
+extern "C" int gpx_debug_chain_trace(long long* out, int cap_records) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  const int n = cap_records < gpx::CHAIN_TRACE_RING ? cap_records : gpx::CHAIN_TRACE_RING;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gpx::gpx_chain_trace), (size_t)n * 8 * sizeof(long long)) != hipSuccess) return -1;
+  return n;
+}
 // debug build only (make trace): copies the phase-trace ring of potf2_slim.h to the host; returns the number of launches traced
 extern "C" int gpx_debug_slim_trace(long long* out, int cap_records, unsigned* counts) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;

@@ -310,3 +310,56 @@ def test_live_tile_grids_give_the_bits_of_the_square_grids_in_batched_sweeps(mon
     for a, b in zip(*outs):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
     assert np.all(np.isfinite(outs[0][0])) and np.all(outs[0][3] == 0)
+
+
+@pytest.mark.gpu
+def test_panel_trsm_riding_in_the_potf2_launch_gives_the_same_bits():
+    """potf2.hip potf2_trsm_kernel (round 6): in one-outer-block factorisations of a single sample the panel TRSM of a
+    step is done by workgroups of the potf2 launch that wait for a device flag, instead of a launch of its own
+    (gp.py:160-164's Cholesky, 3 -> 2 launches per 128 columns).  Same strip body, same bits: factors (padded orders, a
+    failing pivot in a block whose strips are already waiting), lml, gradient, the posterior with the k_pX rows riding along,
+    switched in ONE context, several times over (the flag's epoch keeps counting)."""
+    import numpy as np
+    from bench_inputs import synthetic_problem
+    from gpax_amd import _lib
+
+    rng = np.random.default_rng(7)
+    mats = []
+    for n in (129, 300, 1100, 2048):
+        B = rng.standard_normal((n, n + 8))
+        mats.append(B @ B.T / n + 0.3 * np.eye(n))
+    bad = mats[2].copy()
+    bad[150, 150] = -1.0  # pivot 151 fails in the second block: NaN from there on, every later flag still published
+    mats.append(bad)
+    X, y, Xn, p = synthetic_problem(1900, 2, 200, seed=3)
+    e = _lib.Engine(0)
+    res = {}
+    for rnd, mode in enumerate(("nofuse", "fuse", "nofuse", "fuse")):
+        e.set_potf2(mode)
+        out = [e.potrf(A) for A in mats]
+        e.set_train(X)
+        lml, info = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+        grad = e.lml_grad()
+        e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)  # (the gradient pass left K^-1 in place of L)
+        post = e.posterior(Xn, p["noise"], 1e-6, want_cov=True, want_var=True)
+        res[rnd] = (out, lml, info, grad, post)
+    # one order, many different matrices back to back: the strips read L^-1 of a block through their XCD's L2 without an
+    # invalidate of their own (potf2.hip) — a line left over from the factorisation before would show here
+    soak = [(lambda B: B @ B.T / 1024 + (0.2 + 0.05 * k) * np.eye(1024))(rng.standard_normal((1024, 1032))) for k in range(12)]
+    e.set_potf2("nofuse")
+    want = [e.potrf(A)[0] for A in soak]
+    e.set_potf2("fuse")
+    for rep in range(3):
+        for A, L in zip(soak, want):
+            assert np.array_equal(e.potrf(A)[0], L)
+    e.close()
+    for rnd in (1, 2, 3):
+        for (L0, i0), (L1, i1) in zip(res[0][0], res[rnd][0]):
+            assert i0 == i1
+            assert np.array_equal(L0, L1, equal_nan=True)
+        assert res[0][1] == res[rnd][1] and res[0][2] == res[rnd][2] == 0
+        for a, b in zip(res[0][3], res[rnd][3]):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+        for a, b in zip(res[0][4], res[rnd][4]):
+            np.testing.assert_array_equal(a, b)
+    assert [i for _, i in res[1][0]] == [0, 0, 0, 0, 151]
