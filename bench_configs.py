@@ -60,10 +60,10 @@ def c1():
     nl = int(sum(int(np.sum(st["n_leapfrog"])) for st in m.mcmc.get_extra_fields()))
     truth = np.prod(np.sin(Xn + 0.3 * np.arange(d)), axis=1)
     # where gpax actually runs (every reference notebook fits N = 6 ... 40 points): one lml + gradient evaluation as the
-    # samplers issue it (gpx_fit_batch, B = 1 — ONE kernel launch up to N = 127, csrc/fit_small.hip), host to host
+    # samplers issue it (gpx_fit_batch, B = 1 — ONE kernel launch up to N = 128, csrc/fit_small.hip), host to host
     eng = _lib.get_engine()
     small = {}
-    for n_small in (25, 100, 512):
+    for n_small in (25, 100, 128, 512):
         Xs, ys_, _, p = bench_inputs.synthetic_problem(n_small, d, 4, seed=1)
         eng.set_train(Xs)
         kind = _lib.kernel_kind("RBF")

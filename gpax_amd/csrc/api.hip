@@ -155,7 +155,7 @@ int dev_factor(gpx_ctx* ctx, bool fused, const BatchPlan& bp, bool want_lml) {
   GPX_TRY(ensure(ctx, ctx->Linv, (size_t)B * bp.linv_bs * sizeof(double)));
   double* K = ctx->K.d();
   ctx->small_grad_ready = false;
-  if (ctx->fit_small && !fused && N < TILE && !ctx->has_diag) {
+  if (ctx->fit_small && !fused && N <= TILE && !ctx->has_diag) {
     // one launch: the factor in K, its inverse in Linv, [quad, sumlog] AND the gradient (a few microseconds more than the
     // lml alone; gpx_lml_grad / the batch's dev_grad then has nothing left to do), alpha (fit_small.hip)
     RoctxRange r("gpx:fit_small (gram, potf2, lml, gradient: one launch)");
@@ -935,7 +935,7 @@ int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const doubl
   GPX_HIP(ctx, hipSetDevice(ctx->device));
   const int N = ctx->N;
   constexpr int SB = 32; // doubles per sample in bscal
-  if (ctx->fit_small && N < TILE && !ctx->has_diag && grad != nullptr) {
+  if (ctx->fit_small && N <= TILE && !ctx->has_diag && grad != nullptr) {
     // Small N: ONE kernel launch (fit_small.hip) that reads its hyper-parameters and residuals from, and writes its
     // results to, page-locked host memory — no copy calls at all around it: at N = 25 the five hipMemcpyAsync of the
     // general sequence cost more than the arithmetic (profiles/r05/fit_small.json).  X stays resident on the device.

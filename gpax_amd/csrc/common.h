@@ -244,7 +244,7 @@ struct gpx_ctx {
   gpx::DevBuf alpha; // N
   gpx::KernelParams theta{};
   double noise = 0, jitter = 0;
-  // N <= 127: the whole fit step (Gram, factorisation, lml terms, alpha, K^-1, gradient contraction) as ONE launch
+  // N <= 128: the whole fit step (Gram, factorisation, lml terms, alpha, K^-1, gradient contraction) as ONE launch
   // (fit_small.hip; GPX_FIT_SMALL=0: the general launch sequence).  small_grad_ready: the gradient of the factorisation in
   // K already sits in the plan's scal / ctx->alpha — dev_grad has nothing left to launch
   bool fit_small = true;
@@ -411,7 +411,7 @@ int launch_potf2_trsm(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int*
 int launch_potf2_inv(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo,
                      int info_base, int batch = 1, int64_t a_bs = 0, int64_t linv_bs = 0);
 
-// fit_small.hip: lml + gradient of `batch` hyper-parameter vectors at N <= 127 in one launch
+// fit_small.hip: lml + gradient of `batch` hyper-parameter vectors at N <= 128 in one launch
 int launch_fit_small(gpx_ctx* ctx, const KernelParams& kp, double diag_train, const ThetaDev* th, TaskStride ts,
                      const double* dX, int N, const double* dy, int64_t y_bs, int y_mod, double* dK, int64_t ldk,
                      int64_t k_bs, double* dLinv, int64_t linv_bs, double* dalpha, int64_t alpha_bs, double* dscal,

@@ -7,7 +7,9 @@
 // augmentation, potf2, lml terms, tree level 0, row dots, K^-1 product, contraction, reduction: ~10 launches for 4e6
 // flop) is nothing but launch latency: 0.17 ms per fit step at N = 128, 0.15 at N = 32 (profiles/r05/bench_first_with_configs.json).
 //
-// N <= 127, i.e. the augmented matrix [[K, .], [y^T, 1e300]] (+ identity padding) is ONE 128 x 128 block:
+// N <= 127, i.e. the augmented matrix [[K, .], [y^T, 1e300]] (+ identity padding) is ONE 128 x 128 block (N = 128: K is the
+// block and the augmentation row rides in the tile row below it — a 16-row strip multiplied with L^-1 after the factorisation,
+// as the general path's panel TRSM does with it):
 //   A  Gram + augmentation row + identity padding -> the block in global memory (L2), L^-1 block preset to the identity;
 //      the same arithmetic as gram_kernel / augment_kernel, so the block — and with it the factor the posterior reads
 //      afterwards — is bit for bit the general path's
@@ -251,12 +253,47 @@ __global__ __launch_bounds__(256) void fit_small_kernel(FitSmallArgs a) {
       *reinterpret_cast<double2*>(Linv + i * PB + j0) = make_double2(i == j0 ? 1.0 : 0.0, i == j0 + 1 ? 1.0 : 0.0);
     }
   }
+  if (N == PB) {
+    // N = 128: K fills the block and the augmentation row opens a tile row of its own below it (rows 128 .. 255 = [y | 1e300],
+    // identity padding — what augment_kernel writes there).  Nothing in that tile needs factoring: what the path reads is
+    // w = y L^-T in row 128, the panel TRSM of the general path (dev_factor: "rides along below the square part")
+    for (int i = PB + h; i < 2 * PB; i += 4) {
+      *reinterpret_cast<double2*>(A + (int64_t)i * lda + j0) = (i == PB) ? make_double2(y0, y1) : make_double2(0.0, 0.0);
+      const int c0 = PB + j0;
+      *reinterpret_cast<double2*>(A + (int64_t)i * lda + c0) =
+          make_double2(i == c0 ? (i == PB ? AUG_BIG : 1.0) : 0.0, i == c0 + 1 ? 1.0 : 0.0);
+    }
+  }
   __syncthreads(); // (workgroup-scope release / acquire: the block is visible to every wave of this workgroup)
 
   // ---- B: L and L^-1 ----------------------------------------------------------------------------------------------------------
   if (N + 1 <= FS_NT * TS) potf2_small_body(A, lda, Linv, info, lds, (N + 1 + TS - 1) / TS);
-  else potf2_slim_body(A, lda, Linv, info, 0, lds, N + 1);
+  else potf2_slim_body(A, lda, Linv, info, 0, lds, N < PB ? N + 1 : PB);
   __syncthreads();
+  if (N == PB) {
+    // w = y L^-T into row 128: the 16-row strip [y; 0 ...] times L^-1 (B operand: row j of L^-1, straight from the L2 this
+    // workgroup just wrote it through), k ascending in v_mfma_f64_16x16x4_f64 steps from 0 — the operations of the panel TRSM
+    // strip of the general path on that row (gemm_tile.h lat_tile / potf2.hip), so the same bits.  Wave w: column tiles 2 w, 2 w + 1.
+    const int lane_ = tid & 63, wave_ = tid >> 6, fr_ = lane_ & 15, fk_ = lane_ >> 4;
+    double* wrow = A + (int64_t)PB * lda;
+    double af[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) af[kk] = (fr_ == 0) ? wrow[4 * kk + fk_] : 0.0;
+    __syncthreads(); // every wave holds y before any wave stores its part of w over it
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int j = (2 * wave_ + n) * TS + fr_;
+      const double* brow = Linv + j * PB + fk_;
+      double bf[32];
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) bf[kk] = brow[4 * kk];
+      pd4_t acc = pd4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk], acc, 0, 0, 0);
+      if (fk_ == 0) wrow[j] = 1.0 * acc[0]; // D: lane l, register r = row (l >> 4) + 4 r, column l & 15 — row 0 is the strip's y row
+    }
+    __syncthreads();
+  }
 
   // ---- C: w, quad, sumlog, alpha ------------------------------------------------------------------------------------------------
   const int lane = tid & 63, wave = tid >> 6;
@@ -416,7 +453,7 @@ static int fit_small_dispatch(gpx_ctx* ctx, const FitSmallArgs& a, int batch) {
     constexpr unsigned bit = 1u << (KIND * 5 + (DD));                                                                   \
     if (lds > 48 * 1024 && !(ctx->fit_small_attr & bit)) {                                                              \
       GPX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_small_kernel<KIND, DD>),                       \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_small_lds<DD>(PB - 1)));    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_small_lds<DD>(PB)));    \
       ctx->fit_small_attr |= bit;                                                                                       \
     }                                                                                                                   \
     fit_small_kernel<KIND, DD><<<batch, 256, lds, ctx->s>>>(a);                                                          \
@@ -433,13 +470,13 @@ static int fit_small_dispatch(gpx_ctx* ctx, const FitSmallArgs& a, int batch) {
   return 0;
 }
 
-// The fit step of `batch` hyper-parameter vectors at N <= 127 as one launch.  K / Linv / alpha / scal as the general path
+// The fit step of `batch` hyper-parameter vectors at N <= 128 as one launch.  K / Linv / alpha / scal as the general path
 // lays them out (BatchPlan strides); afterwards K holds L (the factor gpx_posterior reads), Linv its inverse.
 int launch_fit_small(gpx_ctx* ctx, const KernelParams& kp, double diag_train, const ThetaDev* th, TaskStride ts,
                      const double* dX, int N, const double* dy, int64_t y_bs, int y_mod, double* dK, int64_t ldk,
                      int64_t k_bs, double* dLinv, int64_t linv_bs, double* dalpha, int64_t alpha_bs, double* dscal,
                      int64_t scal_bs, int* dinfo, int want_grad, int batch) {
-  if (N < 1 || N > PB - 1) return bad_arg(ctx, "fit_small: N must be 1..127");
+  if (N < 1 || N > PB) return bad_arg(ctx, "fit_small: N must be 1..128");
   if (batch < 1) batch = 1;
   FitSmallArgs a{};
   a.X = dX;

@@ -1,5 +1,5 @@
 """The fused small-N fit step (csrc/fit_small.hip: Gram + augmentation + factorisation + lml terms + alpha + K^-1 + gradient
-contraction as ONE launch, N <= 127) against the general launch sequence (GPX_FIT_SMALL=0) and the oracle
+contraction as ONE launch, N <= 128) against the general launch sequence (GPX_FIT_SMALL=0) and the oracle
 (gpax/models/gp.py:137-164 and its reverse-mode gradient): every N where a branch of the kernel changes — one tile row, the
 LDS-resident factorisation up to N = 63, the 128 x 128 kernel above — all three kernels, generic d, failed pivots."""
 import numpy as np
@@ -40,7 +40,7 @@ def _run(monkeypatch, fused, X, y, Xn, kind, ell, scale, noise):
 
 @pytest.mark.parametrize("kind,name", KINDS)
 @pytest.mark.parametrize("N,d", [(2, 1), (7, 1), (15, 2), (16, 1), (25, 1), (31, 3), (32, 2), (47, 1), (63, 2), (64, 1), (100, 5),
-                                 (127, 2)])
+                                 (127, 2), (128, 1), (128, 3)])
 def test_fused_fit_step_equals_the_general_path_and_the_oracle(monkeypatch, kind, name, N, d):
     X, y, Xn, ell, scale, noise = _problem(N, d, kind, seed=100 * N + d)
     f = _run(monkeypatch, True, X, y, Xn, kind, ell, scale, noise)
@@ -73,9 +73,9 @@ def test_fused_fit_step_equals_the_general_path_and_the_oracle(monkeypatch, kind
 
 def test_fused_fit_step_reports_a_failed_pivot_like_the_general_path(monkeypatch):
     """tests/test_gp.py:196-206 of the reference feeds hyper-parameters that make K indefinite: NaN and a pivot report, never a
-    crash — from the LDS-resident factorisation (N = 30) and from the 128 x 128 kernel (N = 90) alike."""
+    crash — from the LDS-resident factorisation (N = 30) and from the 128 x 128 kernel (N = 90, and N = 128 where the augmentation row rides below the block) alike."""
     from gpax_amd import _lib
-    for N in (30, 90):
+    for N in (30, 90, 128):
         X, y, _, p = bench_inputs.synthetic_problem(N, 1, 4, seed=N)
         X[N // 2] = X[N // 2 - 1]  # two coincident points and a negative "noise": a non-positive pivot
         out = {}

@@ -1,4 +1,4 @@
-"""The fused small-N fit step (csrc/fit_small.hip: Gram + factorisation + lml + gradient in ONE launch, N <= 127) against
+"""The fused small-N fit step (csrc/fit_small.hip: Gram + factorisation + lml + gradient in ONE launch, N <= 128) against
 the general launch sequence (GPX_FIT_SMALL=0): device time per launch (HIP events around the kernel), host time per
 gpx_factor + gpx_lml_grad pair and per gpx_fit_batch call at B = 1 / 4 / 64.  One JSON line."""
 import json
@@ -13,7 +13,7 @@ import bench_inputs  # noqa: E402
 from gpax_amd import _lib  # noqa: E402
 
 out = []
-for N, d, kind in [(7, 1, 0), (25, 1, 0), (40, 2, 1), (64, 2, 0), (100, 2, 1), (127, 3, 0)]:
+for N, d, kind in [(7, 1, 0), (25, 1, 0), (40, 2, 1), (64, 2, 0), (100, 2, 1), (127, 3, 0), (128, 2, 0)]:
     X, y, _, p = bench_inputs.synthetic_problem(N, d, 4, seed=N)
     rec = {"N": N, "d": d, "kernel": ["RBF", "Matern"][kind]}
     for mode in ("1", "0"):
