@@ -80,6 +80,11 @@ def load_library() -> C.CDLL:
         "gpx_profile_read_bytes": (C.c_int, [vp, C.c_int, _dp]),
         "gpx_debug_set_potf2": (C.c_int, [vp, C.c_char_p]),
         "gpx_debug_set_lat_gemm": (C.c_int, [vp, C.c_char_p]),
+        "gpx_nuts_transition": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp,
+                                          _dp, _dp, _dp, _dp, C.c_double, _dp, C.c_int, C.POINTER(C.c_uint64), _dp, _ip, _ip]),
+        "gpx_debug_pcg64_doubles": (C.c_int, [C.POINTER(C.c_uint64), C.c_int, _dp]),
+        "gpx_nuts_potential": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp,
+                                         _dp, _dp, _dp]),
         "gpx_debug_set_serialise_trailing": (C.c_int, [vp, C.c_int]),
         "gpx_debug_gemm_time": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
         "gpx_debug_tile_list": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
@@ -126,7 +131,7 @@ EXPORTED_SYMBOLS = (
     "gpx_init gpx_device_count gpx_device_pci gpx_destroy gpx_last_error gpx_device_info gpx_synchronize gpx_gram gpx_set_train gpx_set_train_tasks gpx_set_diag "
     "gpx_factor gpx_lml_grad gpx_lml_grad_diag gpx_fit_batch gpx_posterior gpx_mvn_draw gpx_predict_sweep gpx_sgp_bound gpx_sgp_posterior "
     "gpx_profile_enable "
-    "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_set_potf2 gpx_debug_set_lat_gemm gpx_debug_set_serialise_trailing gpx_debug_gemm_time gpx_debug_tile_list gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
+    "gpx_profile_reset gpx_profile_read gpx_profile_read_bytes gpx_debug_set_potf2 gpx_debug_set_lat_gemm gpx_nuts_transition gpx_nuts_potential gpx_debug_pcg64_doubles gpx_debug_set_serialise_trailing gpx_debug_gemm_time gpx_debug_tile_list gpx_time_stage gpx_sweep_resident gpx_sweep_stats gpx_mfma_f64_peak gpx_gemm_nt "
     "gpx_potrf gpx_node_init gpx_node_destroy gpx_node_last_error gpx_node_info gpx_node_last_shares gpx_predict_sweep_multi "
     "gpx_rank_unique_id gpx_rank_init gpx_rank_destroy gpx_rank_last_error gpx_rank_info gpx_rank_device_pci gpx_rank_collective_calls gpx_rank_barrier gpx_rank_calibrate gpx_shard_ranges_weighted "
     "gpx_rank_allreduce_max gpx_rank_bcast gpx_rank_predict_sweep gpx_shard_range"
@@ -307,6 +312,49 @@ class Engine:
                                             _ptr(yres), rows, _ptr(lml), info.ctypes.data_as(_ip), _ptr(grad),
                                             _ptr(alpha)), "gpx_fit_batch")
         return lml, info, grad, alpha
+
+    def nuts_plan(self, kind: int, idx_ell, idx_scale: int, idx_noise: int, loc, scale, const, jitter: float, yres):
+        """The constant arguments of gpx_nuts_transition, converted once per chain (see nuts_transition)."""
+        idx = np.ascontiguousarray(idx_ell, dtype=np.int32)
+        return dict(kind=int(kind), dim=int(idx.size) + 2, ne=int(idx.size), idx=idx, idx_scale=int(idx_scale),
+                    idx_noise=int(idx_noise), loc=_f64(loc).copy(), scale=_f64(scale).copy(), const=_f64(const).copy(),
+                    jitter=float(jitter), yres=_f64(yres, (self.N,)).copy(), state=(C.c_uint64 * 4)(), acc=C.c_double(),
+                    nl=C.c_int(), div=C.c_int(), U=C.c_double())
+
+    def nuts_potential(self, plan: dict, u):
+        """(U, g) of the potential gpx_nuts_transition integrates, at u (gpx_nuts_potential)."""
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        g = np.empty_like(u)
+        U = C.c_double()
+        self._check(self._lib.gpx_nuts_potential(
+            self._ctx, plan["kind"], plan["dim"], plan["ne"], plan["idx"].ctypes.data_as(_ip), plan["idx_scale"],
+            plan["idx_noise"], _ptr(plan["loc"]), _ptr(plan["scale"]), _ptr(plan["const"]), plan["jitter"], _ptr(plan["yres"]),
+            _ptr(u), C.byref(U), _ptr(g)), "gpx_nuts_potential")
+        return U.value, g
+
+    def nuts_transition(self, plan: dict, u, U: float, g, p0, eps: float, inv_mass, max_tree_depth: int, rng):
+        """One NUTS transition in the library (gpx_nuts_transition, csrc/nuts.hip): (u, U, g, accept, n_leapfrog,
+        diverging) — the uniforms come out of `rng` (a Generator over PCG64), which is advanced exactly as the Python
+        loop of gpax_amd/infer/nuts.py would advance it."""
+        bg = rng.bit_generator
+        st = bg.state
+        s_, i_ = st["state"]["state"], st["state"]["inc"]
+        state = plan["state"]
+        state[0], state[1], state[2], state[3] = s_ >> 64, s_ & 0xFFFFFFFFFFFFFFFF, i_ >> 64, i_ & 0xFFFFFFFFFFFFFFFF
+        u = np.array(u, dtype=np.float64)
+        g = np.array(g, dtype=np.float64)
+        p0 = np.ascontiguousarray(p0, dtype=np.float64)
+        im = np.ascontiguousarray(inv_mass, dtype=np.float64)
+        plan["U"].value = float(U)
+        self._check(self._lib.gpx_nuts_transition(
+            self._ctx, plan["kind"], plan["dim"], plan["ne"], plan["idx"].ctypes.data_as(_ip), plan["idx_scale"],
+            plan["idx_noise"], _ptr(plan["loc"]), _ptr(plan["scale"]), _ptr(plan["const"]), plan["jitter"], _ptr(plan["yres"]),
+            _ptr(u), C.byref(plan["U"]), _ptr(g), _ptr(p0), float(eps), _ptr(im), int(max_tree_depth), state,
+            C.byref(plan["acc"]), C.byref(plan["nl"]), C.byref(plan["div"])), "gpx_nuts_transition")
+        st["state"]["state"] = (int(state[0]) << 64) | int(state[1])
+        bg.state = st
+        self._last_kind = plan["kind"]
+        return u, plan["U"].value, g, plan["acc"].value, plan["nl"].value, bool(plan["div"].value)
 
     def _xu(self, Xu) -> np.ndarray:
         Xu = _f64(Xu)
@@ -592,6 +640,18 @@ class Node:
 
 
 UNIQUE_ID_BYTES = 128
+
+
+def pcg64_doubles(rng: np.random.Generator, n: int) -> np.ndarray:
+    """n uniforms of `rng` (a Generator over PCG64) drawn by the library's own PCG64 (gpx_debug_pcg64_doubles) WITHOUT
+    advancing `rng` — what tests compare with rng.uniform()."""
+    st = rng.bit_generator.state
+    s_, i_ = st["state"]["state"], st["state"]["inc"]
+    state = (C.c_uint64 * 4)(s_ >> 64, s_ & 0xFFFFFFFFFFFFFFFF, i_ >> 64, i_ & 0xFFFFFFFFFFFFFFFF)
+    out = np.empty(int(n))
+    if load_library().gpx_debug_pcg64_doubles(state, int(n), _ptr(out)) != 0:
+        raise ValueError("gpx_debug_pcg64_doubles")
+    return out
 
 
 def shard_ranges_weighted(S: int, weights) -> list:

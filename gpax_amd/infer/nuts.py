@@ -191,8 +191,12 @@ def find_reasonable_step_size(pe_fn, u, U, g, inv_mass, rng, eps=1.0):
 
 def run_nuts(potential_and_grad: Callable[[np.ndarray], Tuple[float, np.ndarray]], u0: np.ndarray,
              num_warmup: int, num_samples: int, rng: np.random.Generator, target_accept: float = 0.8,
-             max_tree_depth: int = 10, progress: Callable[[int, int, dict], None] = None) -> Dict[str, np.ndarray]:
-    """Warm-up + sampling for one chain.  Returns unconstrained draws and diagnostics."""
+             max_tree_depth: int = 10, progress: Callable[[int, int, dict], None] = None,
+             transition: Callable = None) -> Dict[str, np.ndarray]:
+    """Warm-up + sampling for one chain.  Returns unconstrained draws and diagnostics.
+    transition(u, U, g, eps, inv_mass, rng, max_tree_depth): a drop-in for nuts_transition over the same potential — the
+    library's own loop (gpx_nuts_transition, csrc/nuts.hip), which consumes `rng` exactly as nuts_transition does."""
+    step = nuts_transition if transition is None else (lambda pe, *a: transition(*a))
     u = np.array(u0, dtype=np.float64)
     dim = u.shape[0]
     U, g = potential_and_grad(u)
@@ -210,7 +214,7 @@ def run_nuts(potential_and_grad: Callable[[np.ndarray], Tuple[float, np.ndarray]
     total = num_warmup + num_samples
     for it in range(total):
         warm = it < num_warmup
-        u, U, g, acc, nl, div = nuts_transition(potential_and_grad, u, U, g, eps, inv_mass, rng, max_tree_depth)
+        u, U, g, acc, nl, div = step(potential_and_grad, u, U, g, eps, inv_mass, rng, max_tree_depth)
         if warm:
             da.update(acc)
             eps = math.exp(da.log_eps)

@@ -452,6 +452,43 @@ class ExactGP:
                 off += s.size
         return val, grad
 
+    def _native_transition(self, sites, jitter: float, rng):
+        """The NUTS transition as ONE call into the library (gpx_nuts_transition, csrc/nuts.hip: the loop of infer/nuts.py in
+        C++ around the device fit step) for the default model — every site LogNormal (gp.py:222-247), no mean function, no
+        subclass hooks, a real device context, a PCG64 generator — else None: the Python loop.  Same chain either way (the
+        library draws its uniforms from `rng`'s own stream); GPX_NATIVE_NUTS=0 keeps the Python loop."""
+        import os
+        if os.environ.get("GPX_NATIVE_NUTS", "1") == "0" or self.mean_fn is not None or getattr(self, "_det", None):
+            return None
+        cls = type(self)
+        if any(getattr(cls, name) is not getattr(ExactGP, name)
+               for name in ("_log_joint", "_log_joint_batch", "_chain_rule", "_prepare_engine", "_unpack", "_ell")):
+            return None
+        plan = self._lognormal_plan(sites)
+        want = {"k_length": self.kernel_dim, "k_scale": 1, "noise": 1}
+        if self.kernel_name == "Periodic":
+            want["period"] = 1
+        if plan is None or {s.name: s.size for s in sites} != want or len(sites) != len(want):
+            return None
+        if type(rng.bit_generator).__name__ != "PCG64":
+            return None
+        eng = self._engine()
+        if not isinstance(eng, _lib.Engine) or self.kernel_dim + 3 > 20:
+            return None
+        off, at = {}, 0
+        for s_ in sites:
+            off[s_.name] = at
+            at += s_.size
+        idx_ell = [off["k_length"] + c for c in range(self.kernel_dim)] + ([off["period"]] if "period" in off else [])
+        nplan = eng.nuts_plan(self._kind, idx_ell, off["k_scale"], off["noise"], plan[0], plan[1], plan[2], jitter, self.y_train)
+
+        def transition(u, U, g, eps, inv_mass, rng_, max_tree_depth):
+            p0 = rng_.standard_normal(u.shape[0]) / np.sqrt(inv_mass)
+            return self._engine().nuts_transition(nplan, u, U, g, p0, eps, inv_mass, max_tree_depth, rng_)
+
+        transition.plan = nplan  # (tests: the same potential through gpx_nuts_potential)
+        return transition
+
     def _init_unconstrained(self, sites, rng, num_samples: int = 10):
         """init_to_median(num_samples=10) (gp.py:207): per-site median of prior draws."""
         parts = []
@@ -532,7 +569,8 @@ class ExactGP:
                         break
                 prog = _Progress(progress_bar and (not concurrent or c == 0),
                                  f"chain {c + 1}/{num_chains}" if num_chains > 1 else "sample")
-                results[c] = run_nuts(potential, u0, num_warmup, num_samples, crng, progress=prog)
+                results[c] = run_nuts(potential, u0, num_warmup, num_samples, crng, progress=prog,
+                                      transition=None if lockstep is not None else self._native_transition(sites, jitter, crng))
                 prog.close()
             except Exception as ex:
                 errors.append(ex)

@@ -120,6 +120,36 @@ int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const doubl
                   const double* noises, double jitter, const double* yres, int yres_rows,
                   double* lml, int* info, double* grad, double* alpha);
 
+/* ---- one NUTS transition on the host side of the library (csrc/nuts.hip) -----------------------------------------
+ * numpyro.infer.NUTS as ExactGP.fit drives it (gpax/models/gp.py:207-218), for the default model: every site of the
+ * unconstrained vector u = log(theta) LogNormal-distributed (gp.py:222-247), no mean function.  Leapfrogs, recursive
+ * doubling, multinomial / biased progressive sampling and the generalised U-turn test around gpx_fit_batch(B = 1) — the
+ * loop of gpax_amd/infer/nuts.py statement for statement, without a Python frame per leapfrog (what dominates at the N = 25
+ * of examples/gpax_simpleGP.ipynb).  Adaptation stays with the caller.
+ *   dim = ne + 2, ne = d (+ 1: period);  idx_ell[c]: position in u of the device's lengthscale entry c, idx_scale /
+ *   idx_noise likewise (together a permutation of 0 .. dim - 1);
+ *   prior_loc / prior_scale / prior_const (dim each): LogNormal(loc, scale) per element, const = log(scale) + log(2 pi) / 2;
+ *   yres (N): residuals (host);  u, U, g: in — the current point, its potential and gradient; out — the new ones;
+ *   p0 (dim): the momentum (drawn by the caller);  eps, inv_mass (dim), max_tree_depth: as nuts_transition;
+ *   pcg_state4: {state hi, state lo, inc hi, inc lo} of a numpy.random.PCG64 — the uniforms are drawn from it in the
+ *   order the Python loop draws them; state hi / lo are advanced on return;
+ *   accept (mean acceptance probability), n_leapfrog, diverging: the transition's diagnostics.
+ * Returns 0, or the error of a device call inside a leapfrog (gpx_last_error). */
+int gpx_nuts_transition(gpx_ctx* ctx, int kind, int dim, int ne, const int* idx_ell, int idx_scale, int idx_noise,
+                        const double* prior_loc, const double* prior_scale, const double* prior_const, double jitter,
+                        const double* yres, double* u, double* U, double* g, const double* p0, double eps,
+                        const double* inv_mass, int max_tree_depth, uint64_t* pcg_state4, double* accept, int* n_leapfrog,
+                        int* diverging);
+/* The potential gpx_nuts_transition integrates, alone: U(u) = -(log p(y | theta) + log prior(theta) + log |d theta / d u|)
+ * at theta = exp(u) and its gradient (arguments as above) — tests drive the Python loop of gpax_amd/infer/nuts.py with it
+ * to show that the two loops are the same algorithm (identical chains when the scalar arithmetic is shared). */
+int gpx_nuts_potential(gpx_ctx* ctx, int kind, int dim, int ne, const int* idx_ell, int idx_scale, int idx_noise,
+                       const double* prior_loc, const double* prior_scale, const double* prior_const, double jitter,
+                       const double* yres, const double* u, double* U, double* g);
+/* Host only (no GPU, no context): n doubles of numpy.random.PCG64 from the state {state hi, state lo, inc hi, inc lo}
+ * (advanced on return) — Generator.uniform()'s stream, as gpx_nuts_transition draws it (tests/test_samplers.py). */
+int gpx_debug_pcg64_doubles(uint64_t* state4, int n, double* out);
+
 /* ---- posterior: ExactGP.get_mvn_posterior, gpax/models/gp.py:253-277 ----------------------
  * Must follow gpx_factor (same theta).  mean (M), cov (M*M, may be NULL), var (M, may be
  * NULL; = diag(cov), what viGP.predict returns, gpax/models/vigp.py:184-185).
