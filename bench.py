@@ -252,6 +252,8 @@ def serialised_trailing_record(eng):
         eng.profile_enable(False)
     finally:
         eng.set_serialise_trailing(False)
+    if not per[0][1]:  # a size whose factorisation is one outer block (test-sized runs): no trailing-update launches at all
+        return {"avg_launch_ms": None, "launches": 0, "flops": 0.0, "passes": 3}
     per.sort(key=lambda r: r[0])
     return {"avg_launch_ms": per[1][0], "launches": per[1][1], "flops": per[1][2], "passes": 3}
 

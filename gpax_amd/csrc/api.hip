@@ -207,8 +207,10 @@ int dev_grad(gpx_ctx* ctx, const BatchPlan& bp) {
     ctx->small_grad_ready = false;
     ctx->factored = false; // (as after the general path, whose K^-1 overwrites the factor)
     ctx->have_kinv = false;
+    ctx->small_no_kinv = (B == 1); // the one-launch step never stores K^-1: gpx_lml_grad_diag re-runs the general sequence
     return 0;
   }
+  ctx->small_no_kinv = false;
   const int nt = (N + TILE - 1) / TILE; // tiles that carry real rows (excludes a pure aug tile)
   const int n128 = nt * TILE;
   const int64_t w_bs = (int64_t)ctx->Np * ctx->ldk, alpha_bs = ctx->Np;
@@ -260,6 +262,7 @@ int dev_grad(gpx_ctx* ctx, const BatchPlan& bp) {
                                ctx->part.d(), &nblocks, B, bp.k_bs, alpha_bs, bp.th, ts_train(ctx)));
   GPX_TRY(launch_grad_reduce(ctx, ctx->part.d(), nblocks, n_ell(ctx->theta) + 2, bp.scal + SC_GRAD, B, bp.scal_bs));
   ctx->factored = false; // K now holds K^-1
+  ctx->small_grad_ready = false;
   ctx->have_kinv = (B == 1);
   return 0;
 }
@@ -618,6 +621,7 @@ int sweep_core(gpx_ctx* ctx, const SweepIO& io) {
   ctx->last_batch = B;
   // the context no longer holds a single factored theta
   ctx->factored = false;
+  ctx->small_grad_ready = false;
   ctx->have_post = false;
   ctx->cov_factored = false;
   return 0;
@@ -692,6 +696,15 @@ int gpx_init(int device, gpx_ctx** out) {
       if (gpx_debug_set_potf2(ctx, e) != 0) return -1;
     }
     if (const char* e = getenv("GPX_POTF2_TRSM")) ctx->potf2_trsm = (e[0] != '0');
+    {
+      // the one-launch fit step wants up to ~100 KB of dynamic LDS per workgroup, the fused potf2 + TRSM launch 128 KB
+      // (gfx950: 160 KB per CU): a device that offers less keeps the general launch sequences
+      int optin = 0;
+      if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) optin = 0;
+      const size_t lds_max = std::max((size_t)(optin > 0 ? optin : 0), (size_t)ctx->prop.maxSharedMemoryPerMultiProcessor);
+      if (lds_max < (size_t)100 * 1024) ctx->fit_small = false;
+      if (lds_max < (size_t)128 * 1024) ctx->potf2_trsm = false;
+    }
     if (const char* e = getenv("GPX_FIT_SMALL")) ctx->fit_small = (e[0] != '0');
     if (const char* e = getenv("GPX_LAT_LIN")) ctx->lat_lin = (e[0] != '0');
     if (const char* e = getenv("GPX_LAT_GEMM")) ctx->lat_gemm = (std::strcmp(e, "r1") == 0) ? 1 : ((std::strcmp(e, "r5") == 0) ? 5 : 0);
@@ -829,6 +842,7 @@ static int set_train_impl(gpx_ctx* ctx, const double* X, int T, int N, int d, bo
                               on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->factored = false;
+  ctx->small_grad_ready = false;
   ctx->have_post = false;
   return 0;
 }
@@ -844,6 +858,7 @@ int gpx_set_diag(gpx_ctx* ctx, const double* v, int n) {
   if (v == nullptr || n == 0) {
     ctx->has_diag = false;
     ctx->factored = false;
+    ctx->small_grad_ready = false;
     return 0;
   }
   if (ctx->N < 1 || n != ctx->N) return bad_arg(ctx, "gpx_set_diag: need one value per training point");
@@ -854,6 +869,7 @@ int gpx_set_diag(gpx_ctx* ctx, const double* v, int n) {
   GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->has_diag = true;
   ctx->factored = false;
+  ctx->small_grad_ready = false;
   return 0;
 }
 
@@ -910,9 +926,19 @@ int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* gra
 
 int gpx_lml_grad_diag(gpx_ctx* ctx, double* grad_diag) {
   if (!ctx || ctx->device < 0) return -1;
-  if (!ctx->have_kinv) return bad_arg(ctx, "gpx_lml_grad_diag must follow gpx_lml_grad");
   if (!grad_diag) return bad_arg(ctx, "null pointer");
   GPX_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->have_kinv && ctx->small_no_kinv) {
+    // the gradient came from the one-launch fit step (N <= 128, no per-point diagonal: fit_small.hip), which contracts K^-1
+    // out of its accumulators and never stores it: once more through the general sequence at the same theta / residuals
+    const bool fs = ctx->fit_small;
+    ctx->fit_small = false;
+    int rc = dev_factor(ctx, false);
+    if (rc == 0) rc = dev_grad(ctx);
+    ctx->fit_small = fs;
+    if (rc != 0) return rc;
+  }
+  if (!ctx->have_kinv) return bad_arg(ctx, "gpx_lml_grad_diag must follow gpx_lml_grad (K^-1 and alpha resident)");
   const int N = ctx->N;
   GPX_TRY(ensure(ctx, ctx->byres, (size_t)N * sizeof(double)));
   GPX_TRY(launch_grad_diag(ctx, ctx->K.d(), ctx->ldk, N, ctx->alpha.d(), ctx->byres.d()));
@@ -974,9 +1000,9 @@ int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const doubl
                              (int64_t)ctx->Np * ctx->ldk, ctx->Linv.d(), (int64_t)TILE * TILE, hal, TILE, hsc, SB, hin, 1, B));
     GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->factored = false;
+    ctx->small_grad_ready = false;
     ctx->have_post = false;
     ctx->have_kinv = false;
-    ctx->small_grad_ready = false;
     const int ne = n_ell(ctx->theta);
     for (int b = 0; b < B; ++b) {
       int hinfo = hin[b];
@@ -1034,6 +1060,7 @@ int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const doubl
                                   hipMemcpyDeviceToHost, ctx->stream));
   GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->factored = false;
+  ctx->small_grad_ready = false;
   ctx->have_post = false;
   for (int b = 0; b < B; ++b) {
     int hinfo = ctx->h_binfo[(size_t)b];
@@ -1359,6 +1386,7 @@ int gpx_time_stage(gpx_ctx* ctx, int stage, int reps, double* elapsed_ms) {
                                    ctx->Np, ctx->noise + ctx->jitter, 1, 1, ctx->K.d(), ctx->ldk, 1, 0, nullptr, 0,
                                    TaskStride(), ctx->has_diag ? ctx->diagv.d() : nullptr));
         ctx->factored = false;
+        ctx->small_grad_ready = false;
         break;
       case GPX_STAGE_POTRF:
         GPX_TRY(dev_factor(ctx, false));

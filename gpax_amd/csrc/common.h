@@ -249,6 +249,7 @@ struct gpx_ctx {
   // K already sits in the plan's scal / ctx->alpha — dev_grad has nothing left to launch
   bool fit_small = true;
   bool small_grad_ready = false;
+  bool small_no_kinv = false; // the last gradient came from the one-launch step: K^-1 was never stored (gpx_lml_grad_diag)
   unsigned fit_small_attr = 0; // fit_small_kernel variants whose dynamic-LDS limit this context has raised on its device
   bool factored = false;
   bool have_kinv = false; // K holds K^-1 and alpha is resident (after the gradient pass)

@@ -340,6 +340,12 @@ static int launch_big(gpx_ctx* ctx, const GemmArgs& g0, int tiles_m, int tiles_n
 int launch_gemm_nt(gpx_ctx* ctx, const GemmArgs& g, int tiles_m, int tiles_n, int splits,
                    int prof_cls, double work) {
   if (tiles_m <= 0 || tiles_n <= 0) return 0;
+  // In place (C == A: the panel TRSM A <- A B^T): every workgroup tile must own the rows it reads — ONE column tile and a k
+  // range no wider than it (K <= 128) — and read its whole k range before its first store.  All three tile bodies do
+  // (gemm_tile.h: the accumulators are complete before the epilogue), so whichever shape the tile count below selects —
+  // strips, 64 x 64 never (tiles_n == 1 keeps C == A off it), the 128 x 128 or the persistent kernel for batched chains —
+  // is safe; anything else in place is refused here rather than left to a race.
+  if (g.C == g.A && (tiles_n != 1 || g.K > TILE)) return bad_arg(ctx, "in-place GEMM: one column tile, K <= 128");
   // algorithmic bytes: `work` = 2 K per updated entry => entries = work / (2 K), each read and written once (beta != 0)
   const double bmul_p = (g.batch > 1 ? g.batch : 1);
   ProfScope ps(ctx, prof_cls, work * bmul_p, (g.K > 0 ? work / (2.0 * g.K) : 0.0) * (g.beta != 0.0 ? 16.0 : 8.0) * bmul_p);

@@ -544,6 +544,7 @@ static int sgp_setup(gpx_ctx* ctx, SgpState* s, int kind, const double* ell, dou
     if (s->reuse) { // everything the forward pass produced is still resident; yres again (the exact-GP entry points share it)
       GPX_HIP(ctx, hipMemcpyAsync(ctx->yres.d(), yres, yb, hipMemcpyHostToDevice, ctx->stream));
       ctx->factored = false;
+      ctx->small_grad_ready = false;
       ctx->have_post = false;
       return 0;
     }
@@ -571,6 +572,7 @@ static int sgp_setup(gpx_ctx* ctx, SgpState* s, int kind, const double* ell, dou
   GPX_HIP(ctx, hipMemcpyAsync(s->Xu.d(), Xu, (size_t)Mi * d * 8, hipMemcpyHostToDevice, ctx->stream));
   GPX_HIP(ctx, hipMemcpyAsync(ctx->yres.d(), yres, (size_t)ctx->N * 8, hipMemcpyHostToDevice, ctx->stream));
   ctx->factored = false;
+  ctx->small_grad_ready = false;
   ctx->have_post = false;
   return 0;
 }

@@ -64,8 +64,10 @@ def _private_dir(path: str, parent: bool = False) -> None:
     """Create `path` for this user only and refuse one that somebody else could have planted (another owner, a symbolic
     link, write access for group / others): the directory carries the 128-byte RCCL bootstrap id.
     parent = True: `path` is the rendezvous directory itself, possibly handed over by the user (GPX_RDZV_DIR made by hand
-    under umask 002 is 0775): only owner and not-a-symlink are checked there — the ids live in the <token>/attempt
-    subdirectories this module creates itself, and those are held to the write-bit rule."""
+    under umask 002 is 0775): owner, not-a-symlink and — unless the sticky bit is set, as on /tmp — no write access for
+    OTHERS are checked there (whoever can write to it could rename the <token> subdirectory between the checks and plant
+    their own); the ids live in the <token>/attempt subdirectories this module creates itself, and those are held to the
+    full write-bit rule."""
     os.makedirs(path, mode=0o700, exist_ok=True)
     st = os.lstat(path)
     import stat as _stat
@@ -75,6 +77,9 @@ def _private_dir(path: str, parent: bool = False) -> None:
         raise PermissionError(f"rendezvous directory {path} belongs to uid {st.st_uid}, not to this user")
     if not parent and st.st_mode & 0o022:
         raise PermissionError(f"rendezvous directory {path} is writable by others (mode {oct(st.st_mode & 0o777)})")
+    if parent and (st.st_mode & 0o002) and not (st.st_mode & _stat.S_ISVTX):
+        raise PermissionError(f"rendezvous directory {path} is world-writable without the sticky bit "
+                              f"(mode {oct(st.st_mode & 0o7777)})")
 
 
 def rank_env(environ=None) -> Optional[RankEnv]:

@@ -569,8 +569,11 @@ class ExactGP:
                         break
                 prog = _Progress(progress_bar and (not concurrent or c == 0),
                                  f"chain {c + 1}/{num_chains}" if num_chains > 1 else "sample")
-                results[c] = run_nuts(potential, u0, num_warmup, num_samples, crng, progress=prog,
-                                      transition=None if lockstep is not None else self._native_transition(sites, jitter, crng))
+                # one chain (the reference's default, and what every notebook runs): the transition loop inside the library.
+                # Several chains keep the Python loop whatever the chain_method, so that 'parallel' / 'vectorized' chains —
+                # which advance in lockstep through _log_joint_batch — stay bit for bit the 'sequential' ones.
+                native = self._native_transition(sites, jitter, crng) if num_chains == 1 else None
+                results[c] = run_nuts(potential, u0, num_warmup, num_samples, crng, progress=prog, transition=native)
                 prog.close()
             except Exception as ex:
                 errors.append(ex)

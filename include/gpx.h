@@ -102,7 +102,9 @@ int gpx_lml_grad(gpx_ctx* ctx, double* grad_ell, double* grad_scale, double* gra
                  double* alpha);
 
 /* d lml / d v for the per-point diagonal of gpx_set_diag (K = k + (noise + jitter) I + diag(v)):
- * grad_diag[i] = 1/2 (alpha_i^2 - (K^-1)_ii).  Call after gpx_lml_grad (K^-1 and alpha resident).
+ * grad_diag[i] = 1/2 (alpha_i^2 - (K^-1)_ii).  Call after gpx_lml_grad (K^-1 and alpha resident; when that gradient came
+ * from the one-launch fit step of N <= 128 — no gpx_set_diag in force — which never stores K^-1, this call re-runs the
+ * general sequence at the same theta first).
  * VarNoiseGP.model (gpax/models/hskgp.py:124-153) differentiates through v = exp(log_var). */
 int gpx_lml_grad_diag(gpx_ctx* ctx, double* grad_diag);
 

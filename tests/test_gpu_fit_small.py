@@ -110,3 +110,24 @@ def test_fused_fit_step_with_a_per_point_diagonal_takes_the_general_path(monkeyp
     al = Ki @ y
     np.testing.assert_allclose(gd, 0.5 * (al * al - np.diag(Ki)), rtol=0, atol=1e-9 * np.abs(al).max() ** 2)
     assert info == 0 and np.isfinite(lml)
+
+
+def test_lml_grad_diag_after_the_one_launch_step_reruns_the_general_sequence():
+    """without gpx_set_diag the fit step of N <= 128 is ONE launch that never stores K^-1; gpx_lml_grad_diag
+    (d lml / d v, hskgp.py:124-153) called behind it used to fail with 'must follow gpx_lml_grad'.  It now re-runs the general
+    sequence at the same theta: 1/2 (alpha_i^2 - (K^-1)_ii) against the oracle's dense inverse."""
+    from gpax_amd import _lib
+    for N in (40, 128):
+        X, y, _, p = bench_inputs.synthetic_problem(N, 2, 4, seed=N)
+        e = _lib.Engine(0)
+        e.set_train(X)
+        lml, info = e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y)
+        g = e.lml_grad()
+        gd = e.lml_grad_diag()
+        g2 = (e.factor(1, p["k_length"], p["k_scale"], p["noise"], 1e-6, y), e.lml_grad())[1]  # the fused path still in force
+        e.close()
+        Ki = np.linalg.inv(ref.get_kernel("Matern")(X, X, p, p["noise"], 1e-6))
+        al = Ki @ y
+        np.testing.assert_allclose(gd, 0.5 * (al * al - np.diag(Ki)), rtol=0, atol=1e-9 * max(1.0, np.abs(al).max() ** 2))
+        for a, b in zip(g, g2):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b))

@@ -172,6 +172,17 @@ def test_a_hand_made_rendezvous_directory_with_group_write_is_accepted_but_its_s
     env2 = launch.rank_env({"RANK": "0", "WORLD_SIZE": "1", "GPX_RDZV_DIR": str(link), "GPX_RDZV_TOKEN": "t"})
     with pytest.raises(PermissionError, match="not a plain directory"):
         launch.init_rank(env2, transport="file", timeout=10.0, make_rank=FakeRank, make_uid=lambda: b"x" * 128)
+    # world-writable without the sticky bit is refused (anybody could rename the <token> subdirectory between the
+    # checks and plant their own); with it — /tmp's mode — only the owner of an entry can rename it
+    open_dir = tmp_path / "open"
+    open_dir.mkdir()
+    os.chmod(open_dir, 0o777)
+    env3 = launch.rank_env({"RANK": "0", "WORLD_SIZE": "1", "GPX_RDZV_DIR": str(open_dir), "GPX_RDZV_TOKEN": "t"})
+    with pytest.raises(PermissionError, match="world-writable without the sticky bit"):
+        launch.init_rank(env3, transport="file", timeout=10.0, make_rank=FakeRank, make_uid=lambda: b"x" * 128)
+    os.chmod(open_dir, 0o1777)
+    rk3 = launch.init_rank(env3, transport="file", timeout=10.0, make_rank=FakeRank, make_uid=lambda: b"x" * 128)
+    assert (os.stat(rk3.args["file_dir"]).st_mode & 0o777) == 0o700
 
 
 def test_the_rendezvous_directory_must_be_private(tmp_path):
