@@ -1,13 +1,13 @@
 #!/bin/bash
 # Regenerate the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_round.sh r05
+#   bash tools/profile_round.sh r06
 #   kernel-trace + stats of the default bench command, separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*), the C4
 #   sweep (S = 1000) with its own kernel trace, and the round's bench line; summarised on the box (the rocpd sqlite
 #   databases stay in /tmp; only .md / .json summaries come back under gpurun_out/prof — copy them to profiles/<round>).
 # NOTE (round 1): a single pass with five TCC_* derived counters on `bench.py --steps 1` did not finish within 10
 # minutes on this pool — keep L2 counters out of this script.  --pmc passes carry --kernel-trace only (gpurun refuses
 # --pmc together with the hip / hsa / memory trace domains).
-RND=${1:-r05}
+RND=${1:-r06}
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/prof
