@@ -586,7 +586,9 @@ def node_record(a):
         dt4 = time.perf_counter() - t0
         rec.update({"c4_S": S4, "c4_seconds": dt4, "c4_posteriors_per_s": S4 / dt4,
                     "c4_nan_rows": int(np.isnan(r4[1]).any(axis=(1, 2)).sum()),
-                    "c4_checksum": float(np.nansum(r4[0]) + np.nansum(r4[1]))})
+                    "c4_checksum": float(np.nansum(r4[0]) + np.nansum(r4[1])),
+                    # the samples are dealt to the GPUs as they go (one cursor over all contexts): who ended up with how many
+                    "c4_samples_per_gpu": node.last_shares()})
     node.close()
     print(json.dumps(rec), flush=True)
 
@@ -843,7 +845,9 @@ def collective_leg(a, env, device, transport, rep, on_hang=None):
         "value": world * K / dt, "unit": "posteriors/s", "ms_per_step": dt / K * 1e3, "per_rank_seconds": per_rank_s,
         "vs_replicas": (world * K / dt) / rep["value"], "transport": info["transport"], "n_gpus": n_distinct,
         "devices_pci": ["%04x:%02x:%02x" % (v >> 16, (v >> 8) & 0xff, v & 0xff) for v in pci],
-        "nan_rows": int(np.isnan(res[1]).any(axis=(1, 2)).sum())}
+        "nan_rows": int(np.isnan(res[1]).any(axis=(1, 2)).sum()),
+        # the ranks' sample blocks are sized by a probe of every GPU (gpx_rank_calibrate, launch.init_rank): relative speeds
+        "rank_speeds": [float(v) for v in getattr(rk, "speeds", [])] or None}
     if c4 is not None:
         out["c4_sweep"] = c4
     return out, rk

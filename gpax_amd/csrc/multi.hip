@@ -33,7 +33,7 @@ struct NodeDev {
   hipStream_t cs = nullptr;   // communication / staging stream
   DevBuf payload;             // [X | X_new | y_res | eps] as broadcast
   DevBuf out;                 // this GPU's result block, laid out for all S samples (it holds those it took, in taking order)
-  DevBuf gather;              // root only: every GPU's block, compacted — the gather target
+  DevBuf gather;              // this GPU's block compacted (what it sends); on the root: every GPU's block — the gather target
 };
 
 } // namespace
@@ -281,8 +281,8 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
     boff[(size_t)r + 1] = boff[(size_t)r] + BlockLayout(logs[(size_t)r].placed, n, M).total;
   }
 
-  // ---- 3. gather on the root GPU: every GPU's block, compacted to the samples it holds (one RCCL group, up to four
-  // segments per GPU: means | draws | vars | pivots), one download --------------------------------------------------
+  // ---- 3. gather on the root GPU: every GPU's block, compacted to the samples it holds (means | draws | vars | pivots),
+  // ONE message per GPU in one RCCL group, one download --------------------------------------------------
   NODE_HIP(nd, hipSetDevice(root.device));
   NODE_HIP(nd, root.gather.ensure((size_t)(boff[(size_t)G] > 0 ? boff[(size_t)G] : 1) * sizeof(double)));
   struct Seg {
@@ -306,17 +306,28 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
       NODE_HIP(nd, hipMemcpyAsync(root.gather.d() + sg[i].dst, root.out.d() + sg[i].src, (size_t)sg[i].cnt * sizeof(double),
                                   hipMemcpyDeviceToDevice, root.cs));
   }
+  // every other GPU compacts its block on ITS device first (the same <= 4 device-to-device copies), so that what crosses xGMI
+  // is ONE contiguous message per GPU — the send / receive pattern of rounds 1 - 5
+  for (int r = 1; r < G; ++r) {
+    NodeDev& D = nd->devs[(size_t)r];
+    const int k = segments(r, sg);
+    if (k == 0) continue;
+    const int64_t tot = boff[(size_t)r + 1] - boff[(size_t)r];
+    NODE_HIP(nd, hipSetDevice(D.device));
+    NODE_HIP(nd, D.gather.ensure((size_t)tot * sizeof(double)));
+    for (int i = 0; i < k; ++i)
+      NODE_HIP(nd, hipMemcpyAsync(D.gather.d() + (sg[i].dst - boff[(size_t)r]), D.out.d() + sg[i].src,
+                                  (size_t)sg[i].cnt * sizeof(double), hipMemcpyDeviceToDevice, D.cs));
+  }
   if (nd->use_rccl) {
     ncclResult_t first = ncclSuccess;
     NODE_NCCL(nd, nd->rccl.GroupStart());
     for (int r = 1; r < G && first == ncclSuccess; ++r) {
+      const int64_t cnt = boff[(size_t)r + 1] - boff[(size_t)r];
+      if (cnt <= 0 || logs[(size_t)r].placed <= 0) continue;
       NodeDev& D = nd->devs[(size_t)r];
-      const int k = segments(r, sg);
-      for (int i = 0; i < k && first == ncclSuccess; ++i) {
-        first = nd->rccl.Recv(root.gather.d() + sg[i].dst, (size_t)sg[i].cnt, ncclDouble, r, nd->comms[0], root.cs);
-        if (first == ncclSuccess)
-          first = nd->rccl.Send(D.out.d() + sg[i].src, (size_t)sg[i].cnt, ncclDouble, 0, nd->comms[(size_t)r], D.cs);
-      }
+      first = nd->rccl.Recv(root.gather.d() + boff[(size_t)r], (size_t)cnt, ncclDouble, r, nd->comms[0], root.cs);
+      if (first == ncclSuccess) first = nd->rccl.Send(D.gather.p, (size_t)cnt, ncclDouble, 0, nd->comms[(size_t)r], D.cs);
     }
     const ncclResult_t ge = nd->rccl.GroupEnd();
     if (first == ncclSuccess) first = ge;
@@ -327,11 +338,14 @@ int gpx_predict_sweep_multi(gpx_node* nd, int kind, const double* X, int N, int 
     }
   } else {
     for (int r = 1; r < G; ++r) {
+      const int64_t cnt = boff[(size_t)r + 1] - boff[(size_t)r];
+      if (cnt <= 0 || logs[(size_t)r].placed <= 0) continue;
       NodeDev& D = nd->devs[(size_t)r];
-      const int k = segments(r, sg);
-      for (int i = 0; i < k; ++i)
-        NODE_HIP(nd, hipMemcpyPeerAsync(root.gather.d() + sg[i].dst, root.device, D.out.d() + sg[i].src, D.device,
-                                        (size_t)sg[i].cnt * sizeof(double), root.cs));
+      NODE_HIP(nd, hipSetDevice(D.device));
+      NODE_HIP(nd, hipStreamSynchronize(D.cs)); // the compaction on the source device is done before the root pulls
+      NODE_HIP(nd, hipSetDevice(root.device));
+      NODE_HIP(nd, hipMemcpyPeerAsync(root.gather.d() + boff[(size_t)r], root.device, D.gather.p, D.device,
+                                      (size_t)cnt * sizeof(double), root.cs));
     }
   }
   NODE_HIP(nd, hipSetDevice(root.device));

@@ -36,12 +36,13 @@ def main():
     assert np.array_equal(b, np.arange(5.0))
     eng = _lib.Engine(0 if a.share_gpu else env.local_rank) if root else None
     # blocks sized by measured GPU speed (gpx_rank_calibrate; launch.init_rank has calibrated once already): rank 1 reports
-    # half its rate, so after the clamp to [0.85, 1.15] of the mean it gets the smaller block — and every case below still
-    # has to come out bit-identical, which it only does when all ranks cut the same blocks
+    # a tenth of its rate (the ranks may share one GPU here and probe it at the same time: anything milder drowns in that),
+    # so after the clamp to [0.85, 1.15] of the mean it gets the smaller block — and every case below still has to come out
+    # bit-identical, which it only does when all ranks cut the same blocks
     if env.world > 1:
         assert getattr(rk, "speeds", None) is not None and len(rk.speeds) == env.world
         if env.rank == 1:
-            os.environ["GPX_RANK_SPEED_SCALE"] = "0.5"
+            os.environ["GPX_RANK_SPEED_SCALE"] = "0.1"
         sp = rk.calibrate()
         os.environ.pop("GPX_RANK_SPEED_SCALE", None)
         assert abs(sp.mean() - 1.0) < 0.16 and sp.min() >= 0.85 and sp.max() <= 1.15 and sp[1] == sp.min() and sp[1] < sp[0]
