@@ -363,3 +363,46 @@ def test_panel_trsm_riding_in_the_potf2_launch_gives_the_same_bits():
         for a, b in zip(res[0][4], res[rnd][4]):
             np.testing.assert_array_equal(a, b)
     assert [i for _, i in res[1][0]] == [0, 0, 0, 0, 151]
+
+
+@pytest.mark.gpu
+def test_fused_chain_steps_of_several_contexts_running_at_once_do_not_wait_for_each_other_forever():
+    """potf2_trsm_kernel's strip workgroups spin on a flag and hold a whole CU each (128 KB of LDS): three contexts factoring
+    at once ask for more spinning workgroups than the chip has CUs.  Every strip waits only for workgroup 0 of its OWN launch,
+    which is dispatched before it, so the earliest launch always finishes — no deadlock, and the same bits as one context
+    alone.  (Three host threads, one context each, 4096 / 2048 / 3000-row factorisations interleaved.)"""
+    import threading
+
+    import numpy as np
+    from gpax_amd import _lib
+
+    rng = np.random.default_rng(13)
+    mats = []
+    for n in (4096, 2048, 3000):
+        B = rng.standard_normal((n, n + 8))
+        mats.append(B @ B.T / n + 0.3 * np.eye(n))
+    ref_eng = _lib.Engine(0)
+    want = [ref_eng.potrf(A)[0] for A in mats]
+    ref_eng.close()
+    engines = [_lib.Engine(0) for _ in range(3)]
+    bad, errs = [], []
+
+    def work(t):
+        try:
+            for rep in range(6):
+                k = (t + rep) % 3
+                L, info = engines[t].potrf(mats[k])
+                if info != 0 or not np.array_equal(L, want[k]):
+                    bad.append((t, rep, k))
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not any(th.is_alive() for th in threads), "a factorisation never returned"
+    for e in engines:
+        e.close()
+    assert not errs and not bad, (errs, bad)
