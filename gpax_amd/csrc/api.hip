@@ -749,6 +749,7 @@ void gpx_destroy(gpx_ctx* ctx) {
                       &ctx->SplitK, &ctx->mean, &ctx->var,  &ctx->eps,    &ctx->draws, &ctx->tA,
                       &ctx->tB,   &ctx->tC,  &ctx->thtab,   &ctx->binfo, &ctx->bscal, &ctx->byres, &ctx->diagv, &ctx->st_eps, &ctx->st_yres,
                       &ctx->st_means, &ctx->st_samples, &ctx->st_infos, &ctx->st_vars, &ctx->st_pred, &ctx->tile_counters, &ctx->chain_flag};
+    ctx->pin_gen.release();
     for (DevBuf* b : bufs) b->release();
     ctx->pin_in.release();
     ctx->pin_out.release();
@@ -1015,15 +1016,43 @@ int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const doubl
     }
     return 0;
   }
-  SweepIO io;
-  io.kind = kind;
-  io.S = B;
-  io.jitter = jitter;
-  io.ells = ells;
-  io.scales = scales;
-  io.noises = noises;
+  // The general launch sequence.  Everything that crosses PCIe around it goes through ONE page-locked region of the context
+  // — [theta table | residuals | lml terms and gradient | pivot reports | alpha] — with asynchronous copies and a single
+  // synchronisation: a copy between the device and PAGEABLE memory (the caller's arrays, a std::vector) is staged by the
+  // runtime and waited for call by call, ~10 - 20 us each, which at N = 512 (one leapfrog of C1's NUTS: 0.26 ms on the device)
+  // was a quarter of the host-side overhead of this call.
   ctx->jitter = jitter;
-  GPX_TRY(fill_theta_table(ctx, io));
+  const int d_ = ctx->d, stride_ = d_ + (kind == GPX_KERNEL_PERIODIC ? 1 : 0);
+  const bool want_alpha = grad != nullptr && alpha != nullptr;
+  const size_t th_b = round_up64((int64_t)B * sizeof(ThetaDev), 64), y_b = round_up64((int64_t)yres_rows * N * 8, 64),
+               sc_b = round_up64((int64_t)B * SB * 8, 64), in_b = round_up64((int64_t)B * sizeof(int), 64),
+               al_b = want_alpha ? (size_t)B * N * 8 : 0;
+  if (ctx->pin_gen.cap < th_b + y_b + sc_b + in_b + al_b) {
+    GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GPX_HIP(ctx, ctx->pin_gen.ensure(2 * (th_b + y_b + sc_b + in_b + al_b)));
+  }
+  char* pbase = static_cast<char*>(ctx->pin_gen.p);
+  ThetaDev* hth = reinterpret_cast<ThetaDev*>(pbase);
+  double* hy = reinterpret_cast<double*>(pbase + th_b);
+  double* hsc = reinterpret_cast<double*>(pbase + th_b + y_b);
+  int* hin = reinterpret_cast<int*>(pbase + th_b + y_b + sc_b);
+  double* hal = reinterpret_cast<double*>(pbase + th_b + y_b + sc_b + in_b);
+  {
+    const KernelParams saved = ctx->theta;
+    for (int b = 0; b < B; ++b) { // (fill_theta_table's entries, built in place)
+      const int rc = set_theta(ctx, kind, d_, ells + (int64_t)b * stride_, scales[b]);
+      if (rc < 0) {
+        ctx->theta = saved;
+        return rc;
+      }
+      hth[b].kp = ctx->theta;
+      hth[b].diag_train = noises[b] + jitter;
+      hth[b].diag_pred = noises[b] + jitter;
+      hth[b].kdiag_pred = kdiag_value(hth[b].kp) + noises[b] + jitter;
+    }
+  }
+  GPX_TRY(ensure(ctx, ctx->thtab, (size_t)B * sizeof(ThetaDev)));
+  GPX_HIP(ctx, hipMemcpyAsync(ctx->thtab.p, hth, (size_t)B * sizeof(ThetaDev), hipMemcpyHostToDevice, ctx->stream));
   BatchPlan bp = make_plan(ctx, B, 0, false);
   bp.th = static_cast<const ThetaDev*>(ctx->thtab.p);
   GPX_TRY(ensure(ctx, ctx->binfo, (size_t)2 * B * sizeof(int)));
@@ -1033,35 +1062,33 @@ int gpx_fit_batch(gpx_ctx* ctx, int kind, int B, const double* ells, const doubl
   bp.info_cov = ctx->binfo.i() + B;
   bp.scal = ctx->bscal.d();
   bp.scal_bs = SB;
+  std::memcpy(hy, yres, (size_t)yres_rows * N * sizeof(double));
   if (yres_rows != 1) {
-    GPX_HIP(ctx, hipMemcpyAsync(ctx->byres.d(), yres, (size_t)yres_rows * N * sizeof(double),
-                                hipMemcpyHostToDevice, ctx->stream));
+    GPX_HIP(ctx, hipMemcpyAsync(ctx->byres.d(), hy, (size_t)yres_rows * N * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->stream));
     bp.yres = ctx->byres.d();
     bp.y_bs = N;
     bp.y_mod = (yres_rows == B) ? 0 : yres_rows;
   } else {
-    GPX_HIP(ctx, hipMemcpyAsync(ctx->yres.d(), yres, (size_t)N * sizeof(double), hipMemcpyHostToDevice,
-                                ctx->stream));
+    GPX_HIP(ctx, hipMemcpyAsync(ctx->yres.d(), hy, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     bp.yres = ctx->yres.d();
     bp.y_bs = 0;
   }
   GPX_TRY(dev_factor(ctx, false, bp, true));
   const int ne = n_ell(ctx->theta);
   if (grad) GPX_TRY(dev_grad(ctx, bp));
-  ctx->h_bscal.resize((size_t)B * SB);
-  ctx->h_binfo.resize((size_t)B);
-  GPX_HIP(ctx, hipMemcpyAsync(ctx->h_bscal.data(), ctx->bscal.d(), (size_t)B * SB * sizeof(double),
-                              hipMemcpyDeviceToHost, ctx->stream));
-  GPX_HIP(ctx, hipMemcpyAsync(ctx->h_binfo.data(), bp.info_train, (size_t)B * sizeof(int),
-                              hipMemcpyDeviceToHost, ctx->stream));
-  if (grad && alpha)
-    GPX_HIP(ctx, hipMemcpy2DAsync(alpha, (size_t)N * sizeof(double), ctx->alpha.d(),
-                                  (size_t)ctx->Np * sizeof(double), (size_t)N * sizeof(double), B,
-                                  hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(ctx, hipMemcpyAsync(hsc, ctx->bscal.d(), (size_t)B * SB * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(ctx, hipMemcpyAsync(hin, bp.info_train, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  if (want_alpha)
+    GPX_HIP(ctx, hipMemcpy2DAsync(hal, (size_t)N * sizeof(double), ctx->alpha.d(), (size_t)ctx->Np * sizeof(double),
+                                  (size_t)N * sizeof(double), B, hipMemcpyDeviceToHost, ctx->stream));
   GPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (want_alpha) std::memcpy(alpha, hal, (size_t)B * N * sizeof(double));
   ctx->factored = false;
   ctx->small_grad_ready = false;
   ctx->have_post = false;
+  ctx->h_binfo.assign(hin, hin + B);
+  ctx->h_bscal.assign(hsc, hsc + (size_t)B * SB);
   for (int b = 0; b < B; ++b) {
     int hinfo = ctx->h_binfo[(size_t)b];
     if (hinfo > N) hinfo = 0; // a failure at the augmentation pivot itself is not a failure of K

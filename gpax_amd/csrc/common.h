@@ -276,6 +276,7 @@ struct gpx_ctx {
   // ---- batched sweep state (gpx_predict_sweep / gpx_sweep_resident) -----------------------
   gpx::DevBuf st_eps, st_yres, st_means, st_samples, st_infos, st_vars, st_pred; // sweep I/O staging (grow-only)
   gpx::PinBuf pin_in, pin_out, pin_x;                                            // page-locked host side of it
+  gpx::PinBuf pin_gen; // gpx_fit_batch, general sequence: [theta table | residuals | results] staged page-locked (round 6)
   gpx::PinBuf pin_fit; // small-N fit batches: [theta table | residuals | results] read and written by the kernel itself
   gpx::DevBuf thtab;   // S x ThetaDev
   gpx::DevBuf binfo;   // 2 x B ints (train / cov pivots of the batch in flight)
