@@ -145,23 +145,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmArgs g, TileMap 
 // counter until none is left.  A tile's arithmetic does not depend on who computes it, so results are those of
 // gemm_nt128_kernel bit for bit.  Used where a launch's tiles differ widely in length (k ranges trimmed to a triangle)
 // and where the panel chain of the driver holds no kernel that needs a drained CU (ctx->persist_scope).
+typedef const __attribute__((address_space(4))) char* kernarg_ptr_t;
+
 template <int TAG, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt128_persist_kernel(GemmArgs g, TileMap tm, int* __restrict__ counter) {
+__global__ __launch_bounds__(256, 2) void gemm_nt128_persist_kernel(GemmArgs g_by_value, TileMap tm_by_value,
+                                                                    int* __restrict__ counter) {
   constexpr int TD = 256 * 16;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (TAG == 0) __builtin_amdgcn_s_setprio(2);
   int* s_tile = reinterpret_cast<int*>(smem + 2 * TD); // 16 B behind the two k-tile buffers (one LDS object only)
+  // The argument block (50 + 10 dwords) is re-read from the kernarg segment for every tile — scalar loads out of the
+  // constant cache, nothing against a tile of >= 10 us — instead of living in SGPRs across the tile loop: held there it took
+  // 33 - 39 of them to VGPR lanes (v_writelane / v_readlane around every use; rounds 2 - 5).  The pointer is made opaque per
+  // iteration so that the loads are not hoisted back out of the loop.
+  (void)g_by_value;
+  (void)tm_by_value;
+#if defined(__HIP_DEVICE_COMPILE__) // (the host pass of hipcc parses kernel bodies too and has no constant address space)
+  kernarg_ptr_t ka = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   for (;;) {
     if (threadIdx.x == 0) *s_tile = atomicAdd(counter, 1);
     __syncthreads();
     const int t = __builtin_amdgcn_readfirstlane(*s_tile);
+    asm volatile("" : "+s"(ka));
+    const TileMap tm = *reinterpret_cast<const __attribute__((address_space(4))) TileMap*>(ka + sizeof(GemmArgs));
     if (t >= tm.total) return;
+    const GemmArgs g = *reinterpret_cast<const __attribute__((address_space(4))) GemmArgs*>(ka);
     const int bzz = t / tm.per_slab;
     int by, bx;
     decode_tile(tm, g.lower, t - bzz * tm.per_slab, by, bx);
     nt128_tile<EPI>(g, smem, __builtin_amdgcn_readfirstlane(bx), __builtin_amdgcn_readfirstlane(by), bzz);
     __syncthreads(); // every wave is done with the k-tile buffers and has read *s_tile
   }
+#endif
 }
 
 // tiles of a (tiles_m x tiles_n) grid; lower: row by holds clamp(by + delta + 1, 0, tiles_n) tiles (delta = ti_off - tj_off)
