@@ -195,7 +195,8 @@ int launch_potf2_trsm(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int*
                       int below) {
   if (!ctx->chain_flag_zeroed) { // once per context
     if (ctx->chain_flag.ensure(64) != hipSuccess) return bad_arg(ctx, "chain flag");
-    GPX_HIP(ctx, hipMemset(ctx->chain_flag.p, 0, 64));
+    GPX_HIP(ctx, hipMemsetAsync(ctx->chain_flag.p, 0, 64, ctx->s)); // in the order of the stream the first launch goes to ...
+    GPX_HIP(ctx, hipStreamSynchronize(ctx->s));                      // ... and done before any other stream of the context uses it
     ctx->chain_flag_zeroed = true;
   }
   if (!ctx->chain_attr_set) { // 128 KB of dynamic LDS: above the default limit, per device (this context's)
