@@ -197,9 +197,9 @@ struct gpx_ctx {
   // one-outer-block chains (a single sample with the chip to itself): the panel TRSM rides in the potf2 launch (potf2.hip
   // potf2_trsm_kernel; GPX_POTF2_TRSM=0 / gpx_debug_set_potf2 "nofuse": the three-launch step)
   bool potf2_trsm = true;
-  gpx::DevBuf chain_flag; // the flag workgroup 0 of potf2_trsm_kernel publishes L^-1 through
+  gpx::DevBuf chain_flag; // the flags (one per stream) workgroup 0 of potf2_trsm_kernel publishes L^-1 through
   bool chain_flag_zeroed = false, chain_attr_set = false;
-  unsigned chain_epoch = 0;
+  unsigned chain_epoch[3] = {0, 0, 0}; // per stream of the context (main, panel, side)
   bool serialise_trailing = false; // measurement mode: every Cholesky trailing update runs alone on the chip (linalg.hip)
   // > 0 while a driver whose own panel chain holds no potf2 (the right-looking TRSM sweeps, the K^-1 = W W^T product)
   // is queueing launches: its big-tile GEMMs run persistently (GPX_PERSIST_SCOPE=0 disables)

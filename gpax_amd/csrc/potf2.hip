@@ -193,10 +193,14 @@ namespace gpx {
 // launch_gemm_nt would get it — A = C = the panel, B = L^-1 of the block, K = 128, alpha = 1, beta = 0), one launch
 int launch_potf2_trsm(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int* dInfo, int info_base, const GemmArgs& g0,
                       int below) {
+  // one flag (and epoch counter) per stream of the context: launches of ONE stream are ordered, so each finds the flag at a
+  // value only earlier launches of that stream have published; two chains of one context on two streams (the sparse path
+  // can run them so) must not publish through the same word
+  constexpr int SLOTS = 3, SLOT_STRIDE = 64; // bytes
   if (!ctx->chain_flag_zeroed) { // once per context
-    if (ctx->chain_flag.ensure(64) != hipSuccess) return bad_arg(ctx, "chain flag");
-    GPX_HIP(ctx, hipMemsetAsync(ctx->chain_flag.p, 0, 64, ctx->s)); // in the order of the stream the first launch goes to ...
-    GPX_HIP(ctx, hipStreamSynchronize(ctx->s));                      // ... and done before any other stream of the context uses it
+    if (ctx->chain_flag.ensure(SLOTS * SLOT_STRIDE) != hipSuccess) return bad_arg(ctx, "chain flag");
+    GPX_HIP(ctx, hipMemsetAsync(ctx->chain_flag.p, 0, SLOTS * SLOT_STRIDE, ctx->s));
+    GPX_HIP(ctx, hipStreamSynchronize(ctx->s)); // done before any other stream of the context uses it
     ctx->chain_flag_zeroed = true;
   }
   if (!ctx->chain_attr_set) { // 128 KB of dynamic LDS: above the default limit, per device (this context's)
@@ -204,12 +208,14 @@ int launch_potf2_trsm(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int*
                                      (int)POTF2_TRSM_LDS));
     ctx->chain_attr_set = true;
   }
+  const int slot = (ctx->s == ctx->stream) ? 0 : ((ctx->s == ctx->pstream) ? 1 : 2);
   GemmArgs g = g0;
   g.nsplit = 1;
   g.batch = 1;
-  ctx->chain_epoch += 1;
-  if (ctx->chain_epoch == 0) ctx->chain_epoch = 1; // (0 is the cleared flag)
-  const unsigned epoch = ctx->chain_epoch;
+  ctx->chain_epoch[slot] += 1;
+  if (ctx->chain_epoch[slot] == 0) ctx->chain_epoch[slot] = 1; // (0 is the cleared flag)
+  const unsigned epoch = ctx->chain_epoch[slot];
+  unsigned* flag = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->chain_flag.p) + slot * SLOT_STRIDE);
 #ifdef GPX_POTF2_TRACE
   {
     long long init[8] = {0, 0, 0, 0x7fffffffffffffffLL, 0, 0, 0, 8LL * below};
@@ -220,7 +226,7 @@ int launch_potf2_trsm(gpx_ctx* ctx, double* dA, int64_t lda, double* dLinv, int*
   {
     ProfScope ps(ctx, GPX_PROF_POTF2, 2.0 * PB * (double)PB * PB / 3.0 + 2.0 * below * TILE * (double)TILE * TILE);
     potf2_trsm_kernel<<<1 + 8 * below, 256, POTF2_TRSM_LDS, ctx->s>>>(dA, lda, dLinv, dInfo, info_base, g,
-                                                                     reinterpret_cast<unsigned*>(ctx->chain_flag.p), epoch);
+                                                                     flag, epoch);
   }
   GPX_HIP(ctx, hipGetLastError());
   return 0;
