@@ -102,6 +102,9 @@ def test_chain_kernels_fit_beside_two_resident_trailing_update_workgroups():
         assert int(r["vgpr_spill_count"]) == 0 and int(r["sgpr_spill_count"]) == 0 and int(r["private_segment_fixed_size"]) == 0
     assert 3 * 128 * 64 <= 28 * 1024 and 2 * 160 * 64 <= 28 * 1024
     assert len([n for n in rows if "fit_small_kernel" in n]) == 15  # 3 kernels x (d = 1 .. 4, generic d)
+    # the fused chain step (potf2 + panel TRSM strips in one launch, round 6): within its 128-VGPR cap, no SGPR spill either
+    fused = find("potf2_trsm_kernel")
+    assert int(fused["vgpr_count"]) <= 128 and int(fused["sgpr_spill_count"]) == 0
     # the persistent big-tile GEMM re-reads its argument block per tile instead of holding it in SGPRs across the tile loop
     # (33 - 39 of them went to VGPR lanes until round 6)
     persist = [r for n, r in rows.items() if "gemm_nt128_persist_kernel" in n]
