@@ -36,10 +36,39 @@ def shard_range(S: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def shard_ranges_weighted(S: int, weights) -> list:
+    """All blocks [(start, stop), ...] over S samples with sizes in proportion to `weights` (largest-remainder rounding,
+    ties to the lower rank) — the rule of gpx_shard_ranges_weighted, which sizes the ranks' blocks of the library's own
+    sweep by measured GPU speed (gpx_rank_calibrate).  Weights that are not all positive and finite: equal blocks."""
+    w = np.asarray(weights, dtype=np.float64).reshape(-1)
+    world = int(w.size)
+    if not (np.all(w > 0.0) and np.all(w < 1e300)):
+        return [shard_range(S, r, world) for r in range(world)]
+    tot = 0.0
+    for v in w:  # (summed in rank order, as the library does)
+        tot += float(v)
+    share = [S * (float(v) / tot) for v in w]
+    cnt = [int(x) for x in share]
+    frac = [x - c for x, c in zip(share, cnt)]
+    for _ in range(S - sum(cnt)):
+        best = 0
+        for r in range(1, world):
+            if frac[r] > frac[best]:
+                best = r
+        cnt[best] += 1
+        frac[best] = -1.0
+    out, at = [], 0
+    for c in cnt:
+        out.append((at, at + c))
+        at += c
+    return out
+
+
 def predict_sharded(engine, kind: int, X, yres, Xnew, samples: Optional[Dict[str, np.ndarray]], eps,
-                    noiseless: bool, jitter: float, comm):
+                    noiseless: bool, jitter: float, comm, weights=None):
     """The S-sample predictive sweep, sharded over comm.world ranks (`engine`: one Engine or a list of
-    contexts on this rank's GPU, see _lib.get_sweep_engines).  Inputs need only be valid on rank 0.  Returns (means (S, M), y_sampled (S, n, M), infos (S,)) on rank 0, None elsewhere."""
+    contexts on this rank's GPU, see _lib.get_sweep_engines).  Inputs need only be valid on rank 0.  weights (rank 0;
+    one positive number per rank, e.g. measured GPU speeds): block sizes in proportion, else equal blocks.  Returns (means (S, M), y_sampled (S, n, M), infos (S,)) on rank 0, None elsewhere."""
     X = comm.bcast(X)
     yres = comm.bcast(yres)
     Xnew = comm.bcast(Xnew)
@@ -48,8 +77,10 @@ def predict_sharded(engine, kind: int, X, yres, Xnew, samples: Optional[Dict[str
     noises = comm.bcast(None if samples is None else np.asarray(samples["noise"], dtype=np.float64))
     eps = comm.bcast(eps)
     S = ells.shape[0]
-    lo, hi = shard_range(S, comm.rank, comm.world)
-    counts = [shard_range(S, r, comm.world)[1] - shard_range(S, r, comm.world)[0] for r in range(comm.world)]
+    w = comm.bcast(np.ones(comm.world) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1))
+    blocks = shard_ranges_weighted(S, w) if w.size == comm.world else [shard_range(S, r, comm.world) for r in range(comm.world)]
+    lo, hi = blocks[comm.rank]
+    counts = [b - a for a, b in blocks]
     M, n = Xnew.shape[0], eps.shape[1]
     if hi > lo:
         from ._lib import concurrent_sweep

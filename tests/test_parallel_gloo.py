@@ -22,6 +22,21 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_weighted_blocks_follow_the_library_rule():
+    """parallel.shard_ranges_weighted restates gpx_shard_ranges_weighted (the blocks the ranks of a calibrated library sweep
+    work off, csrc/rccl_bind.h): the same partition for the same weights, equal weights = shard_range."""
+    from gpax_amd import _lib
+    from gpax_amd.parallel import shard_ranges_weighted
+    rng = np.random.default_rng(1)
+    for S in (0, 1, 5, 40, 999, 1000):
+        for world in (1, 2, 3, 8):
+            assert shard_ranges_weighted(S, np.ones(world)) == [shard_range(S, r, world) for r in range(world)]
+            for _ in range(5):
+                w = rng.uniform(0.85, 1.15, world)
+                assert shard_ranges_weighted(S, w) == _lib.shard_ranges_weighted(S, w)
+            assert shard_ranges_weighted(S, [1.0] * (world - 1) + [0.0]) == [shard_range(S, r, world) for r in range(world)]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -54,9 +69,13 @@ def _worker(rank, world, port, outdir):
     comm = Communicator()
     args = _problem() if rank == 0 else (None, None, None, None, None)
     res = predict_sharded(OracleEngine(), 1, *args, False, 1e-6, comm)
+    # the same sweep with blocks sized by (made-up) rank speeds: 5 samples over weights (1, 0.5[, 1.5]) = blocks of 3 + 2 /
+    # 2 + 1 + 2 — whoever computes a sample, the gathered result is the same
+    wres = predict_sharded(OracleEngine(), 1, *args, False, 1e-6, comm, weights=[1.0, 0.5, 1.5][:world] if rank == 0 else None)
     if rank == 0:
         means, draws, infos = res
-        np.savez(os.path.join(outdir, "out.npz"), means=means, draws=draws, infos=infos)
+        np.savez(os.path.join(outdir, "out.npz"), means=means, draws=draws, infos=infos, wmeans=wres[0], wdraws=wres[1],
+                 winfos=wres[2])
     else:
         assert res is None
     dist.barrier()
@@ -76,6 +95,9 @@ def test_sharded_sweep_equals_single_process(tmp_path, world):
     np.testing.assert_allclose(got["means"], means, rtol=1e-10)
     np.testing.assert_allclose(got["draws"], yy, rtol=1e-9, atol=1e-12)
     assert got["infos"].shape == (5,) and np.all(got["infos"] == 0)
+    np.testing.assert_array_equal(got["wmeans"], got["means"])
+    np.testing.assert_array_equal(got["wdraws"], got["draws"])
+    np.testing.assert_array_equal(got["winfos"], got["infos"])
 
 
 def _model_worker(rank, world, port, outdir):
