@@ -113,3 +113,30 @@ def test_chain_kernels_fit_beside_two_resident_trailing_update_workgroups():
     assert len(rows) > 100
     for n, r in rows.items():
         assert int(r["vgpr_spill_count"]) == 0 and int(r["private_segment_fixed_size"]) == 0, n
+
+
+def test_the_fused_chain_step_publishes_with_a_release_and_its_strips_do_not_invalidate_the_l2():
+    """potf2.hip potf2_trsm_kernel, read from the code object hipcc emits (no GPU needed): workgroup 0 ends with ONE
+    agent-scope release (`buffer_wbl2 sc1`, then the flag store `sc1`); the strip part — everything before the first
+    `s_endpgm` — polls the flag with an L2-bypassing load (`sc1`) between `s_sleep`s, carries NO `buffer_inv` (the per-wave
+    acquire made every strip workgroup re-fetch L^-1 from memory: profiles/r06/potf2_trsm.md; the comment in the kernel says
+    why none is needed), brings its 32 rows of L^-1 in with 32 LDS-direct loads, passes ONE barrier (before the flag) and
+    issues 2 accumulators x 32 k-steps of v_mfma_f64_16x16x4_f64 (gp.py:160-164's Cholesky, the panel TRSM of a step)."""
+    import os
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import kernel_resources as kr
+
+    asm = kr.kernel_asm(os.path.join(os.path.dirname(__file__), "..", "gpax_amd", "csrc", "potf2.hip"), "potf2_trsm_kernel")
+    ends = [m.start() for m in re.finditer(r"s_endpgm", asm)]
+    assert len(ends) == 2
+    strips, wg0 = asm[:ends[0]], asm[ends[0]:]
+    assert "buffer_inv" not in asm
+    assert len(re.findall(r"buffer_wbl2 sc1", wg0)) == 1 and "buffer_wbl2" not in strips
+    assert re.search(r"global_store_dword [^\n]* sc1", wg0[wg0.index("buffer_wbl2 sc1"):])
+    assert "s_sleep" in strips and re.search(r"global_load_dword [^\n]* sc1", strips)
+    assert len(re.findall(r"buffer_load_dwordx4 [^\n]* lds", strips)) == 32
+    assert len(re.findall(r"v_mfma_f64_16x16x4", strips)) == 64
+    assert len(re.findall(r"s_barrier", strips)) == 1
+    assert strips.index("s_barrier") < strips.index("s_sleep")

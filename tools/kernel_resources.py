@@ -45,6 +45,21 @@ def resources(src, extra=()):
     return rows
 
 
+def kernel_asm(src, name_part, extra=()):
+    """The gfx950 assembly of the ONE kernel of `src` whose mangled name contains `name_part` (label to end of function)."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+               "--cuda-device-only", "-S", src, "-o", out, *extra]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    labels = [m.group(1) for m in re.finditer(r"^(\S*%s\S*):\s" % re.escape(name_part), text, re.M)]
+    assert len(labels) == 1, labels
+    start = text.index("\n" + labels[0] + ":")
+    end = text.index(".Lfunc_end", start)
+    return text[start:end]
+
+
 def main():
     srcs = sys.argv[1:] or sorted(os.path.join(ROOT, "gpax_amd", "csrc", f)
                                   for f in os.listdir(os.path.join(ROOT, "gpax_amd", "csrc")) if f.endswith(".hip"))
