@@ -25,7 +25,7 @@ import numpy as np
 from .. import _lib
 from ..infer import dist
 from ..infer.nuts import run_nuts
-from ..infer.primitives import trace_sites
+from ..infer.primitives import deterministic, plate, sample, trace_sites
 from ..kernels.kernels import kernel_name
 from ..utils import threefry as _threefry
 from ..utils.utils import rng_from_key, split_in_batches
@@ -172,15 +172,7 @@ class ExactGP:
         device (gpx_factor).  y = None: the log prior alone.  NaN when K(theta) is not positive definite."""
         X = self._set_data(X)
         sites = self._sites()
-        theta = {s.name: (np.full(s.shape, float(s.dist.median())) if s.shape else float(s.dist.median()))
-                 for s in sites}
-        if params is not None:
-            theta.update({k: v for k, v in params.items() if k in theta})
-        theta = self._with_deterministic(theta)
-        val = 0.0
-        with np.errstate(divide="ignore", invalid="ignore"):
-            for s_ in sites:
-                val += float(np.sum(s_.dist.log_prob(np.asarray(theta[s_.name], dtype=np.float64).reshape(-1))))
+        theta, val = self._theta_and_log_prior(sites, params)
         if y is None:
             return val
         y = np.asarray(y, dtype=np.float64).squeeze()
@@ -190,6 +182,45 @@ class ExactGP:
         lml, info = eng.factor(self._kind, self._ell(theta), self._scalar(theta["k_scale"]),
                                self._scalar(theta["noise"]), jitter, y - self._mean(X, theta))
         return val + lml if info == 0 else float("nan")
+
+    def _theta_and_log_prior(self, sites, params):
+        """theta: site name -> constrained value (`params` where given, the prior median elsewhere, plus the deterministic
+        sites) and the sum of the site log-densities there — the prior part of what `model` returns."""
+        theta = {s.name: (np.full(s.shape, float(s.dist.median())) if s.shape else float(s.dist.median()))
+                 for s in sites}
+        if params is not None:
+            theta.update({k: v for k, v in params.items() if k in theta})
+        theta = self._with_deterministic(theta)
+        val = 0.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for s_ in sites:
+                val += float(np.sum(s_.dist.log_prob(np.asarray(theta[s_.name], dtype=np.float64).reshape(-1))))
+        return theta, val
+
+    def _unconstrained(self, sites, theta) -> np.ndarray:
+        """u with theta = T(u), site by site (the inverse of _unpack)."""
+        return np.concatenate([np.asarray(s.dist.inverse(np.asarray(theta[s.name], dtype=np.float64).reshape(-1)),
+                                          dtype=np.float64).reshape(-1) for s in sites])
+
+    class _TrainingData:
+        """`with model._TrainingData(model, X, y):` — the model's training data swapped for the block (what the `model`
+        methods of the subclasses evaluate their log joint on), put back afterwards whatever happens inside."""
+
+        def __init__(self, m, X, y):
+            self.m, self.new = m, (X, y)
+
+        def __enter__(self):
+            m = self.m
+            self.old = (m.X_train, m.y_train)
+            m.X_train, m.y_train = self.new
+            m._data_version += 1
+            return m
+
+        def __exit__(self, *exc):
+            m = self.m
+            m.X_train, m.y_train = self.old
+            m._data_version += 1
+            return False
 
     def _kernel_sites(self):
         """k_length (plate 'ard'), k_scale, period — default priors (gp.py:229-247) or the traced kernel_prior."""
@@ -206,12 +237,31 @@ class ExactGP:
                     raise ValueError(f"k_length site has {sx.size} entries for input_dim {self.kernel_dim}")
             self._det.update({k: v for k, v in det.items() if k in ("k_length", "k_scale", "period")})
             return sites
-        length_dist = self.lengthscale_prior_dist if self.lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
-        sites = [_Site("k_length", (self.kernel_dim,), length_dist),  # plate "ard", gp.py:238-239
-                 _Site("k_scale", (), dist.LogNormal(0.0, 1.0))]     # gp.py:241
-        if self.kernel_name == "Periodic":
-            sites.append(_Site("period", (), dist.LogNormal(0.0, 1.0)))  # gp.py:243-244
+        # the default priors are the program the reference runs (gp.py:229-247), traced like a user's kernel_prior: a
+        # subclass that overrides _sample_kernel_params — as the reference's own subclasses do — changes the sites
+        sites, returned, det = self._traced(self._sample_kernel_params, "_sample_kernel_params")
+        self._det.update({k: v for k, v in det.items() if k in ("k_length", "k_scale", "period")})
         return sites
+
+    def _sample_noise(self):
+        """The reference's default noise prior as a program (gp.py:222-227): `sample("noise", noise_prior_dist or
+        LogNormal(0, 1))` — meaningful inside a trace (models trace it once to learn the site); override to change it."""
+        noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
+        return sample("noise", noise_dist)
+
+    def _sample_kernel_params(self, output_scale=True) -> Dict[str, np.ndarray]:
+        """The reference's default kernel priors as a program (gp.py:229-247): k_length under plate 'ard'
+        (lengthscale_prior_dist or LogNormal(0, 1)), k_scale LogNormal(0, 1) — or the constant 1 when not output_scale —
+        and, for the Periodic kernel, period LogNormal(0, 1)."""
+        length_dist = self.lengthscale_prior_dist if self.lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
+        with plate("ard", self.kernel_dim):  # gp.py:238-239
+            length = sample("k_length", length_dist)
+        if output_scale:
+            scale = sample("k_scale", dist.LogNormal(0.0, 1.0))  # gp.py:241
+        else:
+            scale = deterministic("k_scale", 1.0)
+        period = sample("period", dist.LogNormal(0.0, 1.0)) if self.kernel_name == "Periodic" else None  # gp.py:243-244
+        return {"k_length": length, "k_scale": scale, "period": period}
 
     def _noise_sites(self):
         if self.noise_prior is not None:  # gp.py:146-147 (deprecated there)
@@ -219,8 +269,10 @@ class ExactGP:
             if len(sites) != 1 or sites[0].name != "noise" or sites[0].size != 1:
                 raise ValueError("noise_prior must sample exactly one scalar site named 'noise'")
             return sites
-        noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
-        return [_Site("noise", (), noise_dist)]  # gp.py:222-227
+        sites, _, _ = self._traced(self._sample_noise, "_sample_noise")  # gp.py:222-227
+        if len(sites) != 1 or sites[0].name != "noise" or sites[0].size != 1:
+            raise ValueError("_sample_noise must sample exactly one scalar site named 'noise'")
+        return sites
 
     def _sites(self):
         return self._kernel_sites() + self._noise_sites() + self._mean_prior_sites()

@@ -84,6 +84,27 @@ class VarNoiseGP(ExactGP):
         sites += [s for s in super()._sites() if s.name != "noise"]      # no inferred scalar noise
         return sites
 
+    def model(self, X, y=None, params: Optional[Dict[str, np.ndarray]] = None, **kwargs: float) -> float:
+        """What the reference's NumPyro program defines (hskgp.py:105-153), evaluated as ExactGP.model evaluates the exact
+        one: site log-densities + the latent site's own density log N(log_var | log noise_mean_fn, k_noise) +
+        log N(y | m, k + jitter I + diag(exp(log_var))) at `params` (default: prior medians, log_var = 0).  y = None:
+        without the last term."""
+        X = self._set_data(X)
+        jitter = float(kwargs.get("jitter", 1e-6))
+        yy = np.zeros(X.shape[0]) if y is None else np.asarray(y, dtype=np.float64).squeeze()
+        with self._TrainingData(self, X, yy):
+            sites = self._sites()
+            theta, val = self._theta_and_log_prior(sites, params)
+            if y is not None:
+                v, _ = self._log_joint(sites, self._unconstrained(sites, theta), jitter, jacobian=False, want_grad=False)
+                return float(v) if np.isfinite(v) else float("nan")
+            eng = self._engine()
+            eng.set_diag(None)
+            lv_res = np.asarray(theta["log_var"], dtype=np.float64).reshape(-1) - self._noise_loc(X, theta)
+            lml2, info2 = eng.factor(self._noise_kind, self._noise_ell(theta), self._scalar(theta["k_noise_scale"]), 0.0,
+                                     jitter, lv_res)
+            return val + lml2 if info2 == 0 else float("nan")
+
     def _noise_loc(self, X, params) -> np.ndarray:
         """Prior mean of log_var: log(noise_mean_fn(X[, params])) or zeros (hskgp.py:120-128)."""
         if self.noise_mean_fn is None:

@@ -48,6 +48,33 @@ class MeasuredNoiseGP(ExactGP):
         theta["noise"] = 0.0
         return theta
 
+    def model(self, X, y=None, measured_noise=None, params: Optional[Dict[str, np.ndarray]] = None, **kwargs) -> float:
+        """What the reference's NumPyro program defines (mngp.py:74-98), evaluated as ExactGP.model evaluates the exact one:
+        sum of the site log-densities + log N(y | m, k(theta) + jitter I + diag(measured_noise)) at `params` (default: the
+        prior medians) — there is no noise site, noise is the deterministic 0.  y = None: the log prior alone."""
+        from .. import _lib
+        X = self._set_data(X)
+        theta, val = self._theta_and_log_prior(self._sites(), params)
+        theta["noise"] = 0.0
+        if y is None:
+            return val
+        if measured_noise is None:
+            raise ValueError("MeasuredNoiseGP.model needs the measured noise variances of the training points")
+        mn = np.ascontiguousarray(np.asarray(measured_noise, dtype=np.float64).reshape(-1))
+        if mn.shape[0] != X.shape[0]:
+            raise ValueError("measured_noise must have one value per training point")
+        y = np.asarray(y, dtype=np.float64).squeeze()
+        eng = _lib.get_engine(self._device)
+        eng.set_train(X)
+        eng.set_diag(mn)
+        try:  # the per-point diagonal must not outlive this call on the shared context
+            lml, info = eng.factor(self._kind, self._ell(theta), self._scalar(theta["k_scale"]), 0.0,
+                                   float(kwargs.get("jitter", 1e-6)), y - self._mean(X, theta))
+        finally:
+            eng.set_diag(None)
+            eng._diag_key = None
+        return val + lml if info == 0 else float("nan")
+
     def _engine(self):
         eng = super()._engine()
         want = self.measured_noise if self._use_measured else None

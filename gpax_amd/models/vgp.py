@@ -51,6 +51,24 @@ class vExactGP(ExactGP):
     def _tasks(self) -> int:
         return self.X_train.shape[0]
 
+    def model(self, X, y=None, params: Optional[Dict[str, np.ndarray]] = None, **kwargs: float) -> float:
+        """What the reference's NumPyro program defines (vgp.py:62-96), evaluated as ExactGP.model evaluates the exact one:
+        the site log-densities (per-task plates) + the sum over the T tasks of log N(y_t | m_t, k_t + (noise_t + jitter) I)
+        at `params` (default: the prior medians).  X (T, N, d), y (T, N); y = None: the log prior alone."""
+        jitter = float(kwargs.get("jitter", 1e-6))
+        if y is None:
+            X = self._set_data(X)
+            yy = np.zeros(X.shape[:2])
+        else:
+            X, yy = self._set_data(X, y)
+        with self._TrainingData(self, X, yy):
+            sites = self._sites()
+            theta, val = self._theta_and_log_prior(sites, params)
+            if y is None:
+                return val
+            v, _ = self._log_joint(sites, self._unconstrained(sites, theta), jitter, jacobian=False)
+            return float(v) if np.isfinite(v) else float("nan")
+
     # -- sample sites (vgp.py:98-120) -------------------------------------------------------------------
     def _sites(self):
         T = self._tasks

@@ -566,6 +566,59 @@ def test_sparse_model_returns_the_vfe_log_joint():
     assert np.isfinite(m2.model(X, y, params=m2.get_samples()))
 
 
+def test_default_priors_are_overridable_programs_like_the_references():
+    """gp.py:222-247: `_sample_noise` / `_sample_kernel_params(output_scale)` ARE the default priors — the reference's own
+    subclasses override or re-parametrise them (corgp.py:68 calls _sample_kernel_params(output_scale=False)).  Here they are
+    the same programs over gpax_amd.sample / plate / deterministic, traced once: the default sites are unchanged, and a
+    subclass that overrides them changes what fit() samples."""
+    import gpax_amd
+    m = ExactGP(2, "Periodic", lengthscale_prior_dist=dist.Gamma(2.0, 5.0), noise_prior_dist=dist.HalfNormal(0.2))
+    assert [(s.name, s.shape, type(s.dist).__name__) for s in m._sites()] == [
+        ("k_length", (2,), "Gamma"), ("k_scale", (), "LogNormal"), ("period", (), "LogNormal"), ("noise", (), "HalfNormal")]
+    with pytest.raises(RuntimeError):
+        m._sample_noise()  # only meaningful while a model traces it
+
+    class UnitScale(ExactGP):
+        def _sample_kernel_params(self, output_scale=True):
+            return super()._sample_kernel_params(output_scale=False)
+
+        def _sample_noise(self):
+            return gpax_amd.sample("noise", dist.HalfNormal(0.3))
+
+    X, y = get_dummy_data()
+    u = UnitScale(1, "RBF")
+    assert [(s.name, type(s.dist).__name__) for s in u._sites()] == [("k_length", "LogNormal"), ("noise", "HalfNormal")]
+    u.fit(get_keys()[0], X, y, num_warmup=10, num_samples=10, progress_bar=False, print_summary=False)
+    smp = u.get_samples()
+    assert set(smp) == {"k_length", "k_scale", "noise"} and np.all(smp["k_scale"] == 1.0)
+    lp = dist.LogNormal(0, 1).log_prob(np.array([0.9]))[0] + dist.HalfNormal(0.3).log_prob(np.array([0.2]))[0]
+    assert abs(u.model(X, None, params={"k_length": np.array([0.9]), "noise": 0.2}) - lp) < 1e-12
+
+
+def test_place_prior_helpers_inside_a_mean_fn_prior():
+    """priors.py:13-68 with the import swapped: the place_*_prior helpers register their site with the model's trace."""
+    from gpax_amd import priors
+    X, y = get_dummy_data()
+
+    def mean_fn(x, p):
+        return p["a"] * x[:, 0] + p["b"]
+
+    def mean_prior():
+        return {"a": priors.place_normal_prior("a", 1.0, 2.0), "b": priors.place_halfnormal_prior("b", 0.5)}
+
+    m = ExactGP(1, "RBF", mean_fn=mean_fn, mean_fn_prior=mean_prior)
+    got = {s.name: s.dist for s in m._sites()}
+    assert isinstance(got["a"], dist.Normal) and isinstance(got["b"], dist.HalfNormal)
+    assert (got["a"].loc, got["a"].scale, got["b"].scale) == (1.0, 2.0, 0.5)
+    for fn, args, kind in [(priors.place_lognormal_prior, ("c", 0.0, 0.3), dist.LogNormal),
+                           (priors.place_uniform_prior, ("c", None, None, np.array([1.0, 4.0])), dist.Uniform),
+                           (priors.place_gamma_prior, ("c", None, None, np.array([1.0, 4.0])), dist.Gamma)]:
+        sites = ExactGP(1, "RBF", mean_fn=lambda x, p: p["c"] * x[:, 0], mean_fn_prior=lambda: {"c": fn(*args)})._sites()
+        assert isinstance({s.name: s.dist for s in sites}["c"], kind)
+    m.fit(get_keys()[0], X, y, num_warmup=5, num_samples=5, progress_bar=False, print_summary=False)
+    assert {"a", "b"} <= set(m.get_samples())
+
+
 def test_sample_from_prior_is_mvn_sample_of_the_prior_draws():
     """gp.py:401-408 against the oracle's mvn_sample: same generator, same consumption order (sites, then eps)."""
     from gpax_amd.utils.utils import rng_from_key

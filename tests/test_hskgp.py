@@ -133,3 +133,24 @@ def test_unsupported_arguments():
         VarNoiseGP(1, "RBF", noise_kernel="Periodic")
     with pytest.raises(NotImplementedError):
         VarNoiseGP(1, "RBF", noise_kernel_prior=lambda: {})
+
+
+def test_model_returns_the_log_joint_of_both_gps():
+    """VarNoiseGP.model(X, y) (hskgp.py:105-153): priors + log N(log_var | log noise_fn, k_noise) + log N(y | 0, k + diag(exp
+    log_var)); y = None drops the last term.  The model's own training data are left alone."""
+    X = np.linspace(0.0, 7.0, 8)
+    y = np.sin(X) + 0.1 * np.cos(5 * X)
+    m = VarNoiseGP(1, "Matern", noise_kernel="RBF")
+    m.X_train, m.y_train = m._set_data(X[:5], y[:5])
+    lv = 0.2 * np.cos(X)
+    params = {"k_length": np.array([0.8]), "k_scale": 1.2, "k_noise_length": 0.6, "k_noise_scale": 0.9, "log_var": lv}
+    full = m.model(X, y, params=params)
+    expect = ref.varnoise_log_likelihood(X[:, None], y, params, kernel="Matern", noise_kernel_name="RBF", jitter=1e-6,
+                                         noise_loc=np.zeros(8))
+    lp = sum(dist.LogNormal(0, 1).log_prob(np.array([v]))[0] for v in (0.8, 1.2, 0.6, 0.9))
+    assert abs(full - (lp + expect)) < 1e-9 * abs(lp + expect)
+    p2 = {"k_length": np.array([0.6]), "k_scale": 0.9, "noise": 0.0}
+    lml2 = ref.exactgp_log_likelihood(X[:, None], lv, p2, kernel="RBF", jitter=1e-6)
+    assert abs(m.model(X, None, params=params) - (lp + lml2)) < 1e-9 * abs(lp + lml2)
+    assert m.X_train.shape == (5, 1) and m.y_train.shape == (5,)  # untouched
+    assert np.isfinite(m.model(X, y))

@@ -154,3 +154,23 @@ def test_second_fit_on_the_same_X_uploads_the_new_measured_noise():
     vals = [v[0] for v in seen if v is not None]
     assert 0.01 in vals and 5.0 in vals
     assert vals.index(5.0) > vals.index(0.01)
+
+
+def test_model_returns_the_log_joint_with_the_measured_noise_on_the_diagonal():
+    """MeasuredNoiseGP.model(X, y, measured_noise) (mngp.py:74-98): priors + log N(y | 0, k + jitter I + diag(measured_noise));
+    no noise site (the deterministic 0).  The inherited ExactGP.model used to fail on the missing site."""
+    from gpax_amd.infer import dist
+    X, y, mn = get_dummy_data()
+    m = MeasuredNoiseGP(1, "Matern")
+    params = {"k_length": np.array([0.7]), "k_scale": 1.4}
+    lp = dist.LogNormal(0, 1).log_prob(np.array([0.7]))[0] + dist.LogNormal(0, 1).log_prob(np.array([1.4]))[0]
+    assert abs(m.model(X, None, params=params) - lp) < 1e-12
+    full = m.model(X, y, mn, params=params)
+    p = {"k_length": np.array([0.7]), "k_scale": 1.4, "noise": 0.0}
+    expect = ref.exactgp_log_likelihood(X[:, None], y, p, kernel="Matern", jitter=1e-6, measured_noise=mn)
+    assert abs(full - (lp + expect)) < 1e-9 * abs(expect)
+    assert m.model(X, y, 10.0 * mn, params=params) != full and np.isfinite(m.model(X, y, mn))
+    with pytest.raises(ValueError):
+        m.model(X, y, params=params)
+    with pytest.raises(ValueError):
+        m.model(X, y, mn[:-1], params=params)

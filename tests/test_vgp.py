@@ -265,3 +265,22 @@ def test_per_task_shared_lengthscale_gradient_matches_finite_differences(shape):
         um[i] -= h
         fd[i] = (m._log_joint(sites, up, 1e-6, True)[0] - m._log_joint(sites, um, 1e-6, True)[0]) / (2 * h)
     np.testing.assert_allclose(grad, fd, rtol=2e-5, atol=2e-6)
+
+
+def test_model_returns_the_sum_of_the_task_log_joints():
+    """vExactGP.model(X, y) (vgp.py:62-96): per-task priors + the sum over tasks of the exact-GP log-likelihoods; y = None:
+    the priors.  The inherited ExactGP.model knew nothing of the task axis."""
+    X, y = get_dummy_data()
+    m = vExactGP(1, "Matern")
+    T = 3
+    params = {"k_length": np.array([[0.7], [0.9], [1.1]]), "k_scale": np.array([1.2, 1.0, 0.8]), "noise": np.array([0.1, 0.2, 0.3])}
+    ln = dist.LogNormal(0, 1)
+    lp = ln.log_prob(params["k_length"].reshape(-1)).sum() + ln.log_prob(params["k_scale"]).sum() + ln.log_prob(params["noise"]).sum()
+    assert abs(m.model(X, None, params=params) - lp) < 1e-12
+    Xs = m._set_data(X)
+    expect = sum(ref.exactgp_log_likelihood(Xs[t], y[t], {"k_length": params["k_length"][t], "k_scale": params["k_scale"][t],
+                                                          "noise": params["noise"][t]}, kernel="Matern", jitter=1e-6)
+                 for t in range(T))
+    full = m.model(X, y, params=params)
+    assert abs(full - (lp + expect)) < 1e-9 * abs(lp + expect)
+    assert m.X_train is None and np.isfinite(m.model(X, y))
