@@ -6,7 +6,7 @@ mean function.
 The reference's auto_*_priors return a callable that runs numpyro.sample per parameter; models here take
 `mean_fn_prior` as a dict name -> distribution, so the auto_* helpers return that dict (same parameter
 discovery: the function's signature minus its leading arguments).  The place_*_prior functions are the reference's
-(priors.py:13-68) with the import swapped — `gpax_amd.sample` instead of `numpyro.sample` — for use inside a prior
+(priors.py:18-68) with the import swapped — `gpax_amd.sample` instead of `numpyro.sample` — for use inside a prior
 callable a model traces (mean_fn_prior / kernel_prior / noise_prior).  The *_kernel_priors variants only exist to build
 NumPyro programs for custom kernels, which have no MI355X path.
 """
@@ -61,31 +61,31 @@ def uniform_dist(low: float = None, high: float = None, input_vec: np.ndarray = 
 
 
 def place_normal_prior(param_name: str, loc: float = 0.0, scale: float = 1.0):
-    """sample(param_name, Normal(loc, scale)) (priors.py:13-19) — inside a prior callable passed to a model."""
+    """sample(param_name, Normal(loc, scale)) (priors.py:18-24) — inside a prior callable passed to a model."""
     from ..infer.primitives import sample
     return sample(param_name, normal_dist(loc, scale))
 
 
 def place_lognormal_prior(param_name: str, loc: float = 0.0, scale: float = 1.0):
-    """sample(param_name, LogNormal(loc, scale)) (priors.py:22-28)."""
+    """sample(param_name, LogNormal(loc, scale)) (priors.py:27-33)."""
     from ..infer.primitives import sample
     return sample(param_name, lognormal_dist(loc, scale))
 
 
 def place_halfnormal_prior(param_name: str, scale: float = 1.0):
-    """sample(param_name, HalfNormal(scale)) (priors.py:31-37)."""
+    """sample(param_name, HalfNormal(scale)) (priors.py:36-42)."""
     from ..infer.primitives import sample
     return sample(param_name, halfnormal_dist(scale))
 
 
 def place_uniform_prior(param_name: str, low: float = None, high: float = None, X: np.ndarray = None):
-    """sample(param_name, Uniform(low, high)), missing bounds from the range of X (priors.py:40-52)."""
+    """sample(param_name, Uniform(low, high)), missing bounds from the range of X (priors.py:45-55)."""
     from ..infer.primitives import sample
     return sample(param_name, uniform_dist(low, high, X))
 
 
 def place_gamma_prior(param_name: str, c: float = None, r: float = None, X: np.ndarray = None):
-    """sample(param_name, Gamma(c, r)), a missing shape from the range of X (priors.py:55-68)."""
+    """sample(param_name, Gamma(c, r)), a missing shape from the range of X (priors.py:58-68)."""
     from ..infer.primitives import sample
     return sample(param_name, gamma_dist(c, r, X))
 

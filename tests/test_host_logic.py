@@ -596,7 +596,7 @@ def test_default_priors_are_overridable_programs_like_the_references():
 
 
 def test_place_prior_helpers_inside_a_mean_fn_prior():
-    """priors.py:13-68 with the import swapped: the place_*_prior helpers register their site with the model's trace."""
+    """priors.py:18-68 with the import swapped: the place_*_prior helpers register their site with the model's trace."""
     from gpax_amd import priors
     X, y = get_dummy_data()
 
