@@ -75,9 +75,10 @@ class VarNoiseGP(ExactGP):
     # -- sites (hskgp.py:102-165) -----------------------------------------------------------------------
     def _sites(self):
         N = self.X_train.shape[0]
-        nl = self.noise_lengthscale_prior_dist if self.noise_lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
-        sites = [_Site("k_noise_scale", (), dist.LogNormal(0.0, 1.0)),  # hskgp.py:163
-                 _Site("k_noise_length", (), nl)]                        # hskgp.py:164 (a scalar, no ARD plate)
+        # the noise kernel's default priors are the reference's program (hskgp.py:155-162), traced — overridable
+        sites, _, _ = self._traced(self._sample_noise_kernel_params, "_sample_noise_kernel_params")
+        if [(sx.name, sx.size) for sx in sites] != [("k_noise_scale", 1), ("k_noise_length", 1)]:
+            raise ValueError("_sample_noise_kernel_params must sample the scalar sites k_noise_scale and k_noise_length")
         for name, d in (self.noise_mean_fn_prior or {}).items():
             sites.append(_Site(name, (), d))
         sites.append(_Site("log_var", (N,), _Flat()))                    # hskgp.py:131-134
@@ -104,6 +105,15 @@ class VarNoiseGP(ExactGP):
             lml2, info2 = eng.factor(self._noise_kind, self._noise_ell(theta), self._scalar(theta["k_noise_scale"]), 0.0,
                                      jitter, lv_res)
             return val + lml2 if info2 == 0 else float("nan")
+
+    def _sample_noise_kernel_params(self) -> Dict[str, np.ndarray]:
+        """The reference's default priors of the noise kernel as a program (hskgp.py:155-162): k_noise_scale
+        LogNormal(0, 1), k_noise_length noise_lengthscale_prior_dist or LogNormal(0, 1) — a scalar, no ARD plate."""
+        from ..infer.primitives import sample
+        nl = self.noise_lengthscale_prior_dist if self.noise_lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
+        noise_scale = sample("k_noise_scale", dist.LogNormal(0.0, 1.0))
+        noise_length = sample("k_noise_length", nl)
+        return {"k_noise_length": noise_length, "k_noise_scale": noise_scale}
 
     def _noise_loc(self, X, params) -> np.ndarray:
         """Prior mean of log_var: log(noise_mean_fn(X[, params])) or zeros (hskgp.py:120-128)."""

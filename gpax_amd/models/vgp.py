@@ -95,24 +95,44 @@ class vExactGP(ExactGP):
                     raise ValueError(f"vExactGP kernel_prior: site {sx.name!r} has shape {tuple(sx.shape)}; with {T} tasks "
                                      f"it must be one of {ok} (the kernel is vmapped over the task axis, vgp.py:84)")
             return sites
-        # The reference draws k_length from LogNormal(0, 1) unconditionally and hands `lengthscale_prior_dist`
-        # to k_scale (vgp.py:111-113); mirrored as is.
-        scale_dist = self.lengthscale_prior_dist if self.lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
-        sites = [_Site("k_length", (T, self.kernel_dim), dist.LogNormal(0.0, 1.0)),
-                 _Site("k_scale", (T,), scale_dist)]
-        if self.kernel_name == "Periodic":
-            sites.append(_Site("period", (T,), dist.LogNormal(0.0, 1.0)))
+        # the default priors are the reference's program (vgp.py:101-120), traced — a subclass may override it
+        sites, _, det = self._traced(lambda: self._sample_kernel_params(task_dim=T), "_sample_kernel_params")
+        if det:
+            raise NotImplementedError("vExactGP: deterministic kernel sites have no per-task MI355X path")
         return sites
+
+    def _sample_kernel_params(self, task_dim: int = None) -> Dict[str, np.ndarray]:
+        """The reference's default kernel priors as a program (vgp.py:101-120): k_length LogNormal(0, 1) under the plates
+        (task, dim -2) x (lengthscale, dim -1); k_scale — which the reference hands `lengthscale_prior_dist` to, mirrored
+        as is — and period under a task plate."""
+        from ..infer.primitives import plate, sample
+        length_dist = self.lengthscale_prior_dist if self.lengthscale_prior_dist is not None else dist.LogNormal(0.0, 1.0)
+        with plate("plate_1", task_dim, dim=-2):  # task dimension
+            with plate("lengthscale", self.kernel_dim, dim=-1):
+                length = sample("k_length", dist.LogNormal(0.0, 1.0))
+        period = None
+        with plate("plate_2", task_dim):
+            scale = sample("k_scale", length_dist)
+            if self.kernel_name == "Periodic":
+                period = sample("period", dist.LogNormal(0.0, 1.0))
+        return {"k_length": length, "k_scale": scale, "period": period}
+
+    def _sample_noise(self, task_dim: int = None):
+        """sample("noise", noise_prior_dist or LogNormal(0, 1)) under plate "noise_plate" (vgp.py:89-99)."""
+        from ..infer.primitives import plate, sample
+        noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
+        with plate("noise_plate", task_dim):
+            return sample("noise", noise_dist)
 
     def _task_noise_sites(self, T):
         if self.noise_prior is not None:  # vgp.py:74-75
             sites, _, _ = self._traced(self.noise_prior, "noise_prior")
-            if len(sites) != 1 or sites[0].name != "noise" or tuple(sites[0].shape) not in [(T,), (T, 1)]:
-                raise ValueError(f"vExactGP noise_prior must sample exactly one site 'noise' of shape ({T},): one "
-                                 "noise variance per task (vgp.py:74-75, 84)")
-            return sites
-        noise_dist = self.noise_prior_dist if self.noise_prior_dist is not None else dist.LogNormal(0.0, 1.0)
-        return [_Site("noise", (T,), noise_dist)]  # plate "noise_plate", vgp.py:89-96
+        else:
+            sites, _, _ = self._traced(lambda: self._sample_noise(T), "_sample_noise")
+        if len(sites) != 1 or sites[0].name != "noise" or tuple(sites[0].shape) not in [(T,), (T, 1)]:
+            raise ValueError(f"vExactGP noise prior must sample exactly one site 'noise' of shape ({T},): one "
+                             "noise variance per task (vgp.py:74-75, 84)")
+        return sites
 
     def _ells(self, theta) -> np.ndarray:
         """(T, n_ell): per-task lengthscales (+ period)."""
