@@ -14,6 +14,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 KERNEL_KINDS = {"RBF": 0, "Matern": 1, "Periodic": 2}
+KIND_R2 = 3  # gpx_gram only (include/gpx.h GPX_KERNEL_R2): the squared scaled distance itself
 KIND_PERIODIC = 2
 MAX_DIM = 16
 

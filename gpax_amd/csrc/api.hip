@@ -801,8 +801,10 @@ int gpx_gram(gpx_ctx* ctx, int kind, const double* X, int n, const double* Z, in
   KernelParams kp{};
   {
     KernelParams saved = ctx->theta;
-    GPX_TRY(set_theta(ctx, kind, d, ell, scale));
+    // GPX_KERNEL_R2: the lengthscales as for the RBF kernel; only this entry point knows the kind
+    GPX_TRY(set_theta(ctx, kind == GPX_KERNEL_R2 ? GPX_KERNEL_RBF : kind, d, ell, scale));
     kp = ctx->theta;
+    if (kind == GPX_KERNEL_R2) kp.kind = GPX_KERNEL_R2;
     ctx->theta = saved;
   }
   const int64_t ld = pick_ld(m);

@@ -37,7 +37,9 @@ enum { GPX_POTF2_SLIM = 0, GPX_POTF2_TILE = 2 }; // gpx_ctx::potf2_mode
 // fit step (fit_small.hip), so that both produce the same matrix bit for bit
 template <int KIND>
 __device__ __forceinline__ double kernel_value(double r2, double scale) {
-  if (KIND == GPX_KERNEL_RBF) {
+  if (KIND == GPX_KERNEL_R2) { // gpx_gram only: the squared scaled distance itself (kernels.py:28-41)
+    return r2;
+  } else if (KIND == GPX_KERNEL_RBF) {
     return scale * exp(-0.5 * r2);
   } else if (KIND == GPX_KERNEL_PERIODIC) { // r2 carries sum_k (sin(pi (x_k - z_k) / p) / l_k)^2
     return scale * exp(-2.0 * r2);

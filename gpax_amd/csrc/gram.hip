@@ -176,7 +176,10 @@ int launch_gram_padded(gpx_ctx* ctx, const KernelParams& kp, const double* dX, i
   // algorithmic bytes: 8*n*m written (+ inputs); SURVEY 8(d): a symmetric build may claim the
   // full 8 n m.
   ProfScope ps(ctx, GPX_PROF_GRAM, 8.0 * (double)n * (double)m * (batch > 1 ? batch : 1));
-  if (kp.kind == GPX_KERNEL_RBF)
+  if (kp.kind == GPX_KERNEL_R2)
+    gram_dispatch<GPX_KERNEL_R2>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
+                                 add_diag, lower_only, dOut, ld, out_bs, th, diag_sel, ts, diag_vec);
+  else if (kp.kind == GPX_KERNEL_RBF)
     gram_dispatch<GPX_KERNEL_RBF>(kp, grid, ctx->s, dX, n, n_pad, dZ, m, m_pad, diag_add,
                                   add_diag, lower_only, dOut, ld, out_bs, th, diag_sel, ts, diag_vec);
   else if (kp.kind == GPX_KERNEL_PERIODIC)

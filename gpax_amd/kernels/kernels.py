@@ -33,6 +33,15 @@ def _scalar(v, name):
     return float(a[0])
 
 
+def square_scaled_distance(X, Z, lengthscale=1.0) -> np.ndarray:
+    """Squared distance between X and Z scaled by the lengthscale (gpax/kernels/kernels.py:28-41), on the GPU: the r^2 the
+    Gram kernels evaluate, by itself — the direct sum_k ((x_k - z_k) / ell_k)^2 (never negative; the reference's expansion
+    ||x/l||^2 - 2 x.z/l^2 + ||z/l||^2 clipped at 0 agrees with it to rounding).  lengthscale: scalar or (d,)."""
+    X, Z = _as2d(X), _as2d(Z)
+    ell = _lib.broadcast_lengthscale(lengthscale, X.shape[1])
+    return _lib.get_engine().gram(_lib.KIND_R2, X, Z, ell, 1.0, 0.0, False)
+
+
 def _gram(kind: int, X, Z, params, noise, jitter):
     X, Z = _as2d(X), _as2d(Z)
     scale = _scalar(params["k_scale"], "k_scale")

@@ -36,6 +36,8 @@ typedef struct gpx_ctx gpx_ctx;
 #define GPX_KERNEL_MATERN52 1 /* gpax/kernels/kernels.py:68-91 */
 #define GPX_KERNEL_PERIODIC 2 /* gpax/kernels/kernels.py:94-117; `ell` then carries d + 1 values:
                                  the d lengthscales followed by the period (and gradients likewise) */
+#define GPX_KERNEL_R2 3       /* gpx_gram ONLY: the squared scaled distance itself, sum_k ((x_k - z_k) / ell_k)^2
+                               * (square_scaled_distance, gpax/kernels/kernels.py:28-41); scale is ignored */
 
 #define GPX_MAX_DIM 16 /* max input dimension d handled by the fused kernels */
 

@@ -51,6 +51,8 @@ class OracleEngine:
 
     def gram(self, kind, X, Z, ell, scale, diag_add, add_diag):
         X, Z = np.asarray(X, dtype=np.float64), np.asarray(Z, dtype=np.float64)
+        if kind == 3:  # GPX_KERNEL_R2: the squared scaled distance itself
+            return ref.square_scaled_distance(X, Z, np.asarray(ell, dtype=np.float64).reshape(-1))
         p = _params(kind, ell, X.shape[1], scale)
         K = ref.get_kernel(_NAMES[kind])(X, Z, p, noise=0.0, jitter=0.0)
         if add_diag:

@@ -26,6 +26,16 @@ def test_kernel_callables_on_gpu():
     p = {"k_length": np.array([1.0, 2.0]), "k_scale": 1.5}
     np.testing.assert_allclose(RBFKernel(X, X, p, noise=0.1), ref.RBFKernel(X, X, p, noise=0.1), rtol=1e-10)
     np.testing.assert_allclose(MaternKernel(X, X[:7], p), ref.MaternKernel(X, X[:7], p), rtol=1e-10, atol=1e-12)
+    # square_scaled_distance (kernels.py:28-41) by itself: the r^2 of the Gram kernels (GPX_KERNEL_R2), direct form — against
+    # the reference's clipped expansion, and exactly 0 (not -1e-16 clipped) on the diagonal of X against itself
+    from gpax_amd.kernels import square_scaled_distance
+    for ell in (0.7, np.array([1.0, 2.0])):
+        r2 = square_scaled_distance(X, X[:7], ell)
+        np.testing.assert_allclose(r2, ref.square_scaled_distance(X, X[:7], ell), rtol=1e-10, atol=1e-12)
+    assert np.all(np.diag(square_scaled_distance(X, X, 0.7)) == 0.0)
+    Z5 = rng.uniform(0, 5, (33, 5))  # generic d
+    np.testing.assert_allclose(square_scaled_distance(Z5, Z5[:4], 1.3), ref.square_scaled_distance(Z5, Z5[:4], 1.3),
+                               rtol=1e-10, atol=1e-12)
 
 
 def test_c1_exactgp_n512_fit_predict():

@@ -203,6 +203,12 @@ def test_kernel_callables_follow_the_protocol():
     K = RBFKernel(x1, x1, {"k_length": 1.0, "k_scale": 1.0}, noise=0.3, jitter=1e-6)
     Kr = ref.RBFKernel(x1, x1, {"k_length": 1.0, "k_scale": 1.0}, noise=0.3, jitter=1e-6)
     np.testing.assert_allclose(K, Kr, rtol=1e-12)
+    # square_scaled_distance (kernels.py:28-41): (n, m), scalar / ARD lengthscale, 1-D inputs, never negative
+    from gpax_amd.kernels import square_scaled_distance
+    r2 = square_scaled_distance(x1, x2[:3], np.array([1.0, 2.0]))
+    assert r2.shape == (5, 3) and np.all(r2 >= 0)
+    np.testing.assert_allclose(r2, ref.square_scaled_distance(x1, x2[:3], np.array([1.0, 2.0])), rtol=1e-12, atol=1e-14)
+    assert square_scaled_distance(x1[:, 0], x1[:, 0], 0.5).shape == (5, 5)
 
 
 def test_utils_match_reference_behaviour():
