@@ -79,3 +79,35 @@ def test_auto_priors_plug_into_a_model():
         assert {"a", "b"} <= set(s) and s["a"].shape == (15,)
     finally:
         _lib.set_engine(None)
+
+
+def _traced_site(program):
+    """The one site a prior program registers when a model traces it (the analogue of numpyro.handlers.trace in
+    gpax/tests/test_priors.py:42-88)."""
+    from gpax_amd.infer.primitives import trace_sites
+    sites, returned, _ = trace_sites(lambda: {"a": program()}, "test")
+    assert len(sites) == 1 and sites[0][0] == "a" and sites[0][1] == ()
+    return sites[0][2], returned["a"]
+
+
+@pytest.mark.parametrize("place", ["place_normal_prior", "place_halfnormal_prior", "place_lognormal_prior"])
+def test_place_prior_returns_a_value_inside_a_trace(place):  # test_priors.py:24-39
+    d, value = _traced_site(lambda: getattr(priors, place)("a"))
+    assert isinstance(value, np.ndarray) and np.isfinite(float(value))
+    with pytest.raises(RuntimeError):
+        getattr(priors, place)("a")  # there is no global tracer: outside a model's trace a site means nothing
+    assert np.isfinite(float(_traced_site(lambda: priors.place_uniform_prior("a", 0, 1))[1]))
+    assert np.isfinite(float(_traced_site(lambda: priors.place_gamma_prior("a", 2, 2))[1]))
+
+
+def test_place_prior_params():  # test_priors.py:42-88
+    d, _ = _traced_site(lambda: priors.place_normal_prior("a", loc=0.5, scale=0.1))
+    assert isinstance(d, dist.Normal) and (d.loc, d.scale) == (0.5, 0.1)
+    d, _ = _traced_site(lambda: priors.place_lognormal_prior("a", loc=0.5, scale=0.1))
+    assert isinstance(d, dist.LogNormal) and (d.loc, d.scale) == (0.5, 0.1)
+    d, _ = _traced_site(lambda: priors.place_halfnormal_prior("a", 0.1))
+    assert isinstance(d, dist.HalfNormal) and d.scale == 0.1
+    d, _ = _traced_site(lambda: priors.place_uniform_prior("a", low=0.5, high=1.0))
+    assert isinstance(d, dist.Uniform) and (d.low, d.high) == (0.5, 1.0)
+    d, _ = _traced_site(lambda: priors.place_gamma_prior("a", c=2.0, r=1.0))
+    assert isinstance(d, dist.Gamma) and (d.concentration, d.rate) == (2.0, 1.0)
