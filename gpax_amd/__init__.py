@@ -5,9 +5,9 @@ gpax_amd — MI355X-native exact-GP hot path behind the gpax API surface
 """
 from . import acquisition, kernels, priors, utils
 from .infer import dist
-from .infer.primitives import deterministic, plate, sample
+from .infer.primitives import deterministic, plate, sample, seed
 from .models import ExactGP, MeasuredNoiseGP, VarNoiseGP, vExactGP, viGP, viSparseGP
 
 __version__ = "0.1.0"
 __all__ = ["ExactGP", "vExactGP", "viGP", "viSparseGP", "MeasuredNoiseGP", "VarNoiseGP", "kernels", "priors", "utils", "acquisition", "dist",
-           "sample", "plate", "deterministic"]
+           "sample", "plate", "deterministic", "seed"]

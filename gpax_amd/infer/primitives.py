@@ -24,7 +24,7 @@ import numpy as np
 
 from . import dist as _dist
 
-__all__ = ["sample", "plate", "deterministic", "trace_sites", "SiteValue"]
+__all__ = ["sample", "plate", "deterministic", "trace_sites", "SiteValue", "seed"]
 
 _STACK: list = []
 
@@ -43,10 +43,32 @@ class SiteValue(np.ndarray):
 
 
 class _Tracer:
-    def __init__(self):
+    def __init__(self, rng=None):
         self.sites: List[Tuple[str, Tuple[int, ...], _dist.Distribution]] = []
         self.deterministic: Dict[str, float] = {}
         self.plates: List[Tuple[int, int]] = []  # (size, dim) of the active plates, dim < 0 as NumPyro counts them
+        self.rng = rng  # seed(): sites return draws of their distribution instead of its median
+
+
+class seed:
+    """numpyro.handlers.seed(rng_seed=...) for prior programs run by hand: inside the block `sample` DRAWS from the
+    site's distribution (a NumPy generator seeded with rng_seed) — what the reference's tests do with
+    `m._sample_kernel_params()` / `m._sample_noise()` (gpax/tests/test_gp.py:79-127).  `.sites` lists what was registered."""
+
+    def __init__(self, rng_seed=0):
+        self._tr = _Tracer(np.random.default_rng(rng_seed))
+
+    def __enter__(self):
+        _STACK.append(self._tr)
+        return self
+
+    def __exit__(self, *exc):
+        _STACK.pop()
+        return False
+
+    @property
+    def sites(self):
+        return list(self._tr.sites)
 
 
 def _plate_shape(plates) -> Tuple[int, ...]:
@@ -76,6 +98,8 @@ def sample(name: str, fn, obs=None, **kwargs):
         raise ValueError(f"site {name!r} sampled twice")
     shape = _plate_shape(tr.plates)
     tr.sites.append((name, shape, fn))
+    if tr.rng is not None:  # under seed(): a draw
+        return SiteValue(np.asarray(fn.sample(tr.rng, shape), dtype=np.float64), name)
     med = np.full(shape, float(fn.median())) if shape else float(fn.median())
     return SiteValue(med, name)
 

@@ -601,6 +601,31 @@ def test_default_priors_are_overridable_programs_like_the_references():
     assert abs(u.model(X, None, params={"k_length": np.array([0.9]), "noise": 0.2}) - lp) < 1e-12
 
 
+@pytest.mark.parametrize("kernel", ["RBF", "Matern", "Periodic"])
+def test_sample_kernel_and_noise_programs_by_hand(kernel):
+    """gpax/tests/test_gp.py:79-127 (test_sample_kernel, test_sample_periodic_kernel, test_sample_noise and the two
+    custom-prior tests): the default prior programs run by hand under a seed handler return arrays — draws, which change
+    with the prior handed to the constructor."""
+    import gpax_amd
+    m = ExactGP(1, kernel)
+    with gpax_amd.seed(rng_seed=1):
+        kernel_params = m._sample_kernel_params()
+    period = kernel_params.pop("period")
+    assert (period is not None) == (kernel == "Periodic")
+    for k, v in kernel_params.items():
+        assert k in ("k_length", "k_scale") and isinstance(v, np.ndarray)
+    with gpax_amd.seed(rng_seed=1):
+        noise1 = m._sample_noise()
+    with gpax_amd.seed(rng_seed=1):
+        noise2 = ExactGP(1, kernel, noise_prior_dist=dist.HalfNormal(0.1))._sample_noise()
+    assert isinstance(noise1, np.ndarray) and not np.array_equal(noise1, noise2)
+    with gpax_amd.seed(rng_seed=1):
+        l1 = m._sample_kernel_params()["k_length"]
+    with gpax_amd.seed(rng_seed=1):
+        l2 = ExactGP(1, kernel, lengthscale_prior_dist=dist.Normal(20, 0.1))._sample_kernel_params()["k_length"]
+    assert not np.array_equal(l1, l2) and abs(float(l2[0]) - 20) < 1.0
+
+
 def test_place_prior_helpers_inside_a_mean_fn_prior():
     """priors.py:18-68 with the import swapped: the place_*_prior helpers register their site with the model's trace."""
     from gpax_amd import priors
