@@ -92,6 +92,13 @@ python tools/gram_bench.py > $O/gram.json 2> $O/gram.err
 run gram_write "python tools/gram_bench.py" --kernel-trace --pmc WRITE_SIZE
 run gram_fetch "python tools/gram_bench.py" --kernel-trace --pmc FETCH_SIZE
 python tools/fit_small_bench.py > $O/fit_small.json 2> $O/fit_small.log
+# round 6: the fused chain step (potf2 + panel TRSM in one launch) against the three-launch step, its per-phase stamps (trace
+# build), and NUTS through the model API with the transition loop in Python / in the library
+python tools/potf2_trsm_ab.py > $O/potf2_trsm_ab.txt 2>&1
+if [ -f gpax_amd/lib/libgpx_trace.so ]; then
+  GPX_LIB=gpax_amd/lib/libgpx_trace.so timeout 300 python tools/potf2_trsm_trace.py 2048 4096 5120 > $O/potf2_trsm_trace.txt 2>&1
+fi
+python tools/nuts_native_time.py > $O/nuts_native_time.txt 2>&1
 python tools/lat_gemm_bench.py > $O/lat_gemm.json 2> $O/lat_gemm.txt
 for N in 25 128 512 2048 4096; do
   rm -rf /tmp/prof_sn$N
